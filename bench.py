@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""inferfps bench of the MI355X-native Wav2Lip-256 render hot path.
+
+A "step" is one `LipReal.inference_batch`-equivalent pass (bank gather + mask +
+pack, the 55 conv/convT layers, sigmoid*255 + uint8 truncation) over one batch
+of B=16 frames per session, with the avatar bank, the weights and the mel
+windows already resident in HBM (avatars/base_avatar.py:364-373 defines
+inferfps as frames / wall time of inference_batch).  BASELINE.json configs[1]:
+wav2lip256, 1 session, 16-frame batch, fp16 on 1x MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sessions S] [--batch B]
+
+N>1 is launched by torch.distributed.run (one rank per GPU, RCCL only for the
+barrier / max-over-ranks reduction; sessions are independent, so the data path
+has no collective).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MACS_PER_FRAME = 27_788_599_296       # SURVEY.md Appendix A (conv + convT + head)
+HEAD_MACS = 32 * 3 * 65536
+PEAK_F16_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+
+
+def cpu_baseline(batch: int, budget_s: float = 20.0):
+    """The oracle restatement of LipReal.inference_batch (fp32, torch CPU) on the
+    host cores, bounded sample."""
+    import numpy as np
+    import torch
+    from oracle import mel_oracle, plugin_oracle, synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(1234).items()}
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=8, full_hw=(360, 640), box=160, seed=0)
+    audio = synth.synthetic_audio(2.0)
+    feats = mel_oracle.mel_chunks(audio[: (20 + 2 * batch) * 320], 20 + 2 * batch)
+    plugin_oracle.inference_batch(sd, faces, 0, 1, feats[:1])  # warm-up (B=1)
+    n, t_total = 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        plugin_oracle.inference_batch(sd, faces, n * batch, batch, feats)
+        t_total += time.perf_counter() - t0
+        n += 1
+        if t_total >= budget_s * 0.5 or n >= 4:
+            break
+    return {"value": round(n * batch / t_total, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} x inference_batch(B={batch}) fp32 torch-CPU oracle, seeded synthetic weights/bank/audio"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sessions", type=int, default=1, help="sessions coalesced per launch on each GPU")
+    ap.add_argument("--batch", type=int, default=16, help="frames per session per step (opt.batch_size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+
+    from livetalking_amd.engine import Engine
+    from oracle import synth  # seeded synthetic inputs only (generators, not the oracle path)
+
+    S, B = args.sessions, args.batch
+    frames_per_step = S * B
+    eng = Engine(local_rank)
+    eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=frames_per_step)
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
+    aid = eng.register_avatar(faces, frames, coords)
+    # mel windows resident in HBM: one (B,80,16) block per session, made by the HIP mel kernel
+    audio = synth.synthetic_audio(4.0)
+    n_chunks = 20 + 2 * B
+    starts = [int(16 + i * 3.2) for i in range(B)]
+    d_mel = torch.zeros(S, B, 80, 16, dtype=torch.float32, device="cuda")
+    for s in range(S):
+        off = (s * 977) % (len(audio) - n_chunks * 320)
+        eng.mel_step(audio[off: off + n_chunks * 320], starts, d_mel[s].data_ptr())
+    d_pred = torch.zeros(frames_per_step, 256, 256, 3, dtype=torch.uint8, device="cuda")
+
+    def step(i):
+        reqs = [(aid, i * B + 7 * s, B, d_mel[s].data_ptr()) for s in range(S)]
+        eng.wav2lip_infer(reqs, d_pred.data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = world * args.steps * frames_per_step
+    value = total_frames / elapsed
+
+    # dominant kernel family (conv_mfma_kernel): HIP events on the engine's stream around the
+    # conv stack only (no gather/pack, no head), averaged over launches of the same workload
+    conv_ms, conv_macs = eng.time_convs(frames_per_step, 10)
+    achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "inferfps",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"wav2lip256, {S} session(s)/GPU, {B}-frame batch, fp16 activations / fp32 accumulate",
+                       "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": f"session-sharded x{world} (no collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
+                         "kernel": "conv_mfma_kernel (54 launches per pass)",
+                         "conv_stack_ms": round(conv_ms, 4), "flops_per_frame": 2 * (MACS_PER_FRAME - HEAD_MACS)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

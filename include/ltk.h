@@ -1,0 +1,131 @@
+/*
+ * libltk_hip.so - MI355X (gfx950) native lip-sync render hot path.
+ *
+ * C ABI: plain pointers and sizes, no torch types.  Every function returns 0 on
+ * success or a negative LTK_E_* code; ltk_last_error() returns a thread-local
+ * message.  All entry points are thread-safe (the reference calls
+ * inference_batch / paste_back_frame / run_step from three threads per session,
+ * avatars/base_avatar.py:475-481).  Device pointers and streams come from the
+ * host runtime (PyTorch-ROCm: tensor.data_ptr(), torch.cuda.current_stream()
+ * .cuda_stream) or are owned by the engine; `stream` is a hipStream_t passed as
+ * void* (NULL = the engine's own stream).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the upstream LiveTalking checkout).
+ */
+#ifndef LTK_H
+#define LTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTK_OK 0
+#define LTK_E_INVALID (-1)   /* bad argument / shape / missing tensor */
+#define LTK_E_HIP (-2)       /* a HIP runtime call failed */
+#define LTK_E_STATE (-3)     /* call order (model not loaded, avatar unknown, ...) */
+#define LTK_E_NOMEM (-4)
+
+typedef struct ltk_engine ltk_engine;
+
+/* One named fp32 host tensor of a PyTorch state_dict (row-major, torch layout). */
+typedef struct ltk_named_tensor {
+    const char* name;
+    const float* data;
+    int ndim;
+    const int64_t* shape;
+} ltk_named_tensor;
+
+/* One session's request inside a cross-session batch: `batch` consecutive
+ * frames starting at running frame index `index` (ping-pong `mirror_index`
+ * over the avatar's bank, utils/image.py:26-32), mel windows at d_mel. */
+typedef struct ltk_w2l_req {
+    int avatar;            /* id returned by ltk_avatar_register */
+    int index;             /* BaseAvatar.inference's running `index` (base_avatar.py:328,366) */
+    int batch;             /* frames in this request (opt.batch_size) */
+    const void* d_mel;     /* device, float32 [batch][80][16] (what ltk_mel_step wrote) */
+} ltk_w2l_req;
+
+const char* ltk_last_error(void);
+const char* ltk_version(void);
+
+/* utils/device.py:4-10 initialize_device + per-process model ownership
+ * (app.py:62,140-151): one engine per GPU. */
+int ltk_engine_create(int device, ltk_engine** out);
+void ltk_engine_destroy(ltk_engine* e);
+int ltk_engine_sync(ltk_engine* e);
+
+/* avatars/wav2lip_avatar.py:59-70 load_model: takes checkpoint["state_dict"]
+ * (380 fp32 tensors, names as in avatars/wav2lip/models/wav2lip_v2.py with any
+ * "module." prefix already stripped), folds eval-mode BatchNorm
+ * (conv.py:7-10,36-39) into per-channel scale/shift, repacks the conv kernels
+ * to fp16 MFMA tiles and sizes the activation arena for `max_frames` frames
+ * per launch (the sum of all requests of one ltk_wav2lip_infer call). */
+int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_frames);
+
+/* avatars/wav2lip_avatar.py:72-88 load_avatar: uploads one avatar bank.
+ * face_bank  uint8 [n][256][256][3] BGR (face_imgs/), full_bank uint8
+ * [n][H][W][3] BGR (full_imgs/), coords int32 [n][4] = (y1,y2,x1,x2)
+ * (coords.pkl, avatars/wav2lip/genavatar.py:130).  Host pointers. */
+int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* full_bank,
+                        const int32_t* coords, int n, int H, int W, int* avatar_id);
+int ltk_avatar_release(ltk_engine* e, int avatar_id);
+
+/* avatars/audio_features/mel.py:43-63 (MelASR.run_step feature part) +
+ * avatars/wav2lip/audio.py:45-51 melspectrogram: `n_samples` PCM samples (the
+ * concatenated l + 2B + r 20-ms chunks, host float32) -> `n_win` windows of
+ * (80,16) float32 written to d_out [n_win][80][16]; window i starts at STFT
+ * column win_start[i] (mel.py:56).  hop 200 / n_fft 800 / 80 mels
+ * (avatars/wav2lip/hparams.py:33-73). */
+int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* win_start,
+                 int n_win, void* d_out, void* stream);
+
+/* avatars/wav2lip_avatar.py:116-139 LipReal.inference_batch for `nreq`
+ * sessions at once: bank gather + lower-half mask + 6-channel pack, the 55
+ * conv/convT layers of Wav2Lip.forward (wav2lip_v2.py:123-163), sigmoid*255 and
+ * the uint8 truncation paste_back_frame applies (wav2lip_avatar.py:138,145).
+ * d_pred_u8: device uint8 [sum(batch)][256][256][3] BGR, request-major. */
+int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* d_pred_u8, void* stream);
+
+/* avatars/wav2lip_avatar.py:141-147 LipReal.paste_back_frame: bilinear-resize
+ * (cv2.resize INTER_LINEAR semantics) the 256x256 prediction to the frame's box
+ * and paste it into a copy of full_bank[idx].  d_pred: device uint8
+ * [256][256][3].  out: uint8 [H][W][3]; out_is_device selects a device buffer
+ * or a (pinned or pageable) host buffer. */
+int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out,
+                   int out_is_device, void* stream);
+
+/* ---- test / measurement hooks (not on the production call path) ---- */
+
+/* Run Wav2Lip.forward on explicit inputs: mel host float32 [B][80][16], face6
+ * host float32 [B][6][256][256] in [0,1] (as wav2lip_avatar.py:133-134 builds
+ * them); pred host float32 [B][3][256][256] = sigmoid output (before *255). */
+int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6, int B, float* pred);
+
+/* After a forward with capture enabled, copy one layer's activation
+ * (state_dict prefix, e.g. "face_encoder_blocks.1.0") as NCHW float32. */
+int ltk_debug_capture(ltk_engine* e, int enable);
+int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats);
+
+/* Conv-stack only (no gather/pack, no head): used by bench.py to time the
+ * dominant kernel family with HIP events.  Returns average milliseconds per
+ * pass over `iters` passes of `frames` frames, and the number of conv/convT
+ * MACs one pass executes (27,788,599,296 x frames for wav2lip256). */
+int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
+
+/* Generic standalone NHWC fp16 conv used by kernel unit tests: x device fp16
+ * [N][H][W][Cin], weight host fp32 torch layout ([Cout][Cin][kh][kw], or
+ * [Cin][Cout][kh][kw] when transposed), scale/shift host fp32 [Cout], res
+ * device fp16 [N][Ho][Wo][Cout] or NULL, y device fp16 [N][Ho][Wo][Cout]. */
+int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
+                   const float* weight, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                   int transposed, int out_pad, const float* scale, const float* shift,
+                   const void* d_res, int relu, void* d_y, int iters, float* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTK_H */

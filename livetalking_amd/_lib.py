@@ -1,0 +1,78 @@
+"""ctypes binding of libltk_hip.so (include/ltk.h).
+
+The HIP library IS the product path: importing this module without the built
+shared object raises, there is no CPU/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libltk_hip.so")
+
+
+class LtkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ltk error {code}: {msg}")
+        self.code = code
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int),
+                ("shape", C.POINTER(C.c_int64))]
+
+
+class W2lReq(C.Structure):
+    _fields_ = [("avatar", C.c_int), ("index", C.c_int), ("batch", C.c_int), ("d_mel", C.c_void_p)]
+
+
+# every symbol include/ltk.h declares: (restype, argtypes)
+SYMBOLS = {
+    "ltk_last_error": (C.c_char_p, []),
+    "ltk_version": (C.c_char_p, []),
+    "ltk_engine_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ltk_engine_destroy": (None, [C.c_void_p]),
+    "ltk_engine_sync": (C.c_int, [C.c_void_p]),
+    "ltk_wav2lip_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int, C.c_int]),
+    "ltk_avatar_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_int)]),
+    "ltk_avatar_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltk_mel_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p, C.c_void_p]),
+    "ltk_paste_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "ltk_wav2lip_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "ltk_conv2d_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                 C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C livetalking_amd/csrc`). livetalking_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ltk_last_error()
+        raise LtkError(rc, msg.decode("utf-8", "replace") if msg else "")

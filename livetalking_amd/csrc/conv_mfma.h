@@ -1,0 +1,95 @@
+// Implicit-GEMM NHWC fp16 convolution on gfx950 MFMA (v_mfma_f32_32x32x16_f16).
+// Host-side plan + launch interface.  See conv_mfma.hip for the kernel and
+// DESIGN.md §Kernels for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace ltk {
+
+typedef _Float16 f16;
+
+constexpr int kConvBM = 256;       // output pixels per workgroup (4 waves x 64)
+constexpr int kMaxTaps = 52;       // 7x7 = 49 (+ pairing pad)
+constexpr int kMaxPhases = 4;      // sub-pixel phases of a stride-2 transposed conv
+
+// One sub-pixel phase of a (transposed) convolution: a tap list over the input
+// patch, its own packed weight slab and output pixel offset.
+struct ConvPhase {
+    int T;                  // taps
+    int ooy, oox;           // output pixel = (oy*osy + ooy, ox*osx + oox)
+    int w_off16;            // offset of this phase's packed weights, in 16-byte units
+    short tapoff[kMaxTaps]; // dy*PW + dx per tap (patch-pixel units); unused entries 0
+};
+
+struct ConvArgs {
+    const f16* x;           // input NHWC, pixel stride x_ld halfs, channels [x_coff, x_coff+Cin)
+    const f16* w;           // packed weights (see pack_weights)
+    const float* scale;     // [Cout] folded BN scale
+    const float* shift;     // [Cout] folded BN shift (+conv bias)
+    const f16* res;         // residual (same pixel mapping as y) or nullptr
+    f16* y;                 // output NHWC
+    int N, H, W;
+    int x_ld, x_coff;
+    int Ho, Wo;             // logical output grid one phase covers
+    int y_ld, y_coff, HoA, WoA, osy, osx;
+    int res_ld, res_coff;
+    int Cin8;               // Cin / 8 (channel planes of 8 halfs)
+    int Cout;
+    int sh, sw, pad_y, pad_x;
+    int PH, PW;             // input patch per image tile
+    int NPIXP;              // padded pixels per LDS channel plane
+    int log2TW, log2TH, NB; // tile = NB images x TH x TW output pixels (<= 256)
+    int tiles_x, tiles_y, tiles_n, n_ntiles, nphase;
+    unsigned magicPW, magicPHW;
+    int nchunks;            // ceil(Cin8 / NC8)
+    int Tp;                 // taps per packed chunk slab (T, or T rounded up to even when NC8==1)
+    int relu;
+    ConvPhase ph[kMaxPhases];
+};
+
+// Static description of a conv layer (weights already packed on device).
+struct ConvPlan {
+    // geometry
+    int Cin = 0, Cout = 0, CoutPad = 0;   // CoutPad: multiple of BN
+    int kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0;
+    bool transposed = false;              // ConvTranspose2d
+    int out_pad = 0;
+    bool gemm_1x1_expand = false;         // convT k x k on a 1x1 map == 1x1 conv to k*k*Cout channels
+    // kernel config
+    int NC8 = 4, NBT = 2;                 // channel planes per chunk, 32-cout subtiles per block
+    bool tt9 = false;                     // 3x3 taps compiled in
+    int nphase = 1;
+    int Tp = 0;
+    ConvPhase phase[kMaxPhases];
+    // device data
+    f16* d_w = nullptr;
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+    size_t w_bytes = 0;
+    double macs_per_image(int H, int W) const;
+    void out_dims(int H, int W, int* Ho, int* Wo) const;
+};
+
+// Build a plan: choose kernel configuration, pack weights (fp32 torch layout ->
+// fp16 [ntile][chunk][tap][plane][cout][8]) and upload.  `weight` is
+// [Cout][Cin][kh][kw] (conv) or [Cin][Cout][kh][kw] (transposed).
+// Cin is padded up to a multiple of 8 with zero weights (CinPad = plan.Cin).
+int conv_plan_create(ConvPlan* p, const float* weight, int Cin, int Cout, int kh, int kw,
+                     int sh, int sw, int ph, int pw, bool transposed, int out_pad,
+                     const float* scale, const float* shift, std::string* err);
+void conv_plan_destroy(ConvPlan* p);
+
+struct ConvIO {
+    const f16* x; int N, H, W; int x_ld, x_coff;
+    f16* y; int y_ld, y_coff;
+    const f16* res; int res_ld, res_coff;
+    int relu;
+};
+
+// Enqueue the layer on `stream`.  Returns 0 or a negative error (message in *err).
+int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err);
+
+}  // namespace ltk

@@ -1,0 +1,581 @@
+// Implicit-GEMM NHWC fp16 convolution for gfx950 (CDNA4) on MFMA.
+//
+// Replaces the torch.nn.Conv2d / ConvTranspose2d + BatchNorm2d(eval) + residual
+// + ReLU blocks of the reference generator (avatars/wav2lip/models/conv.py:5-44,
+// instantiated at avatars/wav2lip/models/wav2lip_v2.py:12-91).
+//
+// Mapping (one workgroup = 4 waves = 256 output pixels x BN output channels):
+//   * the input patch a tile needs ((TH-1)*s+k rows x (TW-1)*s+k cols, zero padded
+//     at the image border) is staged ONCE per 16/32-channel chunk into LDS as
+//     channel planes [c8][patch pixel][8 halfs]; all k*k taps then read their
+//     operand from that patch at a shifted address, so a 3x3 layer reads its
+//     input once from HBM/L2 instead of nine times;
+//   * weights are pre-packed on the host in LDS image order
+//     [cout tile][chunk][tap][c8][cout][8 halfs], so a chunk's slab is one
+//     contiguous, fully coalesced copy;
+//   * v_mfma_f32_32x32x16_f16 with the WEIGHTS as the row operand and the PIXELS
+//     as the column operand: a lane's 16 accumulators then are 4 groups of 4
+//     consecutive output channels of ONE pixel -> 8-byte NHWC stores, and the
+//     folded BN scale/shift, residual add and ReLU are applied in registers;
+//   * channel-offset reads/writes (x_ld/x_coff, y_ld/y_coff) make the decoder's
+//     torch.cat skip connections (wav2lip_v2.py:146) free;
+//   * ConvTranspose2d(k3,s2,p1,op1) runs as its 4 sub-pixel phases (1/2/2/4
+//     taps over a 2x2 input neighbourhood) in one launch: no zero-insertion.
+//
+// LDS (dynamic, one array - keeps hipcc from draining vmcnt per k-step):
+//   [2 x A planes][2 x B slab][tap table]
+#include "conv_mfma.h"
+
+#include <hip/hip_fp16.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace ltk {
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PhaseMeta {
+    int T, ooy, oox, w_off16;
+    signed char dy[kMaxTaps], dx[kMaxTaps];
+};
+
+struct KArgs {
+    const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
+    const PhaseMeta* phases;
+    int N, H, W, x_ld, x_coff;
+    int Ho, Wo, y_ld, y_coff, HoA, WoA, osy, osx;
+    int res_ld, res_coff;
+    int Cin8, Cout;
+    int sh, sw, pad_y, pad_x;
+    int PH, PW, NPIXP;
+    int log2TW, log2TH, NB;
+    int tiles_x, tiles_y, tiles_n, n_ntiles;
+    unsigned magicPW, magicPHW;
+    int nchunks, Tp, relu;
+};
+
+__host__ __device__ constexpr int max_a_items(int NC8, int NBT) {
+    return NC8 == 4 ? 6 : (NC8 == 1 ? 5 : (NBT == 4 ? 3 : 10));
+}
+constexpr int kMaxBItems = 9;
+constexpr int kTapTableBytes = 128;
+constexpr int kLdsLimit = 160 * 1024;
+
+template <int NC8, int NBT, bool TT9>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BN = NBT * 32;
+    constexpr int MAXA = max_a_items(NC8, NBT);
+    constexpr int MAXB = kMaxBItems;
+    constexpr int LOG2NC8 = NC8 == 4 ? 2 : (NC8 == 2 ? 1 : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    // ---- block -> (phase, image tile, y tile, x tile, cout tile); consecutive
+    // logical ids (same pixel tile, different cout tiles) share an XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int ntile = bid % a.n_ntiles;
+    int t0 = bid / a.n_ntiles;
+    const int tx_t = t0 % a.tiles_x; t0 /= a.tiles_x;
+    const int ty_t = t0 % a.tiles_y; t0 /= a.tiles_y;
+    const int tn_t = t0 % a.tiles_n;
+    const int phase = t0 / a.tiles_n;
+
+    const PhaseMeta* __restrict__ pm = a.phases + phase;
+    const int T = pm->T;
+    const int ooy = pm->ooy, oox = pm->oox;
+
+    const int A_BYTES = NC8 * a.NPIXP * 16;
+    const int B_BYTES = a.Tp * NC8 * BN * 16;
+    unsigned char* const smemA = smem;
+    unsigned char* const smemB = smem + 2 * A_BYTES;
+    short* const tapl = reinterpret_cast<short*>(smem + 2 * A_BYTES + 2 * B_BYTES);
+
+    if (tid < kMaxTaps) {
+        short v = 0;
+        if (tid < T) v = (short)(pm->dy[tid] * a.PW + pm->dx[tid]);
+        tapl[tid] = v;
+    }
+
+    const int TWm = (1 << a.log2TW) - 1, THm = (1 << a.log2TH) - 1;
+    const int tx0 = tx_t << a.log2TW, ty0 = ty_t << a.log2TH, n0 = tn_t * a.NB;
+    const int iy0 = ty0 * a.sh - a.pad_y, ix0 = tx0 * a.sw - a.pad_x;
+    const int PHW = a.PH * a.PW;
+    const int nitemsA = a.NB * PHW * NC8;
+
+    // ---- A staging descriptors (chunk independent)
+    int a_goff[MAXA];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        const int i = tid + k * 256;
+        const int pix = i >> LOG2NC8;
+        const int c8 = i & (NC8 - 1);
+        // exact for pix < 2^16; a divisor of 1 has no 32-bit magic
+        const int b = (PHW == 1) ? pix : (int)__umulhi((unsigned)pix, a.magicPHW);
+        const int rem = pix - b * PHW;
+        const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
+        const int px = rem - py * a.PW;
+        const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
+        const bool ok = (i < nitemsA) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
+        a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + c8 * 8) : -1;
+    }
+
+    const int slab = a.Tp * NC8 * BN;  // 16-byte items per (cout tile, chunk)
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + pm->w_off16 + (size_t)ntile * a.nchunks * slab;
+
+    uint4 ra[MAXA];
+    uint4 rb[MAXB];
+
+    auto load_chunk = [&](int c) {
+        const int cbase = c * NC8;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            const int c8 = (tid + k * 256) & (NC8 - 1);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (a_goff[k] >= 0 && cbase + c8 < a.Cin8)
+                v = *reinterpret_cast<const uint4*>(a.x + a_goff[k] + cbase * 8);
+            ra[k] = v;
+        }
+        const uint4* ws = wsrc + (size_t)c * slab;
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) {
+            const int i = tid + k * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < slab) v = ws[i];
+            rb[k] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* Ab = smemA + buf * A_BYTES;
+        unsigned char* Bb = smemB + buf * B_BYTES;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            const int i = tid + k * 256;
+            if (i < nitemsA) {
+                const int pix = i >> LOG2NC8, c8 = i & (NC8 - 1);
+                *reinterpret_cast<uint4*>(Ab + (c8 * a.NPIXP + pix) * 16) = ra[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) {
+            const int i = tid + k * 256;
+            if (i < slab) *reinterpret_cast<uint4*>(Bb + i * 16) = rb[k];
+        }
+    };
+
+    // ---- per-lane operand bases: this lane's output pixel in each 32-pixel subtile
+    int pixb[2];
+    bool rowok[2];
+    int orow[2];  // output pixel linear index (n, oyA, oxA) or -1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = wave * 64 + j * 32 + l31;
+        const int tx = m & TWm;
+        const int ty = (m >> a.log2TW) & THm;
+        const int b = m >> (a.log2TW + a.log2TH);
+        const bool inb = b < a.NB;
+        pixb[j] = inb ? ((b * a.PH + ty * a.sh) * a.PW + tx * a.sw) * 16 : 0;
+        const int n = n0 + b, oy = ty0 + ty, ox = tx0 + tx;
+        rowok[j] = inb && n < a.N && oy < a.Ho && ox < a.Wo;
+        orow[j] = (n * a.HoA + oy * a.osy + ooy) * a.WoA + ox * a.osx + oox;
+    }
+
+    f32x16 acc[NBT][2];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int PS = a.NPIXP * 16;
+    const int nchunks = a.nchunks;
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        const bool more = (c + 1) < nchunks;
+        if (more) load_chunk(c + 1);
+
+        const unsigned char* Ab = smemA + cur * A_BYTES;
+        const unsigned char* Bb = smemB + cur * B_BYTES;
+        if constexpr (NC8 == 1) {
+            // 8-channel input: one MFMA k16 step = two taps (lanes 0-31 tap 2s, lanes 32-63 tap 2s+1)
+            const int nsteps = a.Tp >> 1;
+            for (int s = 0; s < nsteps; ++s) {
+                const int tp = 2 * s + hh;
+                const int toff = (int)tapl[tp] * 16;
+                f16x8 xa[2], wf[NBT];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ab + pixb[j] + toff);
+#pragma unroll
+                for (int i = 0; i < NBT; ++i) wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((tp * BN) + i * 32 + l31) * 16);
+#pragma unroll
+                for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xa[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int planes = min(NC8, a.Cin8 - c * NC8);
+            auto tap_body = [&](int t, int toff) {
+#pragma unroll
+                for (int q = 0; q < NC8 / 2; ++q) {
+                    if (2 * q < planes) {
+                        const int plane = 2 * q + hh;
+                        f16x8 xa[2], wf[NBT];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ab + plane * PS + pixb[j] + toff);
+#pragma unroll
+                        for (int i = 0; i < NBT; ++i)
+                            wf[i] = *reinterpret_cast<const f16x8*>(Bb + (((t * NC8 + plane) * BN) + i * 32 + l31) * 16);
+#pragma unroll
+                        for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xa[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            };
+            if constexpr (TT9) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) tap_body(t, ((t / 3) * a.PW + (t % 3)) * 16);
+            } else {
+                for (int t = 0; t < T; ++t) tap_body(t, (int)tapl[t] * 16);
+            }
+        }
+
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = acc*scale + shift (+res) (relu) -> fp16, 4 channels (8 B) per store
+    const int cout0 = ntile * BN;
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = cout0 + i * 32 + 8 * g + 4 * hh;
+            if (co < a.Cout) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + co);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (rowok[j]) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * sc[r] + sf[r];
+                        if (a.res) {
+                            const f16x4 rr = *reinterpret_cast<const f16x4*>(a.res + (size_t)orow[j] * a.res_ld + a.res_coff + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                        }
+                        f16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = v[r];
+                            if (a.relu) t = fmaxf(t, 0.f);
+                            t = fminf(fmaxf(t, -65504.f), 65504.f);
+                            o[r] = (f16)t;
+                        }
+                        *reinterpret_cast<f16x4*>(a.y + (size_t)orow[j] * a.y_ld + a.y_coff + co) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+typedef void (*conv_kernel_t)(const KArgs);
+
+template <int NC8, int NBT, bool TT9>
+static conv_kernel_t kptr() { return conv_mfma_kernel<NC8, NBT, TT9>; }
+
+static conv_kernel_t pick_kernel(int NC8, int NBT, bool tt9) {
+    if (NC8 == 1) return NBT == 1 ? kptr<1, 1, false>() : nullptr;
+    if (NC8 == 2) {
+        if (NBT == 1) return tt9 ? kptr<2, 1, true>() : kptr<2, 1, false>();
+        if (NBT == 2) return tt9 ? kptr<2, 2, true>() : kptr<2, 2, false>();
+        if (NBT == 4) return tt9 ? kptr<2, 4, true>() : kptr<2, 4, false>();
+    }
+    if (NC8 == 4) {
+        if (NBT == 1) return tt9 ? kptr<4, 1, true>() : kptr<4, 1, false>();
+        if (NBT == 2) return tt9 ? kptr<4, 2, true>() : kptr<4, 2, false>();
+        if (NBT == 4) return tt9 ? nullptr : kptr<4, 4, false>();
+    }
+    return nullptr;
+}
+
+static int ceil_log2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+void ConvPlan::out_dims(int H, int W, int* Ho, int* Wo) const {
+    if (!transposed) {
+        *Ho = (H + 2 * ph - kh) / sh + 1;
+        *Wo = (W + 2 * pw - kw) / sw + 1;
+    } else {
+        *Ho = (H - 1) * sh - 2 * ph + kh + out_pad;
+        *Wo = (W - 1) * sw - 2 * pw + kw + out_pad;
+    }
+}
+
+double ConvPlan::macs_per_image(int H, int W) const {
+    int Ho, Wo;
+    out_dims(H, W, &Ho, &Wo);
+    if (!transposed) return (double)Cout * kh * kw * Ho * Wo;  // x real Cin applied by caller
+    return (double)Cout * kh * kw * H * W;
+}
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(_e);        \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, int kh, int kw,
+                     int sh, int sw, int ph, int pw, bool transposed, int out_pad,
+                     const float* scale, const float* shift, std::string* err) {
+    *p = ConvPlan();
+    const int Cin = (CinReal + 7) / 8 * 8;
+    p->kh = kh; p->kw = kw; p->sh = sh; p->sw = sw; p->ph = ph; p->pw = pw;
+    p->transposed = transposed; p->out_pad = out_pad;
+    p->Cin = Cin; p->Cout = Cout;
+
+    // logical conv the kernel executes
+    int lCout = Cout;        // output channels of the executed conv
+    int lsh = sh, lsw = sw;  // input stride
+    struct Tap { int ky, kx, dy, dx; };
+    std::vector<std::vector<Tap>> phases;
+    std::vector<std::pair<int, int>> phase_off;
+    if (!transposed) {
+        std::vector<Tap> taps;
+        for (int y = 0; y < kh; ++y)
+            for (int x = 0; x < kw; ++x) taps.push_back({y, x, y, x});
+        phases.push_back(taps);
+        phase_off.push_back({0, 0});
+    } else if (sh == 1 && sw == 1 && ph == 0 && pw == 0 && out_pad == 0) {
+        // k x k transposed conv: only the 1x1-input case is supported (a GEMM to k*k*Cout channels)
+        p->gemm_1x1_expand = true;
+        lCout = kh * kw * Cout;
+        phases.push_back({{0, 0, 0, 0}});
+        phase_off.push_back({0, 0});
+    } else if (kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && out_pad == 1) {
+        lsh = lsw = 1;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                std::vector<std::pair<int, int>> ys, xs;  // (k index, input offset)
+                if (py == 0) ys = {{1, 0}}; else ys = {{0, 1}, {2, 0}};
+                if (px == 0) xs = {{1, 0}}; else xs = {{0, 1}, {2, 0}};
+                std::vector<Tap> taps;
+                for (auto& yy : ys)
+                    for (auto& xx : xs) taps.push_back({yy.first, xx.first, yy.second, xx.second});
+                phases.push_back(taps);
+                phase_off.push_back({py, px});
+            }
+    } else {
+        if (err) *err = "unsupported transposed conv configuration";
+        return -1;
+    }
+
+    const int Cin8 = Cin / 8;
+    int NC8, NBT;
+    const int Tmax = (int)std::max_element(phases.begin(), phases.end(),
+                                           [](const std::vector<Tap>& a, const std::vector<Tap>& b) { return a.size() < b.size(); })->size();
+    if (Cin8 == 1) {
+        NC8 = 1; NBT = 1;
+        if (lCout > 32) { if (err) *err = "Cin<=8 layers support Cout<=32"; return -1; }
+    } else {
+        if (Cin8 % 2) { if (err) *err = "Cin must be 8 or a multiple of 16"; return -1; }
+        NBT = lCout >= 128 ? 4 : (lCout >= 64 ? 2 : 1);
+        const bool strided = (lsh > 1 || lsw > 1);
+        if (strided) { NC8 = 2; NBT = std::min(NBT, 2); }
+        else if (Tmax > 9) { NC8 = 2; NBT = std::min(NBT, 2); }
+        else if (Tmax == 9 && NBT == 4) NC8 = 2;
+        else NC8 = (Cin8 >= 4) ? 4 : 2;
+    }
+    const int BN = NBT * 32;
+    p->NC8 = NC8; p->NBT = NBT;
+    p->tt9 = (!transposed && kh == 3 && kw == 3 && NC8 >= 2);
+    p->nphase = (int)phases.size();
+    const int Tp = (NC8 == 1) ? ((Tmax + 1) / 2 * 2) : Tmax;
+    p->Tp = Tp;
+    if (Tp * NC8 * BN > kMaxBItems * 256) { if (err) *err = "weight slab too large for staging registers"; return -1; }
+    if (!pick_kernel(NC8, NBT, p->tt9)) { if (err) *err = "no kernel instantiation for this configuration"; return -1; }
+
+    const int CoutPad = (lCout + BN - 1) / BN * BN;
+    p->CoutPad = CoutPad;
+    const int n_ntiles = CoutPad / BN;
+    const int nchunks = (Cin8 + NC8 - 1) / NC8;
+    const size_t slab_halfs = (size_t)Tp * NC8 * BN * 8;
+    const size_t phase_halfs = (size_t)n_ntiles * nchunks * slab_halfs;
+    std::vector<f16> packed(phase_halfs * phases.size(), (f16)0.f);
+
+    auto wval = [&](int co, int ci, int ky, int kx) -> float {
+        if (ci >= CinReal) return 0.f;
+        if (!transposed) return weight[(((size_t)co * CinReal + ci) * kh + ky) * kw + kx];
+        return weight[(((size_t)ci * Cout + co) * kh + ky) * kw + kx];
+    };
+
+    std::vector<PhaseMeta> metas(phases.size());
+    for (size_t pi = 0; pi < phases.size(); ++pi) {
+        PhaseMeta& m = metas[pi];
+        memset(&m, 0, sizeof(m));
+        m.T = (int)phases[pi].size();
+        m.ooy = phase_off[pi].first;
+        m.oox = phase_off[pi].second;
+        m.w_off16 = (int)(pi * phase_halfs / 8);
+        for (int t = 0; t < m.T; ++t) { m.dy[t] = (signed char)phases[pi][t].dy; m.dx[t] = (signed char)phases[pi][t].dx; }
+        p->phase[pi].T = m.T; p->phase[pi].ooy = m.ooy; p->phase[pi].oox = m.oox; p->phase[pi].w_off16 = m.w_off16;
+        f16* base = packed.data() + pi * phase_halfs;
+        for (int nt = 0; nt < n_ntiles; ++nt)
+            for (int c = 0; c < nchunks; ++c)
+                for (int t = 0; t < m.T; ++t)
+                    for (int pl = 0; pl < NC8; ++pl) {
+                        const int c8 = c * NC8 + pl;
+                        if (c8 >= Cin8) continue;
+                        for (int n = 0; n < BN; ++n) {
+                            const int lco = nt * BN + n;
+                            if (lco >= lCout) continue;
+                            int co = lco, ky = phases[pi][t].ky, kx = phases[pi][t].kx;
+                            if (p->gemm_1x1_expand) { co = lco % Cout; const int pos = lco / Cout; ky = pos / kw; kx = pos % kw; }
+                            f16* dst = base + ((((size_t)(nt * nchunks + c) * Tp + t) * NC8 + pl) * BN + n) * 8;
+                            for (int j = 0; j < 8; ++j) dst[j] = (f16)wval(co, c8 * 8 + j, ky, kx);
+                        }
+                    }
+    }
+
+    // folded BN parameters (padded to CoutPad; replicated per position for the 1x1-expand case)
+    std::vector<float> sc(CoutPad, 0.f), sf(CoutPad, 0.f);
+    for (int i = 0; i < lCout; ++i) { sc[i] = scale ? scale[i % Cout] : 1.f; sf[i] = shift ? shift[i % Cout] : 0.f; }
+
+    p->w_bytes = packed.size() * sizeof(f16);
+    HIPCHK(hipMalloc((void**)&p->d_w, p->w_bytes + metas.size() * sizeof(PhaseMeta) + 256));
+    HIPCHK(hipMemcpy(p->d_w, packed.data(), p->w_bytes, hipMemcpyHostToDevice));
+    // phase metadata lives behind the weights (16-byte aligned)
+    {
+        const size_t off = (p->w_bytes + 15) / 16 * 16;
+        HIPCHK(hipMemcpy((char*)p->d_w + off, metas.data(), metas.size() * sizeof(PhaseMeta), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void**)&p->d_scale, CoutPad * sizeof(float) * 2));
+    p->d_shift = p->d_scale + CoutPad;
+    HIPCHK(hipMemcpy(p->d_scale, sc.data(), CoutPad * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_shift, sf.data(), CoutPad * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void conv_plan_destroy(ConvPlan* p) {
+    if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_scale) (void)hipFree(p->d_scale);
+    p->d_w = nullptr; p->d_scale = nullptr; p->d_shift = nullptr;
+}
+
+static unsigned magic_u16(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+
+int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err) {
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    const int NC8 = p.NC8, NBT = p.NBT, BN = NBT * 32;
+    int HoA, WoA;
+    p.out_dims(io.H, io.W, &HoA, &WoA);
+    a.x = io.x; a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift; a.res = io.res; a.y = io.y;
+    a.phases = reinterpret_cast<const PhaseMeta*>((const char*)p.d_w + (p.w_bytes + 15) / 16 * 16);
+    a.N = io.N; a.H = io.H; a.W = io.W; a.x_ld = io.x_ld; a.x_coff = io.x_coff;
+    a.res_ld = io.res_ld; a.res_coff = io.res_coff;
+    a.Cin8 = p.Cin / 8;
+    a.relu = io.relu;
+    a.y_ld = io.y_ld; a.y_coff = io.y_coff;
+    int kext_y, kext_x;
+    if (p.gemm_1x1_expand) {
+        if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }
+        if (io.y_ld != p.Cout || io.y_coff != 0) { if (err) *err = "1x1-expand output must be contiguous"; return -1; }
+        a.Ho = 1; a.Wo = 1; a.HoA = 1; a.WoA = 1; a.osy = 1; a.osx = 1;
+        a.y_ld = p.kh * p.kw * p.Cout;
+        a.Cout = p.kh * p.kw * p.Cout;
+        a.sh = a.sw = 1; a.pad_y = a.pad_x = 0; kext_y = kext_x = 1;
+    } else if (p.transposed) {
+        a.Ho = io.H; a.Wo = io.W; a.HoA = HoA; a.WoA = WoA; a.osy = 2; a.osx = 2;
+        a.Cout = p.Cout; a.sh = a.sw = 1; a.pad_y = a.pad_x = 0; kext_y = kext_x = 2;
+    } else {
+        a.Ho = HoA; a.Wo = WoA; a.HoA = HoA; a.WoA = WoA; a.osy = 1; a.osx = 1;
+        a.Cout = p.Cout; a.sh = p.sh; a.sw = p.sw; a.pad_y = p.ph; a.pad_x = p.pw; kext_y = p.kh; kext_x = p.kw;
+    }
+    if ((a.x_ld | a.x_coff | a.y_ld | a.y_coff) & 3 || (a.x_ld & 7) || (a.x_coff & 7)) {
+        if (err) *err = "channel strides/offsets must be multiples of 8 (input) / 4 (output)";
+        return -1;
+    }
+    if (io.res && ((io.res_ld | io.res_coff) & 3)) { if (err) *err = "residual stride/offset must be a multiple of 4"; return -1; }
+
+    // tile: TW x TH output pixels x NB images, 256 rows
+    int l2w = std::min(5, ceil_log2(a.Wo));
+    int l2h = std::min(8 - l2w, ceil_log2(a.Ho));
+    const int maxpix = max_a_items(NC8, NBT) * 256 / NC8;
+    int PH, PW, NB;
+    for (;;) {
+        PH = ((1 << l2h) - 1) * a.sh + kext_y;
+        PW = ((1 << l2w) - 1) * a.sw + kext_x;
+        NB = std::min(kConvBM >> (l2w + l2h), maxpix / (PH * PW));
+        if (NB >= 1) break;
+        if (l2h > 0) --l2h; else if (l2w > 0) --l2w; else { if (err) *err = "patch does not fit"; return -1; }
+    }
+    NB = std::min(NB, std::max(1, io.N));
+    a.log2TW = l2w; a.log2TH = l2h; a.NB = NB; a.PH = PH; a.PW = PW;
+    const int npix = NB * PH * PW;
+    int NPIXP = npix;
+    const int want = NC8 == 4 ? 2 : (NC8 == 2 ? 4 : 0);
+    if (NC8 > 1) while ((NPIXP & 7) != want) ++NPIXP;
+    a.NPIXP = NPIXP;
+    a.magicPW = magic_u16(PW);
+    a.magicPHW = magic_u16(PH * PW);
+    a.tiles_x = (a.Wo + (1 << l2w) - 1) >> l2w;
+    a.tiles_y = (a.Ho + (1 << l2h) - 1) >> l2h;
+    a.tiles_n = (io.N + NB - 1) / NB;
+    a.n_ntiles = p.CoutPad / BN;
+    a.nchunks = (a.Cin8 + NC8 - 1) / NC8;
+    a.Tp = p.Tp;
+
+    const size_t lds = (size_t)2 * NC8 * NPIXP * 16 + (size_t)2 * p.Tp * NC8 * BN * 16 + kTapTableBytes;
+    if (lds > (size_t)kLdsLimit) { if (err) *err = "LDS budget exceeded"; return -1; }
+    // largest 32-bit element offset the kernel forms
+    if ((double)io.N * io.H * io.W * io.x_ld >= 2147483647.0) { if (err) *err = "input tensor too large for 32-bit offsets"; return -1; }
+
+    conv_kernel_t k = pick_kernel(NC8, NBT, p.tt9);
+    const long long nblk = (long long)p.nphase * a.tiles_n * a.tiles_y * a.tiles_x * a.n_ntiles;
+    if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
+    static thread_local std::vector<const void*> configured;
+    if (std::find(configured.begin(), configured.end(), (const void*)k) == configured.end()) {
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        configured.push_back((const void*)k);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ltk

@@ -1,0 +1,772 @@
+// libltk_hip.so: engine + C ABI (include/ltk.h).
+//
+// Host-side statement of the Wav2Lip-256 generator graph
+// (avatars/wav2lip/models/wav2lip_v2.py:12-91, forward :123-163) as a static
+// layer program over a device activation arena: every layer is one launch of
+// the MFMA implicit-GEMM kernel (conv_mfma.hip); torch.cat skip connections are
+// channel-offset writes into shared NHWC buffers; eval-mode BatchNorm is folded
+// into the epilogue scale/shift at load time.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ltk.h"
+#include "conv_mfma.h"
+#include "misc_kernels.h"
+
+using namespace ltk;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define CHK(expr)                                                                        \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) return fail(LTK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+// ---------------------------------------------------------------- network description
+struct LayerDef {
+    const char* prefix;
+    bool transposed;
+    int cin, cout, k, sh, sw, pad, out_pad;
+    bool residual;
+};
+
+// wav2lip_v2.py:41-58
+const LayerDef kAudio[] = {
+    {"audio_encoder.0", false, 1, 32, 3, 1, 1, 1, 0, false},
+    {"audio_encoder.1", false, 32, 32, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.2", false, 32, 32, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.3", false, 32, 64, 3, 3, 1, 1, 0, false},
+    {"audio_encoder.4", false, 64, 64, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.5", false, 64, 64, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.6", false, 64, 128, 3, 3, 3, 1, 0, false},
+    {"audio_encoder.7", false, 128, 128, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.8", false, 128, 128, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.9", false, 128, 256, 3, 3, 2, 1, 0, false},
+    {"audio_encoder.10", false, 256, 256, 3, 1, 1, 1, 0, true},
+    {"audio_encoder.11", false, 256, 512, 3, 1, 1, 0, 0, false},
+    {"audio_encoder.12", false, 512, 512, 1, 1, 1, 0, 0, false},
+};
+// wav2lip_v2.py:12-39 (blocks separated by block index)
+struct BlockLayer { int block; LayerDef d; };
+const BlockLayer kFaceEnc[] = {
+    {0, {"face_encoder_blocks.0.0", false, 6, 16, 7, 1, 1, 3, 0, false}},
+    {1, {"face_encoder_blocks.1.0", false, 16, 32, 3, 2, 2, 1, 0, false}},
+    {1, {"face_encoder_blocks.1.1", false, 32, 32, 3, 1, 1, 1, 0, true}},
+    {1, {"face_encoder_blocks.1.2", false, 32, 32, 3, 1, 1, 1, 0, true}},
+    {2, {"face_encoder_blocks.2.0", false, 32, 64, 3, 2, 2, 1, 0, false}},
+    {2, {"face_encoder_blocks.2.1", false, 64, 64, 3, 1, 1, 1, 0, true}},
+    {2, {"face_encoder_blocks.2.2", false, 64, 64, 3, 1, 1, 1, 0, true}},
+    {2, {"face_encoder_blocks.2.3", false, 64, 64, 3, 1, 1, 1, 0, true}},
+    {3, {"face_encoder_blocks.3.0", false, 64, 128, 3, 2, 2, 1, 0, false}},
+    {3, {"face_encoder_blocks.3.1", false, 128, 128, 3, 1, 1, 1, 0, true}},
+    {3, {"face_encoder_blocks.3.2", false, 128, 128, 3, 1, 1, 1, 0, true}},
+    {4, {"face_encoder_blocks.4.0", false, 128, 256, 3, 2, 2, 1, 0, false}},
+    {4, {"face_encoder_blocks.4.1", false, 256, 256, 3, 1, 1, 1, 0, true}},
+    {4, {"face_encoder_blocks.4.2", false, 256, 256, 3, 1, 1, 1, 0, true}},
+    {5, {"face_encoder_blocks.5.0", false, 256, 512, 3, 2, 2, 1, 0, false}},
+    {5, {"face_encoder_blocks.5.1", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {6, {"face_encoder_blocks.6.0", false, 512, 512, 3, 2, 2, 1, 0, false}},
+    {6, {"face_encoder_blocks.6.1", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {7, {"face_encoder_blocks.7.0", false, 512, 512, 4, 1, 1, 0, 0, false}},
+    {7, {"face_encoder_blocks.7.1", false, 512, 512, 1, 1, 1, 0, 0, false}},
+};
+// wav2lip_v2.py:60-87
+const BlockLayer kFaceDec[] = {
+    {0, {"face_decoder_blocks.0.0", false, 512, 512, 1, 1, 1, 0, 0, false}},
+    {1, {"face_decoder_blocks.1.0", true, 1024, 512, 4, 1, 1, 0, 0, false}},
+    {1, {"face_decoder_blocks.1.1", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {2, {"face_decoder_blocks.2.0", true, 1024, 512, 3, 2, 2, 1, 1, false}},
+    {2, {"face_decoder_blocks.2.1", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {3, {"face_decoder_blocks.3.0", true, 1024, 512, 3, 2, 2, 1, 1, false}},
+    {3, {"face_decoder_blocks.3.1", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {3, {"face_decoder_blocks.3.2", false, 512, 512, 3, 1, 1, 1, 0, true}},
+    {4, {"face_decoder_blocks.4.0", true, 768, 384, 3, 2, 2, 1, 1, false}},
+    {4, {"face_decoder_blocks.4.1", false, 384, 384, 3, 1, 1, 1, 0, true}},
+    {4, {"face_decoder_blocks.4.2", false, 384, 384, 3, 1, 1, 1, 0, true}},
+    {5, {"face_decoder_blocks.5.0", true, 512, 256, 3, 2, 2, 1, 1, false}},
+    {5, {"face_decoder_blocks.5.1", false, 256, 256, 3, 1, 1, 1, 0, true}},
+    {5, {"face_decoder_blocks.5.2", false, 256, 256, 3, 1, 1, 1, 0, true}},
+    {6, {"face_decoder_blocks.6.0", true, 320, 128, 3, 2, 2, 1, 1, false}},
+    {6, {"face_decoder_blocks.6.1", false, 128, 128, 3, 1, 1, 1, 0, true}},
+    {6, {"face_decoder_blocks.6.2", false, 128, 128, 3, 1, 1, 1, 0, true}},
+    {7, {"face_decoder_blocks.7.0", true, 160, 64, 3, 2, 2, 1, 1, false}},
+    {7, {"face_decoder_blocks.7.1", false, 64, 64, 3, 1, 1, 1, 0, true}},
+    {7, {"face_decoder_blocks.7.2", false, 64, 64, 3, 1, 1, 1, 0, true}},
+};
+const LayerDef kOutConv = {"output_block.0", false, 80, 32, 3, 1, 1, 1, 0, false};  // wav2lip_v2.py:89
+const int kDecCh[8] = {512, 512, 512, 512, 384, 256, 128, 64};
+const int kFeatCh[8] = {16, 32, 64, 128, 256, 512, 512, 512};
+const int kFeatHW[8] = {256, 128, 64, 32, 16, 8, 4, 1};
+const float kBnEps = 1e-5f;  // nn.BatchNorm2d default (conv.py:9,38)
+
+enum BufId { B_MEL = 0, B_AT0, B_AT1, B_X0, B_T0, B_T1, B_OUT32, B_CAT0, B_COUNT = B_CAT0 + 8 };
+
+struct Layer {
+    std::string name;
+    ConvPlan plan;
+    int cin_real = 0;
+    int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
+    int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
+    bool residual = false;
+    double macs = 0;  // per frame
+};
+
+struct Avatar {
+    uint8_t* d_face = nullptr;
+    uint8_t* d_full = nullptr;
+    std::vector<int32_t> coords;
+    int n = 0, H = 0, W = 0;
+};
+
+struct Scratch {
+    void* d = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct ltk_engine {
+    int device = 0;
+    hipStream_t compute = nullptr;
+    std::mutex mu;            // enqueue order on `compute` + arena ownership
+    std::mutex pool_mu;       // scratch / stream pools, avatar table
+    // wav2lip
+    bool loaded = false;
+    int max_frames = 0;
+    int micro_batch = 0;
+    std::vector<Layer> layers;
+    f16* buf[B_COUNT] = {nullptr};
+    size_t buf_halfs[B_COUNT] = {0};  // per frame
+    float* d_head = nullptr;          // 96 weights + 3 bias
+    double macs_per_frame = 0;
+    // debug capture
+    bool capture = false;
+    std::map<std::string, std::vector<float>> taps;
+    std::map<std::string, std::vector<int>> tap_shape;
+    // avatars
+    std::map<int, Avatar> avatars;
+    int next_avatar = 1;
+    // mel
+    float* d_basis = nullptr;
+    int32_t* d_lohi = nullptr;
+    // pools
+    std::vector<Scratch> scratch_free;
+    std::vector<hipStream_t> stream_free;
+};
+
+namespace {
+
+struct ScratchLease {
+    ltk_engine* e;
+    Scratch s;
+    ScratchLease(ltk_engine* e_, size_t bytes) : e(e_) {
+        {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            for (size_t i = 0; i < e->scratch_free.size(); ++i)
+                if (e->scratch_free[i].cap >= bytes) {
+                    s = e->scratch_free[i];
+                    e->scratch_free.erase(e->scratch_free.begin() + i);
+                    break;
+                }
+        }
+        if (!s.d) {
+            size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+            if (hipMalloc(&s.d, cap) == hipSuccess) s.cap = cap; else s.d = nullptr;
+        }
+    }
+    ~ScratchLease() {
+        if (s.d) {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            e->scratch_free.push_back(s);
+        }
+    }
+};
+
+struct StreamLease {
+    ltk_engine* e;
+    hipStream_t s = nullptr;
+    bool owned = false;
+    StreamLease(ltk_engine* e_, void* user) : e(e_) {
+        if (user) { s = (hipStream_t)user; return; }
+        owned = true;
+        {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            if (!e->stream_free.empty()) { s = e->stream_free.back(); e->stream_free.pop_back(); }
+        }
+        if (!s) (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    }
+    ~StreamLease() {
+        if (owned && s) {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            e->stream_free.push_back(s);
+        }
+    }
+};
+
+const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& name, size_t expect) {
+    for (int i = 0; i < n; ++i) {
+        if (name == sd[i].name) {
+            size_t cnt = 1;
+            for (int d = 0; d < sd[i].ndim; ++d) cnt *= (size_t)sd[i].shape[d];
+            if (cnt != expect) return nullptr;
+            return sd[i].data;
+        }
+    }
+    return nullptr;
+}
+
+int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L) {
+    const std::string p = d.prefix;
+    const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
+    const float* w = find_tensor(sd, n, p + ".conv_block.0.weight", wcount);
+    const float* b = find_tensor(sd, n, p + ".conv_block.0.bias", d.cout);
+    const float* g = find_tensor(sd, n, p + ".conv_block.1.weight", d.cout);
+    const float* beta = find_tensor(sd, n, p + ".conv_block.1.bias", d.cout);
+    const float* mean = find_tensor(sd, n, p + ".conv_block.1.running_mean", d.cout);
+    const float* var = find_tensor(sd, n, p + ".conv_block.1.running_var", d.cout);
+    if (!w || !b || !g || !beta || !mean || !var)
+        return fail(LTK_E_INVALID, "state_dict is missing (or has a wrong shape for) tensors of layer " + p);
+    std::vector<float> sc(d.cout), sf(d.cout);
+    for (int c = 0; c < d.cout; ++c) {
+        // BatchNorm2d eval: y = (x - mean)/sqrt(var+eps)*gamma + beta, x = conv + bias
+        const float s = g[c] / sqrtf(var[c] + kBnEps);
+        sc[c] = s;
+        sf[c] = (b[c] - mean[c]) * s + beta[c];
+    }
+    std::string err;
+    int rc = conv_plan_create(&L->plan, w, d.cin, d.cout, d.k, d.k, d.sh, d.sw, d.pad, d.pad, d.transposed, d.out_pad,
+                              sc.data(), sf.data(), &err);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+    L->name = p;
+    L->cin_real = d.cin;
+    L->residual = d.residual;
+    return 0;
+}
+
+
+void bump(size_t* cur, size_t v) { if (v > *cur) *cur = v; }
+
+// Wire the layer program: buffers, channel offsets (torch.cat), spatial dims.
+int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
+    e->layers.clear();
+    size_t* bh = e->buf_halfs;
+    for (int i = 0; i < B_COUNT; ++i) bh[i] = 0;
+    bh[B_MEL] = 80 * 16 * 8;
+    bh[B_X0] = 65536 * 8;
+    bh[B_OUT32] = 65536 * 32;
+    for (int k = 0; k < 8; ++k) {
+        const int hw = kFeatHW[7 - k];
+        bh[B_CAT0 + k] = (size_t)hw * hw * (kDecCh[k] + kFeatCh[7 - k]);
+    }
+    int rc;
+    // ---- audio encoder (wav2lip_v2.py:132): MEL -> AT0/AT1 ping-pong
+    {
+        int H = 80, W = 16, in_buf = B_MEL, in_ld = 8, pp = 0;
+        for (const LayerDef& d : kAudio) {
+            Layer L;
+            if ((rc = build_layer(e, d, sd, n, &L))) return rc;
+            L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = 0; L.H = H; L.W = W;
+            L.plan.out_dims(H, W, &L.Ho, &L.Wo);
+            L.out_buf = B_AT0 + pp; L.out_ld = d.cout; L.out_coff = 0;
+            bump(&bh[L.out_buf], (size_t)L.Ho * L.Wo * d.cout);
+            L.macs = (double)d.cin * d.cout * d.k * d.k * L.Ho * L.Wo;
+            e->layers.push_back(L);
+            in_buf = L.out_buf; in_ld = d.cout; H = L.Ho; W = L.Wo; pp ^= 1;
+        }
+    }
+    const int audio_emb_buf = e->layers.back().out_buf;
+    // ---- face encoder (wav2lip_v2.py:136-140): block i ends in CAT[7-i] at channel offset dec_ch
+    {
+        int H = 256, W = 256, in_buf = B_X0, in_ld = 8, in_coff = 0, pp = 0;
+        const int nl = (int)(sizeof(kFaceEnc) / sizeof(kFaceEnc[0]));
+        for (int li = 0; li < nl; ++li) {
+            const BlockLayer& bl = kFaceEnc[li];
+            const bool last = (li + 1 == nl) || kFaceEnc[li + 1].block != bl.block;
+            Layer L;
+            if ((rc = build_layer(e, bl.d, sd, n, &L))) return rc;
+            L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
+            L.plan.out_dims(H, W, &L.Ho, &L.Wo);
+            if (last) {
+                const int k = 7 - bl.block;
+                L.out_buf = B_CAT0 + k; L.out_ld = kDecCh[k] + kFeatCh[bl.block]; L.out_coff = kDecCh[k];
+                if (L.Ho != kFeatHW[bl.block] || bl.d.cout != kFeatCh[bl.block]) return fail(LTK_E_INVALID, "encoder geometry mismatch");
+            } else {
+                L.out_buf = B_T0 + pp; L.out_ld = bl.d.cout; L.out_coff = 0; pp ^= 1;
+                bump(&bh[L.out_buf], (size_t)L.Ho * L.Wo * bl.d.cout);
+            }
+            L.macs = (double)bl.d.cin * bl.d.cout * bl.d.k * bl.d.k * L.Ho * L.Wo;
+            e->layers.push_back(L);
+            in_buf = L.out_buf; in_ld = L.out_ld; in_coff = L.out_coff; H = L.Ho; W = L.Wo;
+        }
+    }
+    // ---- decoder (wav2lip_v2.py:142-152): block k reads CAT[k-1] (all channels), ends in CAT[k][0:dec_ch)
+    {
+        int H = 1, W = 1, in_buf = audio_emb_buf, in_ld = 512, in_coff = 0, pp = 0;
+        const int nl = (int)(sizeof(kFaceDec) / sizeof(kFaceDec[0]));
+        for (int li = 0; li < nl; ++li) {
+            const BlockLayer& bl = kFaceDec[li];
+            const bool last = (li + 1 == nl) || kFaceDec[li + 1].block != bl.block;
+            Layer L;
+            if ((rc = build_layer(e, bl.d, sd, n, &L))) return rc;
+            L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
+            L.plan.out_dims(H, W, &L.Ho, &L.Wo);
+            if (last) {
+                const int k = bl.block;
+                L.out_buf = B_CAT0 + k; L.out_ld = kDecCh[k] + kFeatCh[7 - k]; L.out_coff = 0;
+                if (L.Ho != kFeatHW[7 - k] || bl.d.cout != kDecCh[k]) return fail(LTK_E_INVALID, "decoder geometry mismatch");
+            } else {
+                L.out_buf = B_T0 + pp; L.out_ld = bl.d.cout; L.out_coff = 0; pp ^= 1;
+                bump(&bh[L.out_buf], (size_t)L.Ho * L.Wo * bl.d.cout);
+            }
+            if (bl.d.transposed) L.macs = (double)bl.d.cin * bl.d.cout * bl.d.k * bl.d.k * H * W;
+            else L.macs = (double)bl.d.cin * bl.d.cout * bl.d.k * bl.d.k * L.Ho * L.Wo;
+            e->layers.push_back(L);
+            in_buf = L.out_buf; in_ld = L.out_ld; in_coff = L.out_coff; H = L.Ho; W = L.Wo;
+        }
+    }
+    // ---- output block conv (wav2lip_v2.py:89,154)
+    {
+        Layer L;
+        if ((rc = build_layer(e, kOutConv, sd, n, &L))) return rc;
+        L.in_buf = B_CAT0 + 7; L.in_ld = 80; L.in_coff = 0; L.H = 256; L.W = 256; L.Ho = 256; L.Wo = 256;
+        L.out_buf = B_OUT32; L.out_ld = 32; L.out_coff = 0;
+        L.macs = 80.0 * 32 * 9 * 65536;
+        e->layers.push_back(L);
+    }
+    // head: plain nn.Conv2d(32,3,1) (wav2lip_v2.py:90)
+    const float* hw = find_tensor(sd, n, "output_block.1.weight", 96);
+    const float* hb = find_tensor(sd, n, "output_block.1.bias", 3);
+    if (!hw || !hb) return fail(LTK_E_INVALID, "state_dict is missing output_block.1.{weight,bias}");
+    std::vector<float> h(99);
+    memcpy(h.data(), hw, 96 * sizeof(float));
+    memcpy(h.data() + 96, hb, 3 * sizeof(float));
+    CHK(hipMalloc((void**)&e->d_head, 99 * sizeof(float)));
+    CHK(hipMemcpy(e->d_head, h.data(), 99 * sizeof(float), hipMemcpyHostToDevice));
+    e->macs_per_frame = 32.0 * 3 * 65536;
+    for (const Layer& L : e->layers) e->macs_per_frame += L.macs;
+    return 0;
+}
+
+f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame0 * e->buf_halfs[id]; }
+
+// Enqueue the 54 conv/convT layers for frames [0, nf) of the arena on `s`.
+int run_convs(ltk_engine* e, int nf, hipStream_t s) {
+    std::string err;
+    for (Layer& L : e->layers) {
+        ConvIO io;
+        io.x = e->buf[L.in_buf]; io.N = nf; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
+        io.y = e->buf[L.out_buf]; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
+        io.res = L.residual ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
+        io.relu = 1;
+        int rc = conv_launch(L.plan, io, s, &err);
+        if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
+        if (e->capture) {
+            const int C = L.plan.Cout;
+            std::vector<float>& t = e->taps[L.name];
+            t.resize((size_t)nf * C * L.Ho * L.Wo);
+            float* d_tmp = nullptr;
+            CHK(hipMalloc((void**)&d_tmp, t.size() * sizeof(float)));
+            launch_nhwc_to_nchw_f32(io.y, nf, L.Ho, L.Wo, L.out_ld, L.out_coff, C, d_tmp, s);
+            CHK(hipStreamSynchronize(s));
+            CHK(hipMemcpy(t.data(), d_tmp, t.size() * sizeof(float), hipMemcpyDeviceToHost));
+            CHK(hipFree(d_tmp));
+            e->tap_shape[L.name] = {nf, C, L.Ho, L.Wo};
+        }
+    }
+    return 0;
+}
+
+// ---- Slaney mel filterbank (librosa.filters.mel semantics: htk=False, norm='slaney', float32),
+// as avatars/wav2lip/audio.py:98-101 requests it (sr 16000, n_fft 800, 80 mels, 55..7600 Hz).
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+void build_mel_basis(std::vector<float>* basis, std::vector<int32_t>* lohi) {
+    const int n_mels = 80, n_bins = 401;
+    const double sr = 16000.0, f_lo = 55.0, f_hi = 7600.0;
+    std::vector<double> mel_f(n_mels + 2);
+    const double m0 = hz_to_mel(f_lo), m1 = hz_to_mel(f_hi);
+    for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (n_mels + 1));
+    basis->assign((size_t)n_mels * n_bins, 0.f);
+    lohi->assign(2 * n_mels, 0);
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int lo = n_bins, hi = 0;
+        for (int k = 0; k < n_bins; ++k) {
+            const double f = (sr / 2) * k / (n_bins - 1);
+            const double lower = -(mel_f[i] - f) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double w = fmax(0.0, lower < upper ? lower : upper) * enorm;
+            const float wf = (float)w;
+            (*basis)[(size_t)i * n_bins + k] = wf;
+            if (wf != 0.f) { if (k < lo) lo = k; if (k + 1 > hi) hi = k + 1; }
+        }
+        if (lo > hi) lo = hi = 0;
+        (*lohi)[2 * i] = lo; (*lohi)[2 * i + 1] = hi;
+    }
+}
+
+int mirror_index(int size, int index) {  // utils/image.py:26-32
+    const int turn = index / size, res = index % size;
+    return (turn % 2 == 0) ? res : size - res - 1;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+const char* ltk_last_error(void) { return g_err.c_str(); }
+const char* ltk_version(void) { return "ltk_hip 0.1 (gfx950)"; }
+
+int ltk_engine_create(int device, ltk_engine** out) {
+    if (!out) return fail(LTK_E_INVALID, "out is null");
+    int ndev = 0;
+    CHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(LTK_E_INVALID, "no such HIP device");
+    CHK(hipSetDevice(device));
+    std::unique_ptr<ltk_engine> e(new ltk_engine());
+    e->device = device;
+    CHK(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
+    std::vector<float> basis;
+    std::vector<int32_t> lohi;
+    build_mel_basis(&basis, &lohi);
+    CHK(hipMalloc((void**)&e->d_basis, basis.size() * sizeof(float)));
+    CHK(hipMemcpy(e->d_basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
+    CHK(hipMalloc((void**)&e->d_lohi, lohi.size() * sizeof(int32_t)));
+    CHK(hipMemcpy(e->d_lohi, lohi.data(), lohi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = e.release();
+    return LTK_OK;
+}
+
+void ltk_engine_destroy(ltk_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (Layer& L : e->layers) conv_plan_destroy(&L.plan);
+    for (int i = 0; i < B_COUNT; ++i) if (e->buf[i]) (void)hipFree(e->buf[i]);
+    if (e->d_head) (void)hipFree(e->d_head);
+    if (e->d_basis) (void)hipFree(e->d_basis);
+    if (e->d_lohi) (void)hipFree(e->d_lohi);
+    for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
+    for (Scratch& s : e->scratch_free) (void)hipFree(s.d);
+    for (hipStream_t s : e->stream_free) (void)hipStreamDestroy(s);
+    if (e->compute) (void)hipStreamDestroy(e->compute);
+    delete e;
+}
+
+int ltk_engine_sync(ltk_engine* e) {
+    if (!e) return fail(LTK_E_INVALID, "engine is null");
+    CHK(hipSetDevice(e->device));
+    CHK(hipDeviceSynchronize());
+    return LTK_OK;
+}
+
+int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_frames) {
+    if (!e || !sd || n <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (max_frames < 1 || max_frames > 4096) return fail(LTK_E_INVALID, "max_frames must be in [1, 4096]");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->loaded) return fail(LTK_E_STATE, "a model is already loaded in this engine");
+    CHK(hipSetDevice(e->device));
+    int rc = build_program(e, sd, n);
+    if (rc) return rc;
+    const char* mb = getenv("LTK_MICROBATCH");
+    e->micro_batch = mb ? atoi(mb) : 0;
+    if (e->micro_batch <= 0 || e->micro_batch > max_frames) e->micro_batch = max_frames;
+    e->max_frames = max_frames;
+    const int arena_frames = e->micro_batch;
+    for (int i = 0; i < B_COUNT; ++i) {
+        if (!e->buf_halfs[i]) continue;
+        const size_t bytes = e->buf_halfs[i] * arena_frames * sizeof(f16) + 4096;
+        if (hipMalloc((void**)&e->buf[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "activation arena allocation failed");
+        CHK(hipMemset(e->buf[i], 0, bytes));
+    }
+    e->loaded = true;
+    return LTK_OK;
+}
+
+int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* full_bank,
+                        const int32_t* coords, int n, int H, int W, int* avatar_id) {
+    if (!e || !face_bank || !full_bank || !coords || !avatar_id || n <= 0 || H <= 0 || W <= 0)
+        return fail(LTK_E_INVALID, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+        const int32_t* c = coords + 4 * i;  // (y1,y2,x1,x2), wav2lip_avatar.py:144
+        if (c[0] < 0 || c[2] < 0 || c[1] > H || c[3] > W || c[1] <= c[0] || c[3] <= c[2])
+            return fail(LTK_E_INVALID, "coords box outside the frame");
+    }
+    CHK(hipSetDevice(e->device));
+    Avatar a;
+    a.n = n; a.H = H; a.W = W;
+    a.coords.assign(coords, coords + 4 * (size_t)n);
+    const size_t fb = (size_t)n * 256 * 256 * 3, ub = (size_t)n * H * W * 3;
+    CHK(hipMalloc((void**)&a.d_face, fb));
+    CHK(hipMalloc((void**)&a.d_full, ub));
+    CHK(hipMemcpy(a.d_face, face_bank, fb, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(a.d_full, full_bank, ub, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> g(e->pool_mu);
+    const int id = e->next_avatar++;
+    e->avatars[id] = a;
+    *avatar_id = id;
+    return LTK_OK;
+}
+
+int ltk_avatar_release(ltk_engine* e, int avatar_id) {
+    if (!e) return fail(LTK_E_INVALID, "engine is null");
+    std::lock_guard<std::mutex> g(e->pool_mu);
+    auto it = e->avatars.find(avatar_id);
+    if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+    (void)hipFree(it->second.d_face);
+    (void)hipFree(it->second.d_full);
+    e->avatars.erase(it);
+    return LTK_OK;
+}
+
+int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* win_start, int n_win,
+                 void* d_out, void* stream) {
+    if (!e || !pcm || !win_start || !d_out || n_samples <= 0 || n_win <= 0 || n_win > 1024)
+        return fail(LTK_E_INVALID, "bad arguments");
+    const int n_cols_total = 1 + n_samples / 200;  // librosa.stft(center=True)
+    int cmin = 1 << 30, cmax = -1;
+    for (int i = 0; i < n_win; ++i) {
+        if (win_start[i] < 0 || win_start[i] + 16 > n_cols_total) return fail(LTK_E_INVALID, "mel window outside the spectrogram");
+        if (win_start[i] < cmin) cmin = win_start[i];
+        if (win_start[i] + 15 > cmax) cmax = win_start[i] + 15;
+    }
+    CHK(hipSetDevice(e->device));
+    const size_t pcm_bytes = (size_t)n_samples * sizeof(float);
+    const size_t ws_off = (pcm_bytes + 255) / 256 * 256;
+    ScratchLease sc(e, ws_off + (size_t)n_win * sizeof(int32_t));
+    if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
+    StreamLease sl(e, stream);
+    CHK(hipMemcpyAsync(sc.s.d, pcm, pcm_bytes, hipMemcpyHostToDevice, sl.s));
+    CHK(hipMemcpyAsync((char*)sc.s.d + ws_off, win_start, (size_t)n_win * sizeof(int32_t), hipMemcpyHostToDevice, sl.s));
+    launch_mel((const float*)sc.s.d, n_samples, (const int32_t*)((char*)sc.s.d + ws_off), n_win, cmin, cmax - cmin + 1,
+               e->d_basis, e->d_lohi, (float*)d_out, sl.s);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
+static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mels, const float* d_face6, int nf,
+                        uint8_t* d_pred_u8, float* d_pred_f32) {
+    hipStream_t s = e->compute;
+    if (faces) launch_pack_faces(*faces, nf, e->buf[B_X0], s);
+    else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
+    launch_pack_mel(*mels, nf, e->buf[B_MEL], s);
+    int rc = run_convs(e, nf, s);
+    if (rc) return rc;
+    launch_head(e->buf[B_OUT32], 32, nf * 65536, e->d_head, e->d_head + 96, d_pred_u8, d_pred_f32, 65536, s);
+    CHK(hipGetLastError());
+    return 0;
+}
+
+int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* d_pred_u8, void* stream) {
+    if (!e || !reqs || nreq <= 0 || !d_pred_u8) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
+    CHK(hipSetDevice(e->device));
+    // resolve every frame's bank crop and mel window up front
+    std::vector<const uint8_t*> fptr;
+    std::vector<const float*> mptr;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        for (int r = 0; r < nreq; ++r) {
+            auto it = e->avatars.find(reqs[r].avatar);
+            if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+            if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_mel) return fail(LTK_E_INVALID, "bad request");
+            const Avatar& a = it->second;
+            for (int i = 0; i < reqs[r].batch; ++i) {
+                const int idx = mirror_index(a.n, reqs[r].index + i);  // wav2lip_avatar.py:121-124
+                fptr.push_back(a.d_face + (size_t)idx * 256 * 256 * 3);
+                mptr.push_back((const float*)reqs[r].d_mel + (size_t)i * 80 * 16);
+            }
+        }
+    }
+    const int total = (int)fptr.size();
+    if (total > e->max_frames) return fail(LTK_E_INVALID, "more frames than max_frames given to ltk_wav2lip_load");
+    hipEvent_t done;
+    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (stream) {  // inputs were produced on the caller's stream
+            hipEvent_t ready;
+            CHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            CHK(hipEventRecord(ready, (hipStream_t)stream));
+            CHK(hipStreamWaitEvent(e->compute, ready, 0));
+            CHK(hipEventDestroy(ready));
+        }
+        const int mbs = std::min(e->micro_batch, kPackMaxFrames);
+        for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
+            const int nf = std::min(mbs, total - f0);
+            FacePtrs fp; MelPtrs mp;
+            for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; }
+            rc = infer_locked(e, &fp, &mp, nullptr, nf, (uint8_t*)d_pred_u8 + (size_t)f0 * 65536 * 3, nullptr);
+        }
+        if (!rc) {
+            if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
+        }
+    }
+    if (!rc) {
+        if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
+        if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+    }
+    (void)hipEventDestroy(done);
+    return rc;
+}
+
+int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream) {
+    if (!e || !d_pred || !out) return fail(LTK_E_INVALID, "bad arguments");
+    Avatar a;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        auto it = e->avatars.find(avatar_id);
+        if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+        a = it->second;
+    }
+    if (idx < 0 || idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
+    CHK(hipSetDevice(e->device));
+    const int32_t* c = a.coords.data() + 4 * (size_t)idx;
+    const size_t bytes = (size_t)a.H * a.W * 3;
+    StreamLease sl(e, stream);
+    const uint8_t* full = a.d_full + (size_t)idx * bytes;
+    if (out_is_device) {
+        launch_paste(full, a.H, a.W, (const uint8_t*)d_pred, c[0], c[1], c[2], c[3], (uint8_t*)out, sl.s);
+        CHK(hipGetLastError());
+        CHK(hipStreamSynchronize(sl.s));
+        return LTK_OK;
+    }
+    ScratchLease sc(e, bytes);
+    if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
+    launch_paste(full, a.H, a.W, (const uint8_t*)d_pred, c[0], c[1], c[2], c[3], (uint8_t*)sc.s.d, sl.s);
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(out, sc.s.d, bytes, hipMemcpyDeviceToHost, sl.s));
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
+// ------------------------------------------------------------------ test / measurement hooks
+int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6, int B, float* pred) {
+    if (!e || !mel || !face6 || !pred || B <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
+    if (B > e->micro_batch || B > kPackMaxFrames) return fail(LTK_E_INVALID, "B exceeds the arena (micro-batch) size");
+    CHK(hipSetDevice(e->device));
+    const size_t melb = (size_t)B * 80 * 16 * sizeof(float), faceb = (size_t)B * 6 * 65536 * sizeof(float);
+    const size_t predb = (size_t)B * 3 * 65536 * sizeof(float);
+    float *d_mel = nullptr, *d_face = nullptr, *d_pred = nullptr;
+    CHK(hipMalloc((void**)&d_mel, melb));
+    CHK(hipMalloc((void**)&d_face, faceb));
+    CHK(hipMalloc((void**)&d_pred, predb));
+    CHK(hipMemcpy(d_mel, mel, melb, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(d_face, face6, faceb, hipMemcpyHostToDevice));
+    MelPtrs mp;
+    for (int i = 0; i < B; ++i) mp.p[i] = d_mel + (size_t)i * 1280;
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        rc = infer_locked(e, nullptr, &mp, d_face, B, nullptr, d_pred);
+        if (!rc && hipStreamSynchronize(e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "stream sync failed");
+    }
+    if (!rc) CHK(hipMemcpy(pred, d_pred, predb, hipMemcpyDeviceToHost));
+    (void)hipFree(d_mel); (void)hipFree(d_face); (void)hipFree(d_pred);
+    return rc;
+}
+
+int ltk_debug_capture(ltk_engine* e, int enable) {
+    if (!e) return fail(LTK_E_INVALID, "engine is null");
+    std::lock_guard<std::mutex> g(e->mu);
+    e->capture = enable != 0;
+    if (!enable) { e->taps.clear(); e->tap_shape.clear(); }
+    return LTK_OK;
+}
+
+int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats) {
+    if (!e || !layer || !out) return fail(LTK_E_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->taps.find(layer);
+    if (it == e->taps.end()) return fail(LTK_E_STATE, std::string("no capture for layer ") + layer);
+    if (it->second.size() != n_floats) return fail(LTK_E_INVALID, "size mismatch: captured " + std::to_string(it->second.size()));
+    memcpy(out, it->second.data(), n_floats * sizeof(float));
+    return LTK_OK;
+}
+
+int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass) {
+    if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
+    if (frames > e->micro_batch) return fail(LTK_E_INVALID, "frames exceeds the arena (micro-batch) size");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
+    hipEvent_t t0, t1;
+    CHK(hipEventCreate(&t0));
+    CHK(hipEventCreate(&t1));
+    int rc = run_convs(e, frames, e->compute);  // warm
+    if (rc) return rc;
+    CHK(hipEventRecord(t0, e->compute));
+    for (int i = 0; i < iters && !rc; ++i) rc = run_convs(e, frames, e->compute);
+    if (rc) return rc;
+    CHK(hipEventRecord(t1, e->compute));
+    CHK(hipEventSynchronize(t1));
+    float ms = 0.f;
+    CHK(hipEventElapsedTime(&ms, t0, t1));
+    *ms_per_pass = ms / iters;
+    if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - 32.0 * 3 * 65536) * frames;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return LTK_OK;
+}
+
+int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
+                   const float* weight, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                   int transposed, int out_pad, const float* scale, const float* shift,
+                   const void* d_res, int relu, void* d_y, int iters, float* ms_avg) {
+    if (!e || !d_x || !weight || !d_y) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(hipSetDevice(e->device));
+    ConvPlan plan;
+    std::string err;
+    int rc = conv_plan_create(&plan, weight, Cin, Cout, kh, kw, sh, sw, ph, pw, transposed != 0, out_pad, scale, shift, &err);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
+    ConvIO io;
+    io.x = (const f16*)d_x; io.N = N; io.H = H; io.W = W; io.x_ld = plan.Cin; io.x_coff = 0;
+    io.y = (f16*)d_y; io.y_ld = Cout; io.y_coff = 0;
+    io.res = (const f16*)d_res; io.res_ld = Cout; io.res_coff = 0;
+    io.relu = relu;
+    hipStream_t s = e->compute;
+    std::lock_guard<std::mutex> g(e->mu);
+    rc = conv_launch(plan, io, s, &err);
+    if (!rc && iters > 0 && ms_avg) {
+        hipEvent_t t0, t1;
+        (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+        (void)hipEventRecord(t0, s);
+        for (int i = 0; i < iters && !rc; ++i) rc = conv_launch(plan, io, s, &err);
+        (void)hipEventRecord(t1, s);
+        (void)hipEventSynchronize(t1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        *ms_avg = ms / iters;
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    }
+    hipError_t he = hipStreamSynchronize(s);
+    conv_plan_destroy(&plan);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
+    if (he != hipSuccess) return fail(LTK_E_HIP, std::string("conv kernel: ") + hipGetErrorString(he));
+    return LTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// HBM-bound helper kernels of the render hot path: input gather/pack, output
+// head, mel-spectrogram, paste-back composite.  Host launch interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ltk {
+
+typedef _Float16 f16;
+
+constexpr int kPackMaxFrames = 256;
+
+// Pointers to the bank face crops of the frames of one launch (kernel argument,
+// 2 KB): avoids a host->device table copy per call.
+struct FacePtrs {
+    const uint8_t* p[kPackMaxFrames];
+};
+
+// wav2lip_avatar.py:125-134: face u8 BGR [256][256][3] -> fp16 NHWC [256][256][8]
+// = {masked b,g,r (rows >= 128 zero), b,g,r, 0, 0} / 255.
+void launch_pack_faces(const FacePtrs& faces, int nframes, f16* x0, hipStream_t s);
+
+struct MelPtrs {
+    const float* p[kPackMaxFrames];   // per frame: float32 [80][16]
+};
+
+// mel float32 [80][16] per frame -> fp16 NHWC [B][80][16][8] (channel 0 = value).
+void launch_pack_mel(const MelPtrs& mel, int nframes, f16* out, hipStream_t s);
+
+// face6 float32 NCHW [B][6][256][256] -> fp16 NHWC [B][256][256][8] (test hook).
+void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_t s);
+
+// wav2lip_v2.py:90-91 + wav2lip_avatar.py:138,145: 1x1 conv 32->3 + sigmoid;
+// writes uint8 trunc(sigmoid*255) NHWC [B][256][256][3] and/or float32 sigmoid
+// NCHW [B][3][256][256] (either may be null).
+void launch_head(const f16* x32, int x_ld, int npix_total, const float* w3x32, const float* b3,
+                 uint8_t* out_u8, float* out_f32_nchw, int hw, hipStream_t s);
+
+// fp16 NHWC (ld, coff, C channels) -> float32 NCHW (debug capture).
+void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s);
+
+// audio.py:45-51 melspectrogram columns + mel.py:56-63 window gather.
+// pcm device float32 [n_samples]; win_start device int32 [n_win];
+// out float32 [n_win][80][16].  basis float32 [80][401], lo/hi int32 [80].
+void launch_mel(const float* pcm, int n_samples, const int32_t* win_start, int n_win, int col_min, int n_cols,
+                const float* basis, const int32_t* lohi, float* out, hipStream_t s);
+
+// wav2lip_avatar.py:141-147 paste_back_frame.
+void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
+                  uint8_t* out, hipStream_t s);
+
+}  // namespace ltk

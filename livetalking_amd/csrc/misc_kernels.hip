@@ -1,0 +1,289 @@
+// HBM-bound helper kernels of the render hot path (gfx950).  Byte/short
+// streaming work: coalesced 8/16-byte accesses, no LDS reuse to exploit except
+// in the mel DFT (frame + twiddle table in LDS).
+#include "misc_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+namespace ltk {
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// input pack: wav2lip_avatar.py:119-134
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_faces_kernel(const FacePtrs faces, f16* __restrict__ x0) {
+    const int f = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;  // 0..65535
+    const uint8_t* __restrict__ src = faces.p[f] + pix * 3;
+    const float k = 1.0f / 255.0f;
+    const float b = src[0] * k, g = src[1] * k, r = src[2] * k;
+    const bool keep = (pix >> 8) < 128;  // img_masked[:, 128:] = 0  (rows)
+    f16x8 o;
+    o[0] = (f16)(keep ? b : 0.f); o[1] = (f16)(keep ? g : 0.f); o[2] = (f16)(keep ? r : 0.f);
+    o[3] = (f16)b; o[4] = (f16)g; o[5] = (f16)r; o[6] = (f16)0.f; o[7] = (f16)0.f;
+    *reinterpret_cast<f16x8*>(x0 + ((size_t)f * 65536 + pix) * 8) = o;
+}
+
+void launch_pack_faces(const FacePtrs& faces, int nframes, f16* x0, hipStream_t s) {
+    hipLaunchKernelGGL(pack_faces_kernel, dim3(256, nframes), dim3(256), 0, s, faces, x0);
+}
+
+__global__ __launch_bounds__(256) void pack_mel_kernel(const MelPtrs mel, f16* __restrict__ out) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;  // 0..1279
+    if (i >= 1280) return;
+    f16x8 o;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) o[j] = (f16)0.f;
+    o[0] = (f16)mel.p[f][i];
+    *reinterpret_cast<f16x8*>(out + ((size_t)f * 1280 + i) * 8) = o;
+}
+
+void launch_pack_mel(const MelPtrs& mel, int nframes, f16* out, hipStream_t s) {
+    hipLaunchKernelGGL(pack_mel_kernel, dim3(5, nframes), dim3(256), 0, s, mel, out);
+}
+
+__global__ __launch_bounds__(256) void pack_face6_nchw_kernel(const float* __restrict__ face6, f16* __restrict__ x0) {
+    const int f = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const float* src = face6 + (size_t)f * 6 * 65536 + pix;
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = (f16)src[(size_t)c * 65536];
+    o[6] = (f16)0.f; o[7] = (f16)0.f;
+    *reinterpret_cast<f16x8*>(x0 + ((size_t)f * 65536 + pix) * 8) = o;
+}
+
+void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_t s) {
+    hipLaunchKernelGGL(pack_face6_nchw_kernel, dim3(256, nframes), dim3(256), 0, s, face6, x0);
+}
+
+// ---------------------------------------------------------------------------------------
+// output head: nn.Conv2d(32,3,1) + Sigmoid (wav2lip_v2.py:90-91), *255 + uint8 truncation
+// (wav2lip_avatar.py:138,145).  One thread = 4 consecutive pixels -> 12 output bytes.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_ld, int npix_total,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    uint8_t* __restrict__ out_u8, float* __restrict__ out_f32, int hw) {
+    __shared__ float sw[3 * 32 + 3];
+    if (threadIdx.x < 96) sw[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 3) sw[96 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;  // quad of pixels
+    const int p0 = q * 4;
+    if (p0 >= npix_total) return;
+    unsigned bytes[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        const f16* px = x + (size_t)p * x_ld;
+        float acc0 = sw[96], acc1 = sw[97], acc2 = sw[98];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(px + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = (float)h[j];
+                acc0 += xv * sw[v * 8 + j];
+                acc1 += xv * sw[32 + v * 8 + j];
+                acc2 += xv * sw[64 + v * 8 + j];
+            }
+        }
+        const float s0 = 1.f / (1.f + __expf(-acc0));
+        const float s1 = 1.f / (1.f + __expf(-acc1));
+        const float s2 = 1.f / (1.f + __expf(-acc2));
+        if (out_f32) {
+            const int n = p / hw, r = p - n * hw;
+            float* o = out_f32 + (size_t)n * 3 * hw + r;
+            o[0] = s0; o[(size_t)hw] = s1; o[(size_t)2 * hw] = s2;
+        }
+        // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
+        const unsigned u0 = (unsigned)(s0 * 255.f), u1 = (unsigned)(s1 * 255.f), u2 = (unsigned)(s2 * 255.f);
+        const int bo = k * 3;
+        bytes[(bo + 0) >> 2] |= u0 << (((bo + 0) & 3) * 8);
+        bytes[(bo + 1) >> 2] |= u1 << (((bo + 1) & 3) * 8);
+        bytes[(bo + 2) >> 2] |= u2 << (((bo + 2) & 3) * 8);
+    }
+    if (out_u8) {
+        unsigned* o = reinterpret_cast<unsigned*>(out_u8 + (size_t)p0 * 3);
+        o[0] = bytes[0]; o[1] = bytes[1]; o[2] = bytes[2];
+    }
+}
+
+void launch_head(const f16* x32, int x_ld, int npix_total, const float* w3x32, const float* b3,
+                 uint8_t* out_u8, float* out_f32_nchw, int hw, hipStream_t s) {
+    const int quads = (npix_total + 3) / 4;
+    hipLaunchKernelGGL(head_kernel, dim3((quads + 255) / 256), dim3(256), 0, s, x32, x_ld, npix_total, w3x32, b3,
+                       out_u8, out_f32_nchw, hw);
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, int N, int HW, int ld, int coff, int C,
+                                                            float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)N * C * HW;
+    if (i >= total) return;
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int n = (int)(i / ((size_t)HW * C));
+    out[i] = (float)x[((size_t)n * HW + p) * ld + coff + c];
+}
+
+void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s) {
+    const size_t total = (size_t)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, N, H * W, ld, coff, C, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// mel-spectrogram: avatars/wav2lip/audio.py:45-51 with hparams.py:33-73 constants, and the
+// (80,16) window gather of avatars/audio_features/mel.py:56-63.
+// One workgroup = one STFT column: pre-emphasis + periodic Hann window into LDS, 401-bin
+// real DFT in fp64 against an LDS twiddle table (the reference computes in float64), mel
+// projection with the float32 Slaney basis, dB + symmetric normalisation.
+// ---------------------------------------------------------------------------------------
+constexpr int kNfft = 800, kHop = 200, kBins = 401, kMels = 80, kMelStep = 16;
+
+__global__ __launch_bounds__(448) void mel_kernel(const float* __restrict__ pcm, int n_samples,
+                                                   const int32_t* __restrict__ win_start, int n_win, int col_min,
+                                                   const float* __restrict__ basis, const int32_t* __restrict__ lohi,
+                                                   float* __restrict__ out) {
+    __shared__ double frame[kNfft];
+    __shared__ double tw_c[kNfft];
+    __shared__ double tw_s[kNfft];
+    __shared__ double mag[kBins + 7];
+    __shared__ float melcol[kMels];
+    const int tid = threadIdx.x;
+    const int col = col_min + blockIdx.x;
+    const int base = col * kHop - kNfft / 2;  // librosa center=True: frame t covers [t*hop - n_fft/2, +n_fft)
+    for (int n = tid; n < kNfft; n += blockDim.x) {
+        const int i = base + n;
+        double y = 0.0;
+        if (i >= 0 && i < n_samples) {
+            // audio.py:20-23 lfilter([1,-0.97],[1]): y[i] = x[i] - 0.97*x[i-1], y[0] = x[0]
+            const double xi = (double)pcm[i];
+            const double xm = (i > 0) ? (double)pcm[i - 1] : 0.0;
+            y = xi - 0.97 * xm;
+        }
+        double s, c;
+        sincospi(2.0 * (double)n / (double)kNfft, &s, &c);
+        frame[n] = y * (0.5 - 0.5 * c);  // periodic Hann
+        tw_c[n] = c;
+        tw_s[n] = s;
+    }
+    __syncthreads();
+    if (tid < kBins) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int n = 0; n < kNfft; ++n) {
+            const double v = frame[n];
+            re += v * tw_c[idx];
+            im -= v * tw_s[idx];
+            idx += tid;
+            if (idx >= kNfft) idx -= kNfft;
+        }
+        mag[tid] = sqrt(re * re + im * im);
+    }
+    __syncthreads();
+    if (tid < kMels) {
+        const int lo = lohi[2 * tid], hi = lohi[2 * tid + 1];
+        double acc = 0.0;
+        for (int k = lo; k < hi; ++k) acc += (double)basis[tid * kBins + k] * mag[k];
+        // audio.py:103-105 / :47 / :110-115
+        const double min_level = 1e-5;  // exp(-100/20*ln 10)
+        double S = 20.0 * log10(fmax(min_level, acc)) - 20.0;
+        double v = 8.0 * ((S + 100.0) / 100.0) - 4.0;
+        v = fmin(fmax(v, -4.0), 4.0);
+        melcol[tid] = (float)v;
+    }
+    __syncthreads();
+    // scatter this column into every window that contains it
+    for (int w = 0; w < n_win; ++w) {
+        const int k = col - win_start[w];
+        if (k >= 0 && k < kMelStep && tid < kMels) out[((size_t)w * kMels + tid) * kMelStep + k] = melcol[tid];
+    }
+}
+
+void launch_mel(const float* pcm, int n_samples, const int32_t* win_start, int n_win, int col_min, int n_cols,
+                const float* basis, const int32_t* lohi, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mel_kernel, dim3(n_cols), dim3(448), 0, s, pcm, n_samples, win_start, n_win, col_min, basis, lohi, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// paste-back composite: avatars/wav2lip_avatar.py:141-147.  cv2.resize(INTER_LINEAR) 8-bit
+// semantics: float32 half-pixel source coordinates, 11-bit fixed-point weights, horizontal
+// then vertical pass with OpenCV's (>>4, >>16, +2, >>2) rounding; exact 2x shrink = 2x2 box.
+// One thread = 4 consecutive output bytes of the flat H*W*3 frame.
+// ---------------------------------------------------------------------------------------
+struct AxisTap { int s0, s1, a0, a1; };
+
+__device__ __forceinline__ AxisTap axis_tap(int d, int dst, int src, bool clamp_f) {
+    const double scale = (double)src / (double)dst;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_f) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= src - 1) { f = 0.f; s = src - 1; }
+    }
+    AxisTap t;
+    t.a0 = __float2int_rn((1.0f - f) * 2048.0f);
+    t.a1 = __float2int_rn(f * 2048.0f);
+    t.s0 = min(max(s, 0), src - 1);
+    t.s1 = min(max(s + 1, 0), src - 1);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void paste_kernel(const uint8_t* __restrict__ full, int H, int W,
+                                                     const uint8_t* __restrict__ pred, int y1, int y2, int x1, int x2,
+                                                     uint8_t* __restrict__ out) {
+    const size_t total = (size_t)H * W * 3;
+    const size_t b0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (b0 >= total) return;
+    const int dh = y2 - y1, dw = x2 - x1;
+    const int rowbytes = W * 3;
+    unsigned word = 0;
+    const int nb = (int)min((size_t)4, total - b0);
+    for (int k = 0; k < nb; ++k) {
+        const size_t bi = b0 + k;
+        const int y = (int)(bi / rowbytes);
+        const int rb = (int)(bi - (size_t)y * rowbytes);
+        const int x = rb / 3, c = rb - x * 3;
+        unsigned v;
+        if (y >= y1 && y < y2 && x >= x1 && x < x2) {
+            const int dy = y - y1, dx = x - x1;
+            if (dw == 256 && dh == 256) {
+                v = pred[(dy * 256 + dx) * 3 + c];
+            } else if (dw == 128 && dh == 128) {
+                const uint8_t* p = pred + ((2 * dy) * 256 + 2 * dx) * 3 + c;
+                v = (p[0] + p[3] + p[768] + p[771] + 2) >> 2;
+            } else {
+                const AxisTap tx = axis_tap(dx, dw, 256, true);
+                const AxisTap ty = axis_tap(dy, dh, 256, false);
+                const uint8_t* r0 = pred + (size_t)ty.s0 * 768 + c;
+                const uint8_t* r1 = pred + (size_t)ty.s1 * 768 + c;
+                const int S0 = r0[tx.s0 * 3] * tx.a0 + r0[tx.s1 * 3] * tx.a1;
+                const int S1 = r1[tx.s0 * 3] * tx.a0 + r1[tx.s1 * 3] * tx.a1;
+                const int o = (((ty.a0 * (S0 >> 4)) >> 16) + ((ty.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                v = (unsigned)min(max(o, 0), 255);
+            }
+        } else {
+            v = full[bi];
+        }
+        word |= v << (8 * k);
+    }
+    if (nb == 4) {
+        *reinterpret_cast<unsigned*>(out + b0) = word;
+    } else {
+        for (int k = 0; k < nb; ++k) out[b0 + k] = (uint8_t)(word >> (8 * k));
+    }
+}
+
+void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
+                  uint8_t* out, hipStream_t s) {
+    const size_t total = (size_t)H * W * 3;
+    const size_t words = (total + 3) / 4;
+    hipLaunchKernelGGL(paste_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, full, H, W, pred256, y1, y2, x1, x2, out);
+}
+
+}  // namespace ltk

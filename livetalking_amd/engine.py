@@ -1,0 +1,160 @@
+"""Python handle on one per-GPU render engine (libltk_hip.so).
+
+PyTorch-ROCm is used only as plumbing here: device buffers (`torch.empty(...,
+device="cuda")`) and their `data_ptr()`s.  All arithmetic runs in the HIP
+library.  One `Engine` per GPU; sessions are sharded across engines by the
+host - there is no cross-GPU traffic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import LtkError, NamedTensor, W2lReq  # noqa: F401
+
+
+def _as_f32(a) -> np.ndarray:
+    if hasattr(a, "detach"):  # torch tensor
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """avatars/wav2lip_avatar.py `model` handle + device-resident avatar banks."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.ltk_engine_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.max_frames = 0
+        self._closed = False
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            self._lib.ltk_engine_destroy(self._h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self._lib.ltk_engine_sync(self._h))
+
+    # ------------------------------------------------------------------ model
+    def load_wav2lip(self, state_dict: Dict[str, object], max_frames: int = 16):
+        """wav2lip_avatar.py:59-70: `state_dict` = checkpoint["state_dict"] with any
+        "module." prefix stripped (tensors or arrays)."""
+        keep = []
+        arr = (NamedTensor * len(state_dict))()
+        n = 0
+        for name, t in state_dict.items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            a = _as_f32(t)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            nm = name.encode()
+            keep.append((a, shape, nm))
+            arr[n].name = nm
+            arr[n].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            arr[n].ndim = a.ndim
+            arr[n].shape = shape
+            n += 1
+        _lib.check(self._lib.ltk_wav2lip_load(self._h, arr, n, int(max_frames)))
+        self.max_frames = int(max_frames)
+
+    # ------------------------------------------------------------------ avatars
+    def register_avatar(self, face_list: Sequence[np.ndarray], frame_list: Sequence[np.ndarray],
+                        coord_list: Sequence[Sequence[int]]) -> int:
+        """Upload (frame_list_cycle, face_list_cycle, coord_list_cycle) as
+        load_avatar returns them (wav2lip_avatar.py:72-88)."""
+        faces = np.ascontiguousarray(np.stack(face_list), dtype=np.uint8)
+        fulls = np.ascontiguousarray(np.stack(frame_list), dtype=np.uint8)
+        coords = np.ascontiguousarray(np.asarray(coord_list, dtype=np.int32).reshape(-1, 4))
+        n = faces.shape[0]
+        if faces.shape[1:] != (256, 256, 3) or fulls.shape[0] != n or coords.shape[0] != n or fulls.shape[3] != 3:
+            raise ValueError("avatar bank shapes: faces (n,256,256,3), frames (n,H,W,3), coords (n,4)")
+        aid = C.c_int()
+        _lib.check(self._lib.ltk_avatar_register(self._h, faces.ctypes.data, fulls.ctypes.data, coords.ctypes.data,
+                                                 n, fulls.shape[1], fulls.shape[2], C.byref(aid)))
+        return aid.value
+
+    def release_avatar(self, avatar_id: int):
+        _lib.check(self._lib.ltk_avatar_release(self._h, int(avatar_id)))
+
+    # ------------------------------------------------------------------ hot path
+    def mel_step(self, pcm: np.ndarray, win_start: Sequence[int], d_out_ptr: int, stream: int = 0):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        ws = np.ascontiguousarray(win_start, dtype=np.int32)
+        _lib.check(self._lib.ltk_mel_step(self._h, pcm.ctypes.data, pcm.shape[0], ws.ctypes.data, ws.shape[0],
+                                          C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def wav2lip_infer(self, reqs: Sequence[tuple], d_pred_ptr: int, stream: int = 0):
+        """reqs: (avatar_id, index, batch, d_mel_ptr) per session."""
+        arr = (W2lReq * len(reqs))()
+        for i, (aid, index, batch, mel_ptr) in enumerate(reqs):
+            arr[i].avatar = int(aid)
+            arr[i].index = int(index)
+            arr[i].batch = int(batch)
+            arr[i].d_mel = C.c_void_p(mel_ptr)
+        _lib.check(self._lib.ltk_wav2lip_infer(self._h, arr, len(reqs), C.c_void_p(d_pred_ptr), C.c_void_p(stream)))
+
+    def paste_back(self, avatar_id: int, idx: int, d_pred_ptr: int, out: np.ndarray, stream: int = 0):
+        """out: C-contiguous uint8 (H,W,3) host array, filled in place."""
+        _lib.check(self._lib.ltk_paste_back(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr),
+                                            out.ctypes.data, 0, C.c_void_p(stream)))
+
+    def paste_back_device(self, avatar_id: int, idx: int, d_pred_ptr: int, d_out_ptr: int, stream: int = 0):
+        _lib.check(self._lib.ltk_paste_back(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr),
+                                            C.c_void_p(d_out_ptr), 1, C.c_void_p(stream)))
+
+    # ------------------------------------------------------------------ test / measurement hooks
+    def wav2lip_forward_host(self, mel: np.ndarray, face6: np.ndarray) -> np.ndarray:
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, 80, 16)
+        face6 = np.ascontiguousarray(face6, dtype=np.float32)
+        B = face6.shape[0]
+        assert face6.shape[1:] == (6, 256, 256) and mel.shape[0] == B
+        pred = np.empty((B, 3, 256, 256), dtype=np.float32)
+        _lib.check(self._lib.ltk_wav2lip_forward_host(self._h, mel.ctypes.data, face6.ctypes.data, B, pred.ctypes.data))
+        return pred
+
+    def debug_capture(self, enable: bool):
+        _lib.check(self._lib.ltk_debug_capture(self._h, 1 if enable else 0))
+
+    def debug_get(self, layer: str, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float32)
+        _lib.check(self._lib.ltk_debug_get(self._h, layer.encode(), out.ctypes.data, out.size))
+        return out
+
+    def time_convs(self, frames: int, iters: int):
+        ms = C.c_float()
+        macs = C.c_double()
+        _lib.check(self._lib.ltk_wav2lip_time_convs(self._h, int(frames), int(iters), C.byref(ms), C.byref(macs)))
+        return ms.value, macs.value
+
+    def conv2d_f16(self, d_x_ptr: int, N, H, W, Cin, weight: np.ndarray, Cout, k, stride, pad, transposed=False,
+                   out_pad=0, scale: Optional[np.ndarray] = None, shift: Optional[np.ndarray] = None,
+                   d_res_ptr: int = 0, relu=True, d_y_ptr: int = 0, iters: int = 0) -> float:
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        sc = np.ascontiguousarray(scale, dtype=np.float32) if scale is not None else None
+        sf = np.ascontiguousarray(shift, dtype=np.float32) if shift is not None else None
+        ms = C.c_float(0)
+        kh, kw = (k, k) if isinstance(k, int) else k
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        ph, pw = (pad, pad) if isinstance(pad, int) else pad
+        _lib.check(self._lib.ltk_conv2d_f16(
+            self._h, C.c_void_p(d_x_ptr), N, H, W, Cin, w.ctypes.data, Cout, kh, kw, sh, sw, ph, pw,
+            1 if transposed else 0, out_pad, sc.ctypes.data if sc is not None else None,
+            sf.ctypes.data if sf is not None else None, C.c_void_p(d_res_ptr) if d_res_ptr else None,
+            1 if relu else 0, C.c_void_p(d_y_ptr), iters, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,108 @@
+"""HIP implicit-GEMM conv kernel vs a plain PyTorch fp32 reference of the same op
+(every distinct layer geometry of avatars/wav2lip/models/wav2lip_v2.py:12-91)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+# (N, H, W, Cin, Cout, k, stride, pad, transposed, out_pad, residual)
+CASES = [
+    # audio encoder
+    (3, 80, 16, 1, 32, 3, 1, 1, False, 0, False),
+    (3, 80, 16, 32, 32, 3, 1, 1, False, 0, True),
+    (3, 80, 16, 32, 64, 3, (3, 1), 1, False, 0, False),
+    (3, 27, 16, 64, 64, 3, 1, 1, False, 0, True),
+    (3, 27, 16, 64, 128, 3, 3, 1, False, 0, False),
+    (3, 9, 6, 128, 128, 3, 1, 1, False, 0, True),
+    (3, 9, 6, 128, 256, 3, (3, 2), 1, False, 0, False),
+    (3, 3, 3, 256, 256, 3, 1, 1, False, 0, True),
+    (3, 3, 3, 256, 512, 3, 1, 0, False, 0, False),
+    (3, 1, 1, 512, 512, 1, 1, 0, False, 0, False),
+    (19, 1, 1, 512, 512, 1, 1, 0, False, 0, False),
+    # face encoder
+    (2, 256, 256, 6, 16, 7, 1, 3, False, 0, False),
+    (2, 256, 256, 16, 32, 3, 2, 1, False, 0, False),
+    (2, 128, 128, 32, 32, 3, 1, 1, False, 0, True),
+    (2, 128, 128, 32, 64, 3, 2, 1, False, 0, False),
+    (2, 64, 64, 64, 64, 3, 1, 1, False, 0, True),
+    (2, 64, 64, 64, 128, 3, 2, 1, False, 0, False),
+    (2, 32, 32, 128, 128, 3, 1, 1, False, 0, True),
+    (2, 32, 32, 128, 256, 3, 2, 1, False, 0, False),
+    (3, 16, 16, 256, 256, 3, 1, 1, False, 0, True),
+    (3, 16, 16, 256, 512, 3, 2, 1, False, 0, False),
+    (3, 8, 8, 512, 512, 3, 1, 1, False, 0, True),
+    (3, 8, 8, 512, 512, 3, 2, 1, False, 0, False),
+    (5, 4, 4, 512, 512, 3, 1, 1, False, 0, True),
+    (5, 4, 4, 512, 512, 4, 1, 0, False, 0, False),
+    # decoder
+    (3, 1, 1, 1024, 512, 4, 1, 0, True, 0, False),
+    (3, 4, 4, 1024, 512, 3, 2, 1, True, 1, False),
+    (3, 8, 8, 1024, 512, 3, 2, 1, True, 1, False),
+    (2, 16, 16, 768, 384, 3, 2, 1, True, 1, False),
+    (2, 32, 32, 384, 384, 3, 1, 1, False, 0, True),
+    (2, 32, 32, 512, 256, 3, 2, 1, True, 1, False),
+    (2, 64, 64, 256, 256, 3, 1, 1, False, 0, True),
+    (2, 64, 64, 320, 128, 3, 2, 1, True, 1, False),
+    (1, 128, 128, 160, 64, 3, 2, 1, True, 1, False),
+    (1, 256, 256, 64, 64, 3, 1, 1, False, 0, True),
+    (1, 256, 256, 80, 32, 3, 1, 1, False, 0, False),
+    # ragged maps (partial tiles in both directions)
+    (2, 37, 21, 32, 32, 3, 1, 1, False, 0, True),
+    (2, 45, 70, 64, 64, 3, 2, 1, False, 0, False),
+]
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else v
+
+
+def run_case(eng, case, seed):
+    N, H, W, Cin, Cout, k, stride, pad, transposed, out_pad, residual = case
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g).half().float()
+    fan = Cin * k * k / (_pair(stride)[0] * _pair(stride)[1] if transposed else 1)
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = (torch.randn(wshape, generator=g) * (2.0 / fan) ** 0.5).half().float()
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    xd, wd = x.cuda(), w.cuda()
+    if transposed:
+        ref = F.conv_transpose2d(xd, wd, None, stride=_pair(stride), padding=_pair(pad), output_padding=out_pad)
+    else:
+        ref = F.conv2d(xd, wd, None, stride=_pair(stride), padding=_pair(pad))
+    ref = ref * scale.cuda()[None, :, None, None] + shift.cuda()[None, :, None, None]
+    cin_pad = (Cin + 7) // 8 * 8
+    x_nhwc = torch.zeros(N, H, W, cin_pad, dtype=torch.float16, device="cuda")
+    x_nhwc[..., :Cin] = xd.permute(0, 2, 3, 1).half()
+    res_ptr = 0
+    if residual:
+        ref = ref + xd
+        res_ptr = x_nhwc.data_ptr()
+    ref = torch.relu(ref)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.float16, device="cuda")
+    eng.conv2d_f16(x_nhwc.data_ptr(), N, H, W, Cin, w.numpy(), Cout, k, stride, pad, transposed, out_pad,
+                   scale.numpy(), shift.numpy(), res_ptr, True, y.data_ptr())
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).float()
+    err = (got - ref).abs()
+    tol = 2e-3 * ref.abs().clamp(min=1.0) + 2e-3
+    bad = (~(err <= tol)).sum().item()   # NaNs count as bad
+    return bad, float(torch.nan_to_num(err, nan=1e9).max()), float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_conv_every_wav2lip_geometry(engine):
+    report = []
+    for i, case in enumerate(CASES):
+        try:
+            bad, maxerr, refmax = run_case(engine, case, 100 + i)
+        except Exception as ex:  # report all cases, not just the first
+            report.append(f"case {i} {case}: EXC {ex}")
+            continue
+        status = "ok" if bad == 0 else "FAIL"
+        print(f"[conv] {status} case {i} {case}: bad={bad} maxerr={maxerr:.4g} refmax={refmax:.3g}")
+        if bad:
+            report.append(f"case {i} {case}: {bad} elements out of tolerance, max err {maxerr:.4g} (ref max {refmax:.3g})")
+    assert not report, "\n".join(report)

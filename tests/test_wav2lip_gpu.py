@@ -1,0 +1,100 @@
+"""Parity of the HIP Wav2Lip path against the oracle (oracle/wav2lip_oracle.py,
+pinned to the reference by oracle/gen_golden.py) and the committed golden
+fixtures produced by the reference's own LipReal.inference_batch.
+
+Tolerances (fp16 activations / fp32 accumulate vs the reference's fp32):
+  per layer : relative L2 error <= 1e-2, |mean| drift small
+  frames    : PSNR >= 40 dB and max-abs <= 6 LSB on the uint8 face crop,
+              >= 99% of bytes within +-2 LSB
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import mel_oracle, plugin_oracle, synth, wav2lip_oracle  # noqa: E402
+
+
+def _golden_inputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wav2lip_golden.npz"))
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    hw = tuple(int(v) for v in g["avatar_hw"])
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=int(g["avatar_frames"]), full_hw=hw,
+                                                 box=int(g["avatar_box"]), seed=int(g["avatar_seed"]))
+    assert zlib.crc32(b"".join(f.tobytes() for f in faces)) == int(g["face_crc"]), "synthetic bank drifted"
+    feats = [gm["ref_chunks"][int(g["mel_step"])][i] for i in range(int(g["batch"]))]
+    return g, frames, faces, coords, feats
+
+
+def psnr_u8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.gpu
+def test_layers_vs_oracle(engine, golden_dir):
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(int(g["weight_seed"])).items()}
+    mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, feats)
+    taps = {}
+    ref = wav2lip_oracle.forward(sd, mel_t, img_t, taps).numpy()
+    engine.debug_capture(True)
+    try:
+        got = engine.wav2lip_forward_host(mel_t.numpy().reshape(B, 80, 16), img_t.numpy())
+        report = []
+        for name in [l.prefix for l in wav2lip_oracle.all_block_layers()]:
+            r = taps[name].numpy()
+            o = engine.debug_get(name, r.shape)
+            rel = float(np.linalg.norm(o - r) / max(np.linalg.norm(r), 1e-9))
+            mx = float(np.abs(o - r).max())
+            print(f"[layer] {name:28s} rel_l2={rel:.3e} maxabs={mx:.3e} refmax={np.abs(r).max():.3g}")
+            if not (rel <= 1e-2):
+                report.append(f"{name}: rel L2 {rel:.3e} (max abs {mx:.3e})")
+    finally:
+        engine.debug_capture(False)
+    assert not report, "\n".join(report)
+    err = np.abs(got - ref)
+    print(f"[forward] sigmoid max abs err {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < 2.5e-2 and err.mean() < 2e-3
+
+
+@pytest.mark.gpu
+def test_infer_vs_reference_golden(engine, golden_dir):
+    """ltk_wav2lip_infer (bank gather + mask + pack + 55 layers + head) against
+    the frames the reference's LipReal.inference_batch produced."""
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    aid = engine.register_avatar(faces, frames, coords)
+    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    engine.wav2lip_infer([(aid, index, B, mel.data_ptr())], pred.data_ptr())
+    got = pred.cpu().numpy()
+    ref = g["ref_pred_u8"]
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    p = psnr_u8(got, ref)
+    frac2 = float((d <= 2).mean())
+    print(f"[infer] PSNR {p:.2f} dB, max abs {d.max()} LSB, within+-2: {frac2:.5f}, within+-1: {float((d <= 1).mean()):.5f}")
+    assert p >= 40.0 and d.max() <= 6 and frac2 >= 0.99
+    engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
+def test_infer_batching_invariance(engine, golden_dir):
+    """Two sessions coalesced into one launch == the same sessions run one by one
+    (cross-session batching must not change any session's frames)."""
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    aid = engine.register_avatar(faces, frames, coords)
+    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    a = torch.zeros(4, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(3, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr())], a.data_ptr())
+    engine.wav2lip_infer([(aid, 7, 3, mel.data_ptr())], b.data_ptr())
+    both = torch.zeros(7, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr()), (aid, 7, 3, mel.data_ptr())], both.data_ptr())
+    assert torch.equal(both[:4], a) and torch.equal(both[4:], b)
+    engine.release_avatar(aid)
