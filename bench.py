@@ -96,11 +96,11 @@ def main():
     for s in range(S):
         off = (s * 977) % (len(audio) - n_chunks * 320)
         eng.mel_step(audio[off: off + n_chunks * 320], starts, d_mel[s].data_ptr())
-    d_pred = torch.zeros(frames_per_step, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    d_pred = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
 
     def step(i):
-        reqs = [(aid, i * B + 7 * s, B, d_mel[s].data_ptr()) for s in range(S)]
-        eng.wav2lip_infer(reqs, d_pred.data_ptr())
+        reqs = [(aid, i * B + 7 * s, B, d_mel[s].data_ptr(), d_pred[s].data_ptr()) for s in range(S)]
+        eng.wav2lip_infer(reqs)
 
     for i in range(args.warmup):
         step(i)

@@ -47,6 +47,7 @@ typedef struct ltk_w2l_req {
     int index;             /* BaseAvatar.inference's running `index` (base_avatar.py:328,366) */
     int batch;             /* frames in this request (opt.batch_size) */
     const void* d_mel;     /* device, float32 [batch][80][16] (what ltk_mel_step wrote) */
+    void* d_pred;          /* device, uint8 [batch][256][256][3] BGR: this request's frames */
 } ltk_w2l_req;
 
 const char* ltk_last_error(void);
@@ -87,8 +88,8 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
  * sessions at once: bank gather + lower-half mask + 6-channel pack, the 55
  * conv/convT layers of Wav2Lip.forward (wav2lip_v2.py:123-163), sigmoid*255 and
  * the uint8 truncation paste_back_frame applies (wav2lip_avatar.py:138,145).
- * d_pred_u8: device uint8 [sum(batch)][256][256][3] BGR, request-major. */
-int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* d_pred_u8, void* stream);
+ * Each request's frames land in its own d_pred.  Returns when they are ready. */
+int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream);
 
 /* avatars/wav2lip_avatar.py:141-147 LipReal.paste_back_frame: bilinear-resize
  * (cv2.resize INTER_LINEAR semantics) the 256x256 prediction to the frame's box

@@ -24,7 +24,8 @@ class NamedTensor(C.Structure):
 
 
 class W2lReq(C.Structure):
-    _fields_ = [("avatar", C.c_int), ("index", C.c_int), ("batch", C.c_int), ("d_mel", C.c_void_p)]
+    _fields_ = [("avatar", C.c_int), ("index", C.c_int), ("batch", C.c_int), ("d_mel", C.c_void_p),
+                ("d_pred", C.c_void_p)]
 
 
 # every symbol include/ltk.h declares: (restype, argtypes)
@@ -39,7 +40,7 @@ SYMBOLS = {
                                       C.POINTER(C.c_int)]),
     "ltk_avatar_release": (C.c_int, [C.c_void_p, C.c_int]),
     "ltk_mel_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p, C.c_void_p]),
+    "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p]),
     "ltk_paste_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,0 +1,151 @@
+"""HIP-backed drop-in for avatars/wav2lip_avatar.py.
+
+Module contract the reference's app.py relies on (app.py:128-151,99):
+  load_model(path) -> model handle        (wav2lip_avatar.py:59-70)
+  load_avatar(avatar_id) -> avatar tuple  (wav2lip_avatar.py:72-88)
+  warm_up(batch_size, model, modelres)    (wav2lip_avatar.py:90-96)
+  @register("avatar", "wav2lip") class LipReal(BaseAvatar) with
+  inference_batch(index, audiofeat_batch) and paste_back_frame(pred_frame, idx)
+                                          (wav2lip_avatar.py:98-147)
+
+What changes underneath: the model handle owns a per-GPU `Engine`
+(libltk_hip.so); the avatar bank is uploaded to HBM once per avatar;
+`inference_batch` returns device handles (uint8 256x256x3 crops, already
+truncated the way paste_back_frame's astype(uint8) does) instead of float
+numpy frames; `paste_back_frame` composites on the GPU and returns the same
+writable C-contiguous uint8 (H,W,3) BGR array the reference returns.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import pickle
+import threading
+
+import numpy as np
+
+from ..engine import Engine
+from ..hostshim import BaseAvatar, mirror_index, register
+from ..scheduler import get_scheduler
+from .audio_features.mel import MelASR
+
+_ENGINES = {}
+_ENGINES_LOCK = threading.Lock()
+
+
+class Wav2LipModel:
+    """Opaque `model` object handed back to app.py; process-global, shared by sessions."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+        self._avatars = {}          # id(face_list) -> engine avatar id
+        self._lock = threading.Lock()
+
+    def avatar_id(self, avatar) -> int:
+        frame_list, face_list, coord_list = avatar
+        key = id(face_list)
+        with self._lock:
+            aid = self._avatars.get(key)
+            if aid is None:
+                aid = self.engine.register_avatar(face_list, frame_list, coord_list)
+                self._avatars[key] = aid
+            return aid
+
+    def eval(self):
+        return self
+
+
+def _device_index() -> int:
+    return int(os.environ.get("LTK_DEVICE", "0"))
+
+
+def _state_dict_from_checkpoint(path):
+    import torch
+    checkpoint = torch.load(path, map_location="cpu")
+    s = checkpoint["state_dict"]
+    return {k.replace("module.", ""): v for k, v in s.items()}
+
+
+def load_model(path, state_dict=None, max_frames=None, device=None):
+    """`path` is the reference's ./models/wav2lip.pth; `state_dict` may be passed
+    directly (tests / bench use seeded synthetic weights: there is no checkpoint
+    in the reference tree)."""
+    if state_dict is None:
+        state_dict = _state_dict_from_checkpoint(path)
+    dev = _device_index() if device is None else int(device)
+    if max_frames is None:
+        max_frames = int(os.environ.get("LTK_MAX_FRAMES", "256"))
+    eng = Engine(dev)
+    eng.load_wav2lip(state_dict, max_frames=max_frames)
+    return Wav2LipModel(eng)
+
+
+def read_imgs(img_list):
+    import cv2  # same third-party reader the reference uses (utils/image.py:14-24)
+    return [cv2.imread(p) for p in img_list]
+
+
+def load_avatar(avatar_id):
+    avatar_path = f"./data/avatars/{avatar_id}"
+    with open(f"{avatar_path}/coords.pkl", "rb") as f:
+        coord_list_cycle = pickle.load(f)
+
+    def numbered(d):
+        files = glob.glob(os.path.join(d, "*.[jpJP][pnPN]*[gG]"))
+        return sorted(files, key=lambda x: int(os.path.splitext(os.path.basename(x))[0]))
+
+    frame_list_cycle = read_imgs(numbered(f"{avatar_path}/full_imgs"))
+    face_list_cycle = read_imgs(numbered(f"{avatar_path}/face_imgs"))
+    return frame_list_cycle, face_list_cycle, coord_list_cycle
+
+
+def warm_up(batch_size, model, modelres=256):
+    """One forward on ones, as the reference does, to fault in kernels and arena."""
+    mel = np.ones((batch_size, 80, 16), dtype=np.float32)
+    img = np.ones((batch_size, 6, modelres, modelres), dtype=np.float32)
+    n = min(batch_size, model.engine.max_frames)
+    model.engine.wav2lip_forward_host(mel[:n], img[:n])
+
+
+@register("avatar", "wav2lip")
+class LipReal(BaseAvatar):
+    def __init__(self, opt, model, avatar):
+        super().__init__(opt)
+        self.model = model
+        self.frame_list_cycle, self.face_list_cycle, self.coord_list_cycle = avatar
+        self._aid = model.avatar_id(avatar)
+        h, w = self.frame_list_cycle[0].shape[:2]
+        self._frame_hw = (int(h), int(w))
+        self._sched = get_scheduler(model.engine)
+        self.asr = MelASR(opt, self, engine=model.engine)
+        self.asr.warm_up()
+
+    def _mel_to_device(self, audiofeat_batch):
+        import torch
+        if isinstance(audiofeat_batch, torch.Tensor):
+            return audiofeat_batch
+        arr = np.ascontiguousarray(np.asarray(audiofeat_batch), dtype=np.float32)   # list of (80,16)
+        return torch.from_numpy(arr).to(torch.device("cuda", self.model.engine.device))
+
+    def inference_batch(self, index, audiofeat_batch):
+        """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for
+        bank index mirror_index(len, index+i)."""
+        import torch
+        mel = self._mel_to_device(audiofeat_batch)
+        B = self.batch_size
+        if mel.shape[0] != B:
+            raise ValueError(f"expected {B} mel windows, got {mel.shape[0]}")
+        pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=mel.device)
+        self._sched.infer(self._aid, int(index), B, mel.data_ptr(), pred.data_ptr())
+        self._last_mel = mel            # keep inputs alive until the call returned (it has)
+        return [pred[i] for i in range(B)]
+
+    def paste_back_frame(self, pred_frame, idx: int):
+        import torch
+        if not isinstance(pred_frame, torch.Tensor):   # a float frame from a foreign inference_batch
+            pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
+                torch.device("cuda", self.model.engine.device))
+        h, w = self._frame_hw
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        self.model.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)
+        return out

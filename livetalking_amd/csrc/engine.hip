@@ -566,36 +566,38 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
 }
 
 static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mels, const float* d_face6, int nf,
-                        uint8_t* d_pred_u8, float* d_pred_f32) {
+                        const OutPtrs* outs, float* d_pred_f32) {
     hipStream_t s = e->compute;
     if (faces) launch_pack_faces(*faces, nf, e->buf[B_X0], s);
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
     launch_pack_mel(*mels, nf, e->buf[B_MEL], s);
     int rc = run_convs(e, nf, s);
     if (rc) return rc;
-    launch_head(e->buf[B_OUT32], 32, nf * 65536, e->d_head, e->d_head + 96, d_pred_u8, d_pred_f32, 65536, s);
+    launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, outs, d_pred_f32, s);
     CHK(hipGetLastError());
     return 0;
 }
 
-int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* d_pred_u8, void* stream) {
-    if (!e || !reqs || nreq <= 0 || !d_pred_u8) return fail(LTK_E_INVALID, "bad arguments");
+int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream) {
+    if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
     CHK(hipSetDevice(e->device));
     // resolve every frame's bank crop and mel window up front
     std::vector<const uint8_t*> fptr;
     std::vector<const float*> mptr;
+    std::vector<uint8_t*> optr;
     {
         std::lock_guard<std::mutex> g(e->pool_mu);
         for (int r = 0; r < nreq; ++r) {
             auto it = e->avatars.find(reqs[r].avatar);
             if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
-            if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_mel) return fail(LTK_E_INVALID, "bad request");
+            if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_mel || !reqs[r].d_pred) return fail(LTK_E_INVALID, "bad request");
             const Avatar& a = it->second;
             for (int i = 0; i < reqs[r].batch; ++i) {
                 const int idx = mirror_index(a.n, reqs[r].index + i);  // wav2lip_avatar.py:121-124
                 fptr.push_back(a.d_face + (size_t)idx * 256 * 256 * 3);
                 mptr.push_back((const float*)reqs[r].d_mel + (size_t)i * 80 * 16);
+                optr.push_back((uint8_t*)reqs[r].d_pred + (size_t)i * 65536 * 3);
             }
         }
     }
@@ -616,9 +618,9 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* d_
         const int mbs = std::min(e->micro_batch, kPackMaxFrames);
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
-            FacePtrs fp; MelPtrs mp;
-            for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; }
-            rc = infer_locked(e, &fp, &mp, nullptr, nf, (uint8_t*)d_pred_u8 + (size_t)f0 * 65536 * 3, nullptr);
+            FacePtrs fp; MelPtrs mp; OutPtrs op;
+            for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; op.p[i] = optr[f0 + i]; }
+            rc = infer_locked(e, &fp, &mp, nullptr, nf, &op, nullptr);
         }
         if (!rc) {
             if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");

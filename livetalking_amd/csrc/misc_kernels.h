@@ -33,8 +33,11 @@ void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_
 // wav2lip_v2.py:90-91 + wav2lip_avatar.py:138,145: 1x1 conv 32->3 + sigmoid;
 // writes uint8 trunc(sigmoid*255) NHWC [B][256][256][3] and/or float32 sigmoid
 // NCHW [B][3][256][256] (either may be null).
-void launch_head(const f16* x32, int x_ld, int npix_total, const float* w3x32, const float* b3,
-                 uint8_t* out_u8, float* out_f32_nchw, int hw, hipStream_t s);
+struct OutPtrs {
+    uint8_t* p[kPackMaxFrames];       // per frame: uint8 [256][256][3] (null = skip)
+};
+void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
+                 const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s);
 
 // fp16 NHWC (ld, coff, C channels) -> float32 NCHW (debug capture).
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s);

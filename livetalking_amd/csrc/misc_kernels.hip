@@ -64,21 +64,21 @@ void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_
 // output head: nn.Conv2d(32,3,1) + Sigmoid (wav2lip_v2.py:90-91), *255 + uint8 truncation
 // (wav2lip_avatar.py:138,145).  One thread = 4 consecutive pixels -> 12 output bytes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_ld, int npix_total,
+__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_ld,
                                                     const float* __restrict__ w, const float* __restrict__ b,
-                                                    uint8_t* __restrict__ out_u8, float* __restrict__ out_f32, int hw) {
+                                                    const OutPtrs outs, int have_u8, float* __restrict__ out_f32) {
+    constexpr int hw = 65536;
     __shared__ float sw[3 * 32 + 3];
     if (threadIdx.x < 96) sw[threadIdx.x] = w[threadIdx.x];
     if (threadIdx.x < 3) sw[96 + threadIdx.x] = b[threadIdx.x];
     __syncthreads();
-    const int q = blockIdx.x * 256 + threadIdx.x;  // quad of pixels
-    const int p0 = q * 4;
-    if (p0 >= npix_total) return;
+    const int f = blockIdx.y;
+    const int r0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // first of 4 consecutive pixels of frame f
     unsigned bytes[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k;
-        const f16* px = x + (size_t)p * x_ld;
+        const int r = r0 + k;
+        const f16* px = x + ((size_t)f * hw + r) * x_ld;
         float acc0 = sw[96], acc1 = sw[97], acc2 = sw[98];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -95,8 +95,7 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, in
         const float s1 = 1.f / (1.f + __expf(-acc1));
         const float s2 = 1.f / (1.f + __expf(-acc2));
         if (out_f32) {
-            const int n = p / hw, r = p - n * hw;
-            float* o = out_f32 + (size_t)n * 3 * hw + r;
+            float* o = out_f32 + (size_t)f * 3 * hw + r;
             o[0] = s0; o[(size_t)hw] = s1; o[(size_t)2 * hw] = s2;
         }
         // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
@@ -106,17 +105,18 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, in
         bytes[(bo + 1) >> 2] |= u1 << (((bo + 1) & 3) * 8);
         bytes[(bo + 2) >> 2] |= u2 << (((bo + 2) & 3) * 8);
     }
-    if (out_u8) {
-        unsigned* o = reinterpret_cast<unsigned*>(out_u8 + (size_t)p0 * 3);
+    if (have_u8 && outs.p[f]) {
+        unsigned* o = reinterpret_cast<unsigned*>(outs.p[f] + (size_t)r0 * 3);
         o[0] = bytes[0]; o[1] = bytes[1]; o[2] = bytes[2];
     }
 }
 
-void launch_head(const f16* x32, int x_ld, int npix_total, const float* w3x32, const float* b3,
-                 uint8_t* out_u8, float* out_f32_nchw, int hw, hipStream_t s) {
-    const int quads = (npix_total + 3) / 4;
-    hipLaunchKernelGGL(head_kernel, dim3((quads + 255) / 256), dim3(256), 0, s, x32, x_ld, npix_total, w3x32, b3,
-                       out_u8, out_f32_nchw, hw);
+void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
+                 const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s) {
+    OutPtrs none;
+    if (!out_u8) for (int i = 0; i < nframes; ++i) none.p[i] = nullptr;
+    hipLaunchKernelGGL(head_kernel, dim3(64, nframes), dim3(256), 0, s, x32, x_ld, w3x32, b3,
+                       out_u8 ? *out_u8 : none, out_u8 ? 1 : 0, out_f32_nchw);
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, int N, int HW, int ld, int coff, int C,

@@ -99,15 +99,17 @@ class Engine:
         _lib.check(self._lib.ltk_mel_step(self._h, pcm.ctypes.data, pcm.shape[0], ws.ctypes.data, ws.shape[0],
                                           C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
-    def wav2lip_infer(self, reqs: Sequence[tuple], d_pred_ptr: int, stream: int = 0):
-        """reqs: (avatar_id, index, batch, d_mel_ptr) per session."""
+    def wav2lip_infer(self, reqs: Sequence[tuple], stream: int = 0):
+        """reqs: (avatar_id, index, batch, d_mel_ptr, d_pred_ptr) per session; each
+        session's uint8 frames [batch][256][256][3] land in its own d_pred."""
         arr = (W2lReq * len(reqs))()
-        for i, (aid, index, batch, mel_ptr) in enumerate(reqs):
+        for i, (aid, index, batch, mel_ptr, pred_ptr) in enumerate(reqs):
             arr[i].avatar = int(aid)
             arr[i].index = int(index)
             arr[i].batch = int(batch)
             arr[i].d_mel = C.c_void_p(mel_ptr)
-        _lib.check(self._lib.ltk_wav2lip_infer(self._h, arr, len(reqs), C.c_void_p(d_pred_ptr), C.c_void_p(stream)))
+            arr[i].d_pred = C.c_void_p(pred_ptr)
+        _lib.check(self._lib.ltk_wav2lip_infer(self._h, arr, len(reqs), C.c_void_p(stream)))
 
     def paste_back(self, avatar_id: int, idx: int, d_pred_ptr: int, out: np.ndarray, stream: int = 0):
         """out: C-contiguous uint8 (H,W,3) host array, filled in place."""

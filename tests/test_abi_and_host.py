@@ -1,0 +1,146 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ltk.h declares
+(no compute calls - there is no GPU here), and the host-side mirror of the
+reference's plugin interface behaves like the reference's."""
+import argparse
+import ctypes
+import os
+import re
+import sys
+import threading
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ltk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from livetalking_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    assert sorted(_lib.SYMBOLS) == declared, "ctypes binding and include/ltk.h disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    loaded = _lib.load()
+    assert loaded.ltk_version().startswith(b"ltk_hip")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from livetalking_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_window_starts_match_reference_slicing():
+    from livetalking_amd.avatars.audio_features.mel import window_starts
+    from oracle import mel_oracle
+    assert window_starts(52, 10, 10, 25, 84) == mel_oracle.window_starts(52, 10, 10)
+    assert window_starts(22, 10, 10, 25, 36) == [16]
+    # tail clamp (mel.py:58-59): a window that would overrun starts at n_cols-16
+    assert window_starts(52, 10, 10, 25, 70)[-1] == 54
+
+
+class FakeEngine:
+    """Stands in for the HIP engine: records calls, fills nothing."""
+    device = 0
+    max_frames = 64
+
+    def __init__(self):
+        self.mel_calls, self.infer_calls = [], []
+        self.lock = threading.Lock()
+
+    def mel_step(self, pcm, starts, ptr, stream=0):
+        self.mel_calls.append((np.array(pcm, copy=True), list(starts)))
+
+    def wav2lip_infer(self, reqs, stream=0):
+        with self.lock:
+            self.infer_calls.append(list(reqs))
+
+
+def test_melasr_protocol_matches_reference_cadence(monkeypatch):
+    """Same queue traffic as mel.py:34-67: 2B chunks out per step, one feature batch
+    once context exists, l+r chunks retained."""
+    torch = pytest.importorskip("torch")
+    from livetalking_amd.avatars.audio_features import mel as melmod
+    opt = argparse.Namespace(fps=25, batch_size=16, l=10, r=10)
+    eng = FakeEngine()
+    asr = melmod.MelASR(opt, None, engine=eng)
+    monkeypatch.setattr(asr, "_torch", types.SimpleNamespace(
+        empty=lambda shape, dtype=None, device=None: types.SimpleNamespace(shape=shape, data_ptr=lambda: 0),
+        float32=None, device=lambda *a: None))
+    rng = np.random.default_rng(0)
+    chunks = [rng.standard_normal(320).astype(np.float32) for _ in range(20 + 64)]
+    for c in chunks:
+        asr.put_audio_frame(c, {})
+    asr.warm_up()
+    assert asr.output_queue.qsize() == 10 and len(asr.frames) == 20
+    asr.run_step()
+    assert asr.output_queue.qsize() == 10 + 32 and asr.feat_queue.qsize() == 1 and len(asr.frames) == 20
+    pcm, starts = eng.mel_calls[0]
+    assert pcm.shape == (16640,) and np.array_equal(pcm, np.concatenate(chunks[:52]))
+    assert starts == [16, 19, 22, 25, 28, 32, 35, 38, 41, 44, 48, 51, 54, 57, 60, 64]
+    asr.run_step()
+    assert np.array_equal(eng.mel_calls[1][0], np.concatenate(chunks[32:84]))
+    # silence synthesis when the queue runs dry: zeros, type 1 (base_asr.py:66-69)
+    f = asr.get_audio_frame()
+    assert f.type == 1 and not f.data.any()
+
+
+def test_coalescing_scheduler_groups_concurrent_sessions():
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+    eng = FakeEngine()
+    sch = scheduler.CoalescingScheduler(eng, window_ms=200.0)
+    threads = [threading.Thread(target=sch.infer, args=(1, 16 * i, 16, 1000 + i, 2000 + i)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=10)
+    sch.close()
+    total = sorted(r for call in eng.infer_calls for r in call)
+    assert total == [(1, 0, 16, 1000, 2000), (1, 16, 16, 1001, 2001), (1, 32, 16, 1002, 2002)]
+    assert len(eng.infer_calls) < 3, "requests inside the window must share a launch"
+
+
+def test_least_loaded_placement_and_round_robin():
+    from livetalking_amd.sharding import LeastLoaded, assign_round_robin, shard_for_rank
+    shards = assign_round_robin(128, 8)
+    assert all(len(s) == 16 for s in shards) and sorted(sum(shards, [])) == list(range(128))
+    assert shard_for_rank(10, 4, 3) == [3, 7]
+    p = LeastLoaded(2, capacity_per_gpu=2)
+    assert [p.place(s) for s in "abcd"] == [0, 1, 0, 1]
+    with pytest.raises(RuntimeError):
+        p.place("e")
+    p.release("a")
+    assert p.place("e") == 0 and p.place("b") == 1
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the upstream checkout (build container only)")
+def test_plugin_module_contract_against_reference_app():
+    """The names app.py pulls from the plugin module exist with the reference's
+    signatures (app.py:134-151) and LipReal registers under ("avatar","wav2lip")."""
+    import inspect
+    import livetalking_amd.avatars.wav2lip_avatar as mine
+    src = open(os.path.join(REFERENCE, "app.py")).read()
+    for fn in ("load_model", "load_avatar", "warm_up"):
+        assert f"avatar_mod.{fn}" in src or fn in src
+        assert callable(getattr(mine, fn))
+    assert list(inspect.signature(mine.warm_up).parameters)[:3] == ["batch_size", "model", "modelres"]
+    assert list(inspect.signature(mine.load_model).parameters)[0] == "path"
+    assert list(inspect.signature(mine.LipReal.__init__).parameters)[1:4] == ["opt", "model", "avatar"]
+    assert list(inspect.signature(mine.LipReal.inference_batch).parameters)[1:] == ["index", "audiofeat_batch"]
+    assert list(inspect.signature(mine.LipReal.paste_back_frame).parameters)[1:] == ["pred_frame", "idx"]

@@ -1,0 +1,101 @@
+"""CPU: the oracle restatements against the committed golden fixtures that were
+produced by the reference's own code (oracle/gen_golden.py)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import mel_oracle, paste_oracle, plugin_oracle, synth, wav2lip_oracle
+
+
+def test_macs_per_frame_matches_survey():
+    assert wav2lip_oracle.macs_per_frame() == 27_788_599_296
+
+
+def test_mel_filterbank_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    fb = mel_oracle.mel_filterbank(16000, 400, 80, 0.0, 8000.0)   # the in-tree whisper asset's parameters
+    assert np.abs(fb.reshape(-1)[g["fb_probe_pos"]] - g["fb_probe_vals"]).max() < 1e-6
+    assert np.abs(fb.sum(axis=1) - g["fb_rowsum"]).max() < 1e-5
+    assert float(g["fb_asset_maxerr"]) < 1e-6 and float(g["transformers_chain_maxerr"]) < 1e-5
+
+
+def test_mel_chain_matches_reference_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    audio = synth.synthetic_audio(float(g["audio_seconds"]), seed=int(g["audio_seed"]))
+    assert np.array_equal(mel_oracle.melspectrogram(audio[:16640]), g["ref_mel_step0"])
+    for s in range(3):
+        mine = np.stack(mel_oracle.mel_chunks(audio[s * 10240: s * 10240 + 16640], 52))
+        assert np.array_equal(mine, g["ref_chunks"][s])
+    assert mel_oracle.window_starts(52, 10, 10) == [int(v) for v in g["window_starts"]]
+    assert mel_oracle.window_starts(52, 10, 10) == [16, 19, 22, 25, 28, 32, 35, 38, 41, 44, 48, 51, 54, 57, 60, 64]
+    assert np.array_equal(np.stack(mel_oracle.mel_chunks(audio[:7040], 22)), g["ref_chunks_b1"])
+
+
+def test_mel_edge_padding_cannot_reach_consumed_columns():
+    wav = synth.synthetic_audio(1.04)[:16640]
+    a = mel_oracle.melspectrogram(wav, pad_mode="constant")
+    b = mel_oracle.melspectrogram(wav, pad_mode="reflect")
+    assert np.array_equal(a[:, 16:80], b[:, 16:80]) and not np.array_equal(a[:, :2], b[:, :2])
+
+
+def test_wav2lip_oracle_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wav2lip_golden.npz"))
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    sd_np = synth.wav2lip_state_dict(int(g["weight_seed"]))
+    assert zlib.crc32(b"".join(sd_np[k].tobytes() for k in sorted(sd_np))) == int(g["weight_crc"])
+    hw = tuple(int(v) for v in g["avatar_hw"])
+    frames, faces, coords = synth.wav2lip_avatar(int(g["avatar_frames"]), hw, int(g["avatar_box"]), int(g["avatar_seed"]))
+    assert zlib.crc32(b"".join(f.tobytes() for f in faces)) == int(g["face_crc"])
+    B, index = int(g["batch"]), int(g["index"])
+    feats = [gm["ref_chunks"][int(g["mel_step"])][i] for i in range(B)]
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    taps = {}
+    mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, feats)
+    pred = wav2lip_oracle.forward(sd, mel_t, img_t, taps).numpy().transpose(0, 2, 3, 1) * 255.
+    assert np.abs(pred[:, ::8, ::8] - g["ref_pred_sub"]).max() < 1e-3
+    d = np.abs(pred.astype(np.uint8).astype(np.int32) - g["ref_pred_u8"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-4      # truncation ties only
+    for n, pos, vals, st in zip(g["tap_names"], g["tap_pos"], g["tap_vals"], g["tap_stats"]):
+        t = taps[str(n)].numpy()
+        assert np.abs(t.reshape(-1)[pos] - vals).max() < 1e-3 * max(1.0, st[2]), n
+        assert abs(t.mean() - st[0]) < 1e-4 * max(1.0, abs(st[0])) + 1e-5, n
+
+
+def test_paste_oracle_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "paste_golden.npz"))
+    gw = np.load(os.path.join(golden_dir, "wav2lip_golden.npz"))
+    hw = tuple(int(v) for v in gw["avatar_hw"])
+    frames, faces, coords = synth.wav2lip_avatar(int(gw["avatar_frames"]), hw, int(gw["avatar_box"]), int(gw["avatar_seed"]))
+    B, index = int(gw["batch"]), int(gw["index"])
+    for i in range(B):
+        idx = paste_oracle.mirror_index(len(frames), index + i)
+        out = paste_oracle.paste_back_frame(gw["ref_pred_u8"][i].astype(np.float32), frames[idx], coords[idx])
+        assert zlib.crc32(out.tobytes()) == int(g["frame_crc"][i])
+        y1, y2, x1, x2 = coords[idx]
+        assert np.array_equal(out[y1:y2:4, x1:x2:4][:36, :36], g["bbox_sub"][i])
+        # outside the box the full frame is untouched, and the input frame is not mutated
+        mask = np.ones(out.shape[:2], bool); mask[y1:y2, x1:x2] = False
+        assert np.array_equal(out[mask], frames[idx][mask])
+
+
+def test_resize_properties():
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    assert np.array_equal(paste_oracle.resize_linear_u8(src, (256, 256)), src)
+    flat = np.full((256, 256, 3), 77, np.uint8)
+    for size in ((320, 311), (200, 190), (128, 128), (1, 1), (700, 3)):
+        out = paste_oracle.resize_linear_u8(flat, size)
+        assert out.shape == (size[1], size[0], 3) and (out == 77).all()
+    # monotone ramp stays monotone (no overshoot in the fixed-point path)
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 256, 0).repeat(3, 2)
+    up = paste_oracle.resize_linear_u8(ramp, (333, 300)).astype(int)
+    assert (np.diff(up[0, :, 0]) >= 0).all()
+
+
+def test_mirror_index_ping_pong():
+    assert [paste_oracle.mirror_index(3, i) for i in range(9)] == [0, 1, 2, 2, 1, 0, 0, 1, 2]
+    assert [paste_oracle.mirror_index(1, i) for i in range(4)] == [0, 0, 0, 0]

@@ -72,7 +72,7 @@ def test_infer_vs_reference_golden(engine, golden_dir):
     aid = engine.register_avatar(faces, frames, coords)
     mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
     pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
-    engine.wav2lip_infer([(aid, index, B, mel.data_ptr())], pred.data_ptr())
+    engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
     got = pred.cpu().numpy()
     ref = g["ref_pred_u8"]
     d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
@@ -92,9 +92,9 @@ def test_infer_batching_invariance(engine, golden_dir):
     mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
     a = torch.zeros(4, 256, 256, 3, dtype=torch.uint8, device="cuda")
     b = torch.zeros(3, 256, 256, 3, dtype=torch.uint8, device="cuda")
-    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr())], a.data_ptr())
-    engine.wav2lip_infer([(aid, 7, 3, mel.data_ptr())], b.data_ptr())
-    both = torch.zeros(7, 256, 256, 3, dtype=torch.uint8, device="cuda")
-    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr()), (aid, 7, 3, mel.data_ptr())], both.data_ptr())
-    assert torch.equal(both[:4], a) and torch.equal(both[4:], b)
+    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr(), a.data_ptr())])
+    engine.wav2lip_infer([(aid, 7, 3, mel.data_ptr(), b.data_ptr())])
+    a2, b2 = torch.zeros_like(a), torch.zeros_like(b)
+    engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr(), a2.data_ptr()), (aid, 7, 3, mel.data_ptr(), b2.data_ptr())])
+    assert torch.equal(a2, a) and torch.equal(b2, b)
     engine.release_avatar(aid)
