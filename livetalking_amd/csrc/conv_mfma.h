@@ -53,7 +53,8 @@ struct ConvArgs {
 // Static description of a conv layer (weights already packed on device).
 struct ConvPlan {
     // geometry
-    int Cin = 0, Cout = 0, CoutPad = 0;   // CoutPad: multiple of BN
+    int Cin = 0, Cout = 0, CoutPad = 0;   // CoutPad: multiple of 128
+    int lCout = 0;                        // output channels of the executed conv (k*k*Cout for the 1x1-expand)
     int kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0;
     bool transposed = false;              // ConvTranspose2d
     int out_pad = 0;
@@ -61,6 +62,7 @@ struct ConvPlan {
     // kernel config
     int NC8 = 4, NBT = 2;                 // channel planes per chunk, 32-cout subtiles per block
     bool tt9 = false;                     // 3x3 taps compiled in
+    int mode = 1;                         // 0 double-buffered LDS, 1 single-buffered + register prefetch
     int nphase = 1;
     int Tp = 0;
     ConvPhase phase[kMaxPhases];

@@ -27,6 +27,7 @@
 #include "conv_mfma.h"
 
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -57,8 +58,10 @@ struct KArgs {
     int tiles_x, tiles_y, tiles_n, n_ntiles;
     unsigned magicPW, magicPHW;
     int nchunks, Tp, relu;
+    int lds_bytes;
 };
 
+// A-patch staging registers per thread (16-byte items): the largest variant a configuration has.
 __host__ __device__ constexpr int max_a_items(int NC8, int NBT) {
     return NC8 == 4 ? 6 : (NC8 == 1 ? 5 : (NBT == 4 ? 3 : 10));
 }
@@ -66,11 +69,13 @@ constexpr int kMaxBItems = 9;
 constexpr int kTapTableBytes = 128;
 constexpr int kLdsLimit = 160 * 1024;
 
-template <int NC8, int NBT, bool TT9>
+// MODE 0: double-buffered LDS (one barrier per chunk, one workgroup per CU when the slabs are large)
+// MODE 1: single-buffered LDS + register prefetch (two barriers per chunk, several workgroups per CU
+//         overlap each other's load / epilogue phases)
+template <int NC8, int NBT, bool TT9, int MODE, int MAXA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BN = NBT * 32;
-    constexpr int MAXA = max_a_items(NC8, NBT);
     constexpr int MAXB = kMaxBItems;
     constexpr int LOG2NC8 = NC8 == 4 ? 2 : (NC8 == 2 ? 1 : 0);
 
@@ -102,9 +107,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 
     const int A_BYTES = NC8 * a.NPIXP * 16;
     const int B_BYTES = a.Tp * NC8 * BN * 16;
+    constexpr int NBUF = (MODE == 0) ? 2 : 1;
     unsigned char* const smemA = smem;
-    unsigned char* const smemB = smem + 2 * A_BYTES;
-    short* const tapl = reinterpret_cast<short*>(smem + 2 * A_BYTES + 2 * B_BYTES);
+    unsigned char* const smemB = smem + NBUF * A_BYTES;
+    // the tap table sits at the very end of the allocation (the epilogue reuses the front)
+    short* const tapl = reinterpret_cast<short*>(smem + a.lds_bytes - kTapTableBytes);
 
     if (tid < kMaxTaps) {
         short v = 0;
@@ -135,8 +142,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + c8 * 8) : -1;
     }
 
-    const int slab = a.Tp * NC8 * BN;  // 16-byte items per (cout tile, chunk)
-    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + pm->w_off16 + (size_t)ntile * a.nchunks * slab;
+    // weights are packed per 32-cout sub-slab: [cout/32][chunk][tap][plane][32][8 halfs]; a block
+    // with BN = NBT*32 stages NBT sub-slabs -> LDS image [sub][tap][plane][32][16 B]
+    const int slab32 = a.Tp * NC8 * 32;   // 16-byte items per (sub-slab, chunk)
+    const int slab = slab32 * NBT;
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + pm->w_off16 + (size_t)(ntile * NBT) * a.nchunks * slab32;
 
     uint4 ra[MAXA];
     uint4 rb[MAXB];
@@ -151,12 +161,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
                 v = *reinterpret_cast<const uint4*>(a.x + a_goff[k] + cbase * 8);
             ra[k] = v;
         }
-        const uint4* ws = wsrc + (size_t)c * slab;
+        const uint4* ws = wsrc + (size_t)c * slab32;
 #pragma unroll
         for (int k = 0; k < MAXB; ++k) {
             const int i = tid + k * 256;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i < slab) v = ws[i];
+            if (i < slab) {
+                int sub = 0;
+                if constexpr (NBT > 1) sub = (i >= slab32) + (NBT > 2 ? ((i >= 2 * slab32) + (i >= 3 * slab32)) : 0);
+                v = ws[(size_t)sub * a.nchunks * slab32 + (i - sub * slab32)];
+            }
             rb[k] = v;
         }
     };
@@ -203,17 +217,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-
     const int PS = a.NPIXP * 16;
     const int nchunks = a.nchunks;
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        const bool more = (c + 1) < nchunks;
-        if (more) load_chunk(c + 1);
-
+    auto compute_chunk = [&](int c, int cur) {
         const unsigned char* Ab = smemA + cur * A_BYTES;
         const unsigned char* Bb = smemB + cur * B_BYTES;
         if constexpr (NC8 == 1) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ab + pixb[j] + toff);
 #pragma unroll
-                for (int i = 0; i < NBT; ++i) wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((tp * BN) + i * 32 + l31) * 16);
+                for (int i = 0; i < NBT; ++i) wf[i] = *reinterpret_cast<const f16x8*>(Bb + (((i * a.Tp + tp) * 32) + l31) * 16);
 #pragma unroll
                 for (int i = 0; i < NBT; ++i)
 #pragma unroll
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
                         for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ab + plane * PS + pixb[j] + toff);
 #pragma unroll
                         for (int i = 0; i < NBT; ++i)
-                            wf[i] = *reinterpret_cast<const f16x8*>(Bb + (((t * NC8 + plane) * BN) + i * 32 + l31) * 16);
+                            wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * a.Tp + t) * NC8 + plane) * 32) + l31) * 16);
 #pragma unroll
                         for (int i = 0; i < NBT; ++i)
 #pragma unroll
@@ -262,44 +268,97 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
             }
         }
 
-        if (more) store_chunk(cur ^ 1);
+    };
+
+    load_chunk(0);
+    if constexpr (MODE == 0) {
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int cur = c & 1;
+            const bool more = (c + 1) < nchunks;
+            if (more) load_chunk(c + 1);
+            compute_chunk(c, cur);
+            if (more) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            if (c) __syncthreads();          // every wave is done reading chunk c-1
+            store_chunk(0);
+            __syncthreads();
+            if (c + 1 < nchunks) load_chunk(c + 1);   // in flight under the MFMAs
+            compute_chunk(c, 0);
+        }
         __syncthreads();
     }
 
-    // ---- epilogue: y = acc*scale + shift (+res) (relu) -> fp16, 4 channels (8 B) per store
+    // ---- epilogue: y = relu(acc*scale + shift + res) -> fp16, through a wave-private LDS
+    // transpose so the residual is READ and the result WRITTEN as whole 16-byte channel
+    // segments of a pixel row (8-byte scattered accesses from the MFMA C layout were
+    // issue-bound).  The main loop ended with a barrier: the front of LDS is free.
+    constexpr int ROWB = BN * 2 + 16;   // bytes per pixel row in the transpose region (+16: bank spread)
+    constexpr int SEGS = BN / 8;        // 16-byte segments per pixel row
+    constexpr int LOG2SEGS = NBT == 1 ? 2 : (NBT == 2 ? 3 : 4);
+    unsigned char* const wreg = smem + wave * (64 * ROWB);
     const int cout0 = ntile * BN;
+    const int nseg_valid = min(SEGS, (a.Cout - cout0) >> 3);
+    const bool has_res = a.res != nullptr;
+
+    if (has_res) {
+#pragma unroll
+        for (int it = 0; it < SEGS; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
+            const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
+            const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
+            const int orw = (row & 32) ? o1 : o0;
+            const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = *reinterpret_cast<const uint4*>(a.res + (size_t)orw * a.res_ld + a.res_coff + cout0 + seg * 8);
+            *reinterpret_cast<uint4*>(wreg + row * ROWB + seg * 16) = v;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NBT; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int co = cout0 + i * 32 + 8 * g + 4 * hh;
-            if (co < a.Cout) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + co);
+            const int cl = i * 32 + 8 * g + 4 * hh;     // channel within the block's BN
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);   // padded to CoutPad
+            const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (rowok[j]) {
-                        float v[4];
+            for (int j = 0; j < 2; ++j) {
+                unsigned char* p = wreg + (j * 32 + l31) * ROWB + cl * 2;
+                float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * sc[r] + sf[r];
-                        if (a.res) {
-                            const f16x4 rr = *reinterpret_cast<const f16x4*>(a.res + (size_t)orow[j] * a.res_ld + a.res_coff + co);
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * sc[r] + sf[r];
+                if (has_res) {
+                    const f16x4 rr = *reinterpret_cast<const f16x4*>(p);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                        }
-                        f16x4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float t = v[r];
-                            if (a.relu) t = fmaxf(t, 0.f);
-                            t = fminf(fmaxf(t, -65504.f), 65504.f);
-                            o[r] = (f16)t;
-                        }
-                        *reinterpret_cast<f16x4*>(a.y + (size_t)orow[j] * a.y_ld + a.y_coff + co) = o;
-                    }
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
                 }
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r];
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    t = fminf(fmaxf(t, -65504.f), 65504.f);
+                    o[r] = (f16)t;
+                }
+                *reinterpret_cast<f16x4*>(p) = o;
             }
         }
+    }
+#pragma unroll
+    for (int it = 0; it < SEGS; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
+        const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
+        const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
+        const int orw = (row & 32) ? o1 : o0;
+        const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+        const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + seg * 16);
+        if (ok) *reinterpret_cast<uint4*>(a.y + (size_t)orw * a.y_ld + a.y_coff + cout0 + seg * 8) = v;
     }
 }
 
@@ -309,22 +368,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 
 typedef void (*conv_kernel_t)(const KArgs);
 
-template <int NC8, int NBT, bool TT9>
-static conv_kernel_t kptr() { return conv_mfma_kernel<NC8, NBT, TT9>; }
+template <int NC8, int NBT, bool TT9, int MAXA>
+static conv_kernel_t kptr(int mode) {
+    return mode == 0 ? (conv_kernel_t)conv_mfma_kernel<NC8, NBT, TT9, 0, MAXA> : (conv_kernel_t)conv_mfma_kernel<NC8, NBT, TT9, 1, MAXA>;
+}
 
-static conv_kernel_t pick_kernel(int NC8, int NBT, bool tt9) {
-    if (NC8 == 1) return NBT == 1 ? kptr<1, 1, false>() : nullptr;
-    if (NC8 == 2) {
-        if (NBT == 1) return tt9 ? kptr<2, 1, true>() : kptr<2, 1, false>();
-        if (NBT == 2) return tt9 ? kptr<2, 2, true>() : kptr<2, 2, false>();
-        if (NBT == 4) return tt9 ? kptr<2, 4, true>() : kptr<2, 4, false>();
-    }
+// `need` = 16-byte A items per thread this launch stages; returns the smallest instantiation that holds them.
+static conv_kernel_t pick_kernel(int NC8, int NBT, bool tt9, int mode, int need) {
+    if (NC8 == 1) return (NBT == 1 && need <= 5) ? kptr<1, 1, false, 5>(mode) : nullptr;
     if (NC8 == 4) {
-        if (NBT == 1) return tt9 ? kptr<4, 1, true>() : kptr<4, 1, false>();
-        if (NBT == 2) return tt9 ? kptr<4, 2, true>() : kptr<4, 2, false>();
-        if (NBT == 4) return tt9 ? nullptr : kptr<4, 4, false>();
+        if (need > 6) return nullptr;
+        if (NBT == 1) return tt9 ? kptr<4, 1, true, 6>(mode) : kptr<4, 1, false, 6>(mode);
+        if (NBT == 2) return tt9 ? kptr<4, 2, true, 6>(mode) : kptr<4, 2, false, 6>(mode);
+        if (NBT == 4) return tt9 ? kptr<4, 4, true, 6>(mode) : kptr<4, 4, false, 6>(mode);
+    }
+    if (NC8 == 2) {
+        if (need <= 3) {
+            if (NBT == 1) return tt9 ? kptr<2, 1, true, 3>(mode) : kptr<2, 1, false, 3>(mode);
+            if (NBT == 2) return tt9 ? kptr<2, 2, true, 3>(mode) : kptr<2, 2, false, 3>(mode);
+            if (NBT == 4) return tt9 ? kptr<2, 4, true, 3>(mode) : kptr<2, 4, false, 3>(mode);
+        } else if (need <= 10) {
+            if (NBT == 1) return tt9 ? kptr<2, 1, true, 10>(mode) : kptr<2, 1, false, 10>(mode);
+            if (NBT == 2) return tt9 ? kptr<2, 2, true, 10>(mode) : kptr<2, 2, false, 10>(mode);
+        }
     }
     return nullptr;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 static int ceil_log2(int v) {
@@ -408,33 +481,40 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
     int NC8, NBT;
     const int Tmax = (int)std::max_element(phases.begin(), phases.end(),
                                            [](const std::vector<Tap>& a, const std::vector<Tap>& b) { return a.size() < b.size(); })->size();
+    const bool strided = (lsh > 1 || lsw > 1);
     if (Cin8 == 1) {
         NC8 = 1; NBT = 1;
         if (lCout > 32) { if (err) *err = "Cin<=8 layers support Cout<=32"; return -1; }
     } else {
         if (Cin8 % 2) { if (err) *err = "Cin must be 8 or a multiple of 16"; return -1; }
         NBT = lCout >= 128 ? 4 : (lCout >= 64 ? 2 : 1);
-        const bool strided = (lsh > 1 || lsw > 1);
-        if (strided) { NC8 = 2; NBT = std::min(NBT, 2); }
-        else if (Tmax > 9) { NC8 = 2; NBT = std::min(NBT, 2); }
-        else if (Tmax == 9 && NBT == 4) NC8 = 2;
-        else NC8 = (Cin8 >= 4) ? 4 : 2;
+        NC8 = (Cin8 >= 4) ? 4 : 2;
+        // tuning overrides (sweeps): LTK_CONV_NBT / LTK_CONV_NC8 apply where legal
+        const int fn = env_int("LTK_CONV_NBT", 0), fc = env_int("LTK_CONV_NC8", 0);
+        if (fn == 1 || fn == 2 || fn == 4) NBT = std::min(NBT, fn);
+        if (fc == 2 || (fc == 4 && Cin8 >= 4)) NC8 = fc;
+        if (strided || Tmax > 9) { NC8 = 2; NBT = std::min(NBT, 2); }   // large patches: 10 staging items, 2 planes
+        // weight slab of one chunk must fit the staging registers (9 x 16 B per thread)
+        while (((NC8 == 1) ? ((Tmax + 1) / 2 * 2) : Tmax) * NC8 * NBT * 32 > kMaxBItems * 256) {
+            if (NC8 > 2) NC8 /= 2; else if (NBT > 1) NBT /= 2; else break;
+        }
     }
-    const int BN = NBT * 32;
-    p->NC8 = NC8; p->NBT = NBT;
+    p->NC8 = NC8; p->NBT = NBT;      // NBT here = the widest block the staging registers allow
     p->tt9 = (!transposed && kh == 3 && kw == 3 && NC8 >= 2);
     p->nphase = (int)phases.size();
+    p->mode = env_int("LTK_CONV_MODE", 1);
     const int Tp = (NC8 == 1) ? ((Tmax + 1) / 2 * 2) : Tmax;
     p->Tp = Tp;
-    if (Tp * NC8 * BN > kMaxBItems * 256) { if (err) *err = "weight slab too large for staging registers"; return -1; }
-    if (!pick_kernel(NC8, NBT, p->tt9)) { if (err) *err = "no kernel instantiation for this configuration"; return -1; }
+    if (Tp * NC8 * NBT * 32 > kMaxBItems * 256) { if (err) *err = "weight slab too large for staging registers"; return -1; }
+    if (!pick_kernel(NC8, NBT, p->tt9, 1, 1)) { if (err) *err = "no kernel instantiation for this configuration"; return -1; }
 
-    const int CoutPad = (lCout + BN - 1) / BN * BN;
+    const int CoutPad = (lCout + 127) / 128 * 128;   // any block width <= 128 tiles it evenly
     p->CoutPad = CoutPad;
-    const int n_ntiles = CoutPad / BN;
+    p->lCout = lCout;
+    const int n_sub = CoutPad / 32;
     const int nchunks = (Cin8 + NC8 - 1) / NC8;
-    const size_t slab_halfs = (size_t)Tp * NC8 * BN * 8;
-    const size_t phase_halfs = (size_t)n_ntiles * nchunks * slab_halfs;
+    const size_t slab_halfs = (size_t)Tp * NC8 * 32 * 8;
+    const size_t phase_halfs = (size_t)n_sub * nchunks * slab_halfs;
     std::vector<f16> packed(phase_halfs * phases.size(), (f16)0.f);
 
     auto wval = [&](int co, int ci, int ky, int kx) -> float {
@@ -454,18 +534,18 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         for (int t = 0; t < m.T; ++t) { m.dy[t] = (signed char)phases[pi][t].dy; m.dx[t] = (signed char)phases[pi][t].dx; }
         p->phase[pi].T = m.T; p->phase[pi].ooy = m.ooy; p->phase[pi].oox = m.oox; p->phase[pi].w_off16 = m.w_off16;
         f16* base = packed.data() + pi * phase_halfs;
-        for (int nt = 0; nt < n_ntiles; ++nt)
+        for (int nt = 0; nt < n_sub; ++nt)
             for (int c = 0; c < nchunks; ++c)
                 for (int t = 0; t < m.T; ++t)
                     for (int pl = 0; pl < NC8; ++pl) {
                         const int c8 = c * NC8 + pl;
                         if (c8 >= Cin8) continue;
-                        for (int n = 0; n < BN; ++n) {
-                            const int lco = nt * BN + n;
+                        for (int n = 0; n < 32; ++n) {
+                            const int lco = nt * 32 + n;
                             if (lco >= lCout) continue;
                             int co = lco, ky = phases[pi][t].ky, kx = phases[pi][t].kx;
                             if (p->gemm_1x1_expand) { co = lco % Cout; const int pos = lco / Cout; ky = pos / kw; kx = pos % kw; }
-                            f16* dst = base + ((((size_t)(nt * nchunks + c) * Tp + t) * NC8 + pl) * BN + n) * 8;
+                            f16* dst = base + ((((size_t)(nt * nchunks + c) * Tp + t) * NC8 + pl) * 32 + n) * 8;
                             for (int j = 0; j < 8; ++j) dst[j] = (f16)wval(co, c8 * 8 + j, ky, kx);
                         }
                     }
@@ -501,7 +581,7 @@ static unsigned magic_u16(int d) { return (unsigned)((0x100000000ull + (unsigned
 int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err) {
     KArgs a;
     memset(&a, 0, sizeof(a));
-    const int NC8 = p.NC8, NBT = p.NBT, BN = NBT * 32;
+    const int NC8 = p.NC8;
     int HoA, WoA;
     p.out_dims(io.H, io.W, &HoA, &WoA);
     a.x = io.x; a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift; a.res = io.res; a.y = io.y;
@@ -535,6 +615,10 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     // tile: TW x TH output pixels x NB images, 256 rows
     int l2w = std::min(5, ceil_log2(a.Wo));
     int l2h = std::min(8 - l2w, ceil_log2(a.Ho));
+    const int forced_nbt = env_int("LTK_CONV_NBT", 0);
+    const int min_blocks = env_int("LTK_CONV_MIN_BLOCKS", 512);
+    int NBT = std::min(p.NBT, 2);
+    if (forced_nbt == 1 || forced_nbt == 2 || forced_nbt == 4) NBT = std::min(p.NBT, forced_nbt);
     const int maxpix = max_a_items(NC8, NBT) * 256 / NC8;
     int PH, PW, NB;
     for (;;) {
@@ -556,16 +640,30 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     a.tiles_x = (a.Wo + (1 << l2w) - 1) >> l2w;
     a.tiles_y = (a.Ho + (1 << l2h) - 1) >> l2h;
     a.tiles_n = (io.N + NB - 1) / NB;
-    a.n_ntiles = p.CoutPad / BN;
+    // block width: the widest (<= 64 couts unless forced) that still gives the chip >= min_blocks workgroups
+    const long long mtiles = (long long)p.nphase * a.tiles_n * a.tiles_y * a.tiles_x;
+    if (!forced_nbt)
+        while (NBT > 1 && mtiles * ((p.lCout + 32 * NBT - 1) / (32 * NBT)) < min_blocks) NBT /= 2;
+    const int BN = NBT * 32;
+    a.n_ntiles = (p.lCout + BN - 1) / BN;
     a.nchunks = (a.Cin8 + NC8 - 1) / NC8;
     a.Tp = p.Tp;
 
-    const size_t lds = (size_t)2 * NC8 * NPIXP * 16 + (size_t)2 * p.Tp * NC8 * BN * 16 + kTapTableBytes;
+    const size_t a_bytes = (size_t)NC8 * NPIXP * 16, b_bytes = (size_t)p.Tp * NC8 * BN * 16;
+    const size_t epi_bytes = (size_t)4 * 64 * (BN * 2 + 16);
+    int mode = p.mode ? 1 : 0;
+    if (mode == 0 && 2 * (a_bytes + b_bytes) + kTapTableBytes > (size_t)kLdsLimit) mode = 1;
+    size_t lds = (mode == 0 ? 2 : 1) * (a_bytes + b_bytes) + kTapTableBytes;
+    lds = std::max(lds, epi_bytes + kTapTableBytes);
+    lds = (lds + 255) / 256 * 256;
     if (lds > (size_t)kLdsLimit) { if (err) *err = "LDS budget exceeded"; return -1; }
+    a.lds_bytes = (int)lds;
     // largest 32-bit element offset the kernel forms
     if ((double)io.N * io.H * io.W * io.x_ld >= 2147483647.0) { if (err) *err = "input tensor too large for 32-bit offsets"; return -1; }
 
-    conv_kernel_t k = pick_kernel(NC8, NBT, p.tt9);
+    const int need = (npix * NC8 + 255) / 256;
+    conv_kernel_t k = pick_kernel(NC8, NBT, p.tt9, mode, need);
+    if (!k) { if (err) *err = "no kernel instantiation for this launch"; return -1; }
     const long long nblk = (long long)p.nphase * a.tiles_n * a.tiles_y * a.tiles_x * a.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
     static thread_local std::vector<const void*> configured;
