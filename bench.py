@@ -36,7 +36,8 @@ def cpu_baseline(batch: int, budget_s: float = 20.0):
     host cores, bounded sample."""
     import numpy as np
     import torch
-    from oracle import mel_oracle, plugin_oracle, synth
+    from livetalking_amd import synth
+    from oracle import mel_oracle, plugin_oracle   # the checker, timed here as the CPU baseline only
     torch.set_num_threads(os.cpu_count() or 1)
     sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(1234).items()}
     frames, faces, coords = synth.wav2lip_avatar(n_frames=8, full_hw=(360, 640), box=160, seed=0)
@@ -80,7 +81,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from livetalking_amd.engine import Engine
-    from oracle import synth  # seeded synthetic inputs only (generators, not the oracle path)
+    from livetalking_amd import synth  # seeded synthetic input generators (product-side; nothing from oracle/)
 
     S, B = args.sessions, args.batch
     frames_per_step = S * B

@@ -1,0 +1,139 @@
+"""Seeded synthetic inputs for parity tests and the bench.
+
+Input generators only - no reference arithmetic lives here, and nothing under
+oracle/ is imported.  There are no trained
+weights, avatar banks or audio clips in the reference tree, so every parity
+claim is made on these seeded stand-ins:
+
+* weights  - He-scaled conv kernels + randomised BatchNorm affine/running stats
+             under the reference state_dict names
+             (avatars/wav2lip/models/wav2lip_v2.py:12-91, conv.py:5-44);
+* audio    - the tone+noise formula of benchmark_asr.py:44-59;
+* avatar   - smooth low-pass-noise face crops / full frames and (y1,y2,x1,x2)
+             boxes in the layout `load_avatar` returns
+             (avatars/wav2lip_avatar.py:72-88, avatars/wav2lip/genavatar.py:130).
+
+Generators use numpy's PCG64 (`default_rng`) only, which is bit-stable across
+platforms, so the GPU box regenerates the exact tensors the golden fixtures
+were made from.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+# (state_dict prefix, kind, cin, cout, k, stride_product, residual) for the 54 Conv2d/Conv2dTranspose
+# blocks of avatars/wav2lip/models/wav2lip_v2.py:12-89, in state_dict order: only what the
+# generator needs (shapes + fan-in).  The engine's own table lives in csrc/engine.hip.
+def _layers():
+    L = []
+    def c(p, cin, cout, k, s=1, res=False): L.append((p, "conv", cin, cout, k, s, res))
+    def t(p, cin, cout, k, s): L.append((p, "convT", cin, cout, k, s, False))
+    a = "audio_encoder."
+    c(a + "0", 1, 32, 3); c(a + "1", 32, 32, 3, 1, True); c(a + "2", 32, 32, 3, 1, True)
+    c(a + "3", 32, 64, 3, 3); c(a + "4", 64, 64, 3, 1, True); c(a + "5", 64, 64, 3, 1, True)
+    c(a + "6", 64, 128, 3, 9); c(a + "7", 128, 128, 3, 1, True); c(a + "8", 128, 128, 3, 1, True)
+    c(a + "9", 128, 256, 3, 6); c(a + "10", 256, 256, 3, 1, True); c(a + "11", 256, 512, 3); c(a + "12", 512, 512, 1)
+    e = "face_encoder_blocks."
+    c(e + "0.0", 6, 16, 7)
+    for b, (ci, co, n) in enumerate([(16, 32, 2), (32, 64, 3), (64, 128, 2), (128, 256, 2), (256, 512, 1), (512, 512, 1)], start=1):
+        c(e + f"{b}.0", ci, co, 3, 4)
+        for j in range(1, n + 1): c(e + f"{b}.{j}", co, co, 3, 1, True)
+    c(e + "7.0", 512, 512, 4); c(e + "7.1", 512, 512, 1)
+    d = "face_decoder_blocks."
+    c(d + "0.0", 512, 512, 1)
+    t(d + "1.0", 1024, 512, 4, 1); c(d + "1.1", 512, 512, 3, 1, True)
+    for b, (ci, co, n) in enumerate([(1024, 512, 1), (1024, 512, 2), (768, 384, 2), (512, 256, 2), (320, 128, 2), (160, 64, 2)], start=2):
+        t(d + f"{b}.0", ci, co, 3, 4)
+        for j in range(1, n + 1): c(d + f"{b}.{j}", co, co, 3, 1, True)
+    c("output_block.0", 80, 32, 3)
+    return L
+
+OUTPUT_HEAD_PREFIX = "output_block.1"
+
+
+def wav2lip_state_dict(seed: int = 1234) -> Dict[str, np.ndarray]:
+    """Reference-named fp32 state_dict as numpy arrays (380 tensors)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for prefix, kind, cin, cout, k, sprod, residual in _layers():
+        if kind == "conv":
+            shape = (cout, cin, k, k)            # nn.Conv2d layout
+            fan_in = cin * k * k
+        else:
+            shape = (cin, cout, k, k)            # nn.ConvTranspose2d layout
+            # each output pixel of the s2 transposed conv sees ~k*k/s*s taps
+            fan_in = cin * k * k / sprod
+        std = np.sqrt(2.0 / fan_in)
+        sd[prefix + ".conv_block.0.weight"] = (rng.standard_normal(shape) * std).astype(np.float32)
+        sd[prefix + ".conv_block.0.bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+        # residual layers: damp the conv branch so y = relu(bn(conv(x)) + x) stays bounded
+        g_lo, g_hi = (0.3, 0.7) if residual else (0.7, 1.3)
+        sd[prefix + ".conv_block.1.weight"] = rng.uniform(g_lo, g_hi, cout).astype(np.float32)
+        sd[prefix + ".conv_block.1.bias"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        sd[prefix + ".conv_block.1.running_mean"] = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+        sd[prefix + ".conv_block.1.running_var"] = rng.uniform(0.6, 1.6, cout).astype(np.float32)
+        sd[prefix + ".conv_block.1.num_batches_tracked"] = np.asarray(1000, dtype=np.int64)
+    # output head: plain conv 32->3; scaled so the sigmoid is used across its range
+    sd[OUTPUT_HEAD_PREFIX + ".weight"] = (rng.standard_normal((3, 32, 1, 1)) * 0.04).astype(np.float32)
+    sd[OUTPUT_HEAD_PREFIX + ".bias"] = (rng.standard_normal(3) * 0.2).astype(np.float32)
+    return sd
+
+
+def synthetic_audio(duration_s: float, sample_rate: int = 16000, seed: int = 42) -> np.ndarray:
+    """benchmark_asr.py:44-59 (same constants, same seed by default)."""
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0, duration_s, int(sample_rate * duration_s), dtype=np.float32)
+    audio = (
+        0.3 * np.sin(2 * np.pi * 200 * t)
+        + 0.2 * np.sin(2 * np.pi * 500 * t)
+        + 0.1 * np.sin(2 * np.pi * 1200 * t)
+        + 0.15 * rng.standard_normal(len(t)).astype(np.float32)
+    )
+    fade = int(0.05 * sample_rate)
+    audio[:fade] *= np.linspace(0, 1, fade)
+    audio[-fade:] *= np.linspace(1, 0, fade)
+    return audio.astype(np.float32)
+
+
+def _smooth_image(rng: np.random.Generator, h: int, w: int, cells: int = 12) -> np.ndarray:
+    """Low-pass noise image uint8 (h,w,3): bilinear upsample of a coarse random
+    grid plus a little fine grain, so bilinear resize / PSNR are meaningful."""
+    gh, gw = cells + 1, cells * w // h + 2
+    coarse = rng.uniform(0, 255, (gh, gw, 3))
+    ys = np.linspace(0, gh - 1.001, h)
+    xs = np.linspace(0, gw - 1.001, w)
+    y0 = ys.astype(np.int64)
+    x0 = xs.astype(np.int64)
+    fy = (ys - y0)[:, None, None]
+    fx = (xs - x0)[None, :, None]
+    a = coarse[y0][:, x0]
+    b = coarse[y0][:, x0 + 1]
+    c = coarse[y0 + 1][:, x0]
+    d = coarse[y0 + 1][:, x0 + 1]
+    img = (a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx)
+    img += rng.normal(0, 3.0, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def wav2lip_avatar(n_frames: int = 8, full_hw: Tuple[int, int] = (720, 1280),
+                   box: int = 320, seed: int = 0
+                   ) -> Tuple[List[np.ndarray], List[np.ndarray], List[Tuple[int, int, int, int]]]:
+    """(frame_list_cycle, face_list_cycle, coord_list_cycle) as `load_avatar`
+    returns them (avatars/wav2lip_avatar.py:72-88): BGR uint8 full frames,
+    BGR uint8 256x256 face crops, (y1,y2,x1,x2) int boxes that differ per frame
+    (avatars/wav2lip/genavatar.py:118-130)."""
+    rng = np.random.default_rng(seed)
+    H, W_ = full_hw
+    frames, faces, coords = [], [], []
+    cy, cx = H // 2, W_ // 2
+    for _ in range(n_frames):
+        frames.append(_smooth_image(rng, H, W_))
+        faces.append(_smooth_image(rng, 256, 256, cells=10))
+        j = rng.integers(-4, 5, 4)
+        y1 = int(cy - box // 2 + j[0]); y2 = int(cy + box // 2 + j[1])
+        x1 = int(cx - box // 2 + j[2]); x2 = int(cx + box // 2 + j[3])
+        coords.append((y1, y2, x1, x2))
+    return frames, faces, coords
