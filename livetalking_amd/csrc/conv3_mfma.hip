@@ -1,0 +1,574 @@
+// conv3: LDS-DMA staged implicit-GEMM convolution for gfx950 (CDNA4), second generation.
+//
+// Covers the layers that carry 97 % of the generator's MACs (avatars/wav2lip/models/
+// wav2lip_v2.py:12-91 through conv.py:5-44):
+//   * Conv2d 3x3 s1 p1 and 1x1 (T = 9 / 1 taps)                                  G = 1
+//   * ConvTranspose2d(k3,s2,p1,op1): all four sub-pixel phases in ONE block       G = 4
+//     (the (TH+1)x(TW+1) input patch is staged once per channel chunk and its four
+//     shifted MFMA operands feed the 1/2/2/4 taps of the four phases)
+// What changed against conv_mfma.hip (kept for the 7x7 / strided layers):
+//   * staging is global_load_lds_dwordx4 straight into LDS (no staging VGPRs, no
+//     ds_write pass), two LDS stages, one barrier per channel chunk;
+//   * a wave owns PXW x 32 pixels x NBT x 32 output channels (G = 1: 128 px x 64 ch =
+//     8 accumulator tiles, 0.75 ds_read_b128 per MFMA instead of 1.0), so a block's
+//     weight slab is amortised over 512 pixels instead of 256;
+//   * split-K over channel chunks (fixed per layer, so results do not depend on the
+//     batch size) for the small-map layers whose grid cannot fill 256 CUs otherwise:
+//     fp32 partial slabs + conv3_finish (fixed summation order -> deterministic).
+// MFMA operand roles, folded-BN epilogue, channel-offset I/O and the weight pack order
+// ([cout/32][chunk][tap][plane][32][8 halfs]) are those of conv_mfma.hip.
+#include "conv_mfma.h"
+
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace ltk {
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct K3Args {
+    const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
+    float* partial;                  // split-K slabs [ksplit][Mtot][CoutP] or nullptr
+    int N, H, W, x_ld, x_coff;
+    int y_ld, y_coff, HoA, WoA;      // output pixel (n,oy,ox) -> ((n*HoA+oy)*WoA+ox)
+    int res_ld, res_coff;
+    int Cout, CoutP;                 // logical output channels; CoutP = padded (scale/shift/partial pitch)
+    int pad;                         // 1 for 3x3, 0 for 1x1 / transposed
+    int PH, PW, NPIXP, NPIX64, npix;
+    int log2TW, log2TH, NB;
+    int tiles_x, tiles_y, tiles_n, n_ntiles;
+    unsigned magicPW, magicPHW;
+    int nchunks, ksplit, chunks_per_split;
+    int relu;
+    int ablate;                      // measurement only (LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no residual read,
+                                     // 16 no output store, 32 no LDS zero fill
+    long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
+};
+
+__host__ __device__ constexpr int k3_maxa(int PXW, int NC8) {
+    // 16-byte A items per thread per chunk: NC8 * NPIX64 / 256
+    return PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
+}
+__host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT * T * NC8 * 32 + 255) / 256; }
+
+#define GLDS16(gptr, lptr)                                                                                   \
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                  \
+                                     (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
+// tap tables of the merged transposed conv: tap t reads input offset (dy,dx) = (o>>1, o&1) and
+// accumulates into phase g = (py<<1)|px.  Host packs the weights in this tap order (k3_convT_taps).
+//   t : 0 1 2 3 | 4 5 | 6 7 | 8
+//   o : 0 0 0 0 | 1 1 | 2 2 | 3
+//   g : 0 1 2 3 | 1 3 | 2 3 | 3
+template <int G, int NBT, int PXW, int NC8, int T>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BN = NBT * 32;
+    constexpr int MAXA = k3_maxa(PXW, NC8);
+    constexpr int MAXB = k3_maxb(NBT, NC8, T);
+    static_assert(G == 1 || (G == 4 && T == 9 && NBT == 1), "merged convT: 9 taps, 32 couts per block");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    // ---- block -> (k split, image tile, y tile, x tile, cout tile); XCD-contiguous logical ids
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int ntile = bid % a.n_ntiles;
+    int t0 = bid / a.n_ntiles;
+    const int tx_t = t0 % a.tiles_x; t0 /= a.tiles_x;
+    const int ty_t = t0 % a.tiles_y; t0 /= a.tiles_y;
+    const int tn_t = t0 % a.tiles_n;
+    const int ks = t0 / a.tiles_n;
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+
+    const int A_BYTES = NC8 * a.NPIXP * 16;
+    constexpr int B_BYTES = T * NC8 * BN * 16;
+    const int STAGE = A_BYTES + B_BYTES;
+
+    const int TWm = (1 << a.log2TW) - 1, THm = (1 << a.log2TH) - 1;
+    const int tx0 = tx_t << a.log2TW, ty0 = ty_t << a.log2TH, n0 = tn_t * a.NB;
+    const int iy0 = ty0 - a.pad, ix0 = tx0 - a.pad;
+    const int PHW = a.PH * a.PW;
+
+    // ---- zero both A stages once: halo slots outside the image are never written by the DMA
+    if (!(a.ablate & 32)) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid * 16; i < A_BYTES; i += 256 * 16) {
+            *reinterpret_cast<uint4*>(smem + i) = z;
+            *reinterpret_cast<uint4*>(smem + STAGE + i) = z;
+        }
+    }
+
+    // ---- A staging descriptors: item (k, wave) = 64 consecutive pixel slots of one channel plane
+    const int p64n = a.NPIX64 >> 6;          // 64-slot groups per plane
+    int a_goff[MAXA];                         // element offset of this lane's pixel (chunk 0), -1 = no copy
+    int a_ldst[MAXA];                         // wave-uniform LDS byte offset inside a stage
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        const int s64 = k * 4 + wave;                       // wave-uniform
+        const int plane = s64 / p64n;
+        const int pix = (s64 - plane * p64n) * 64 + lane;
+        const int b = (PHW == 1) ? pix : (int)__umulhi((unsigned)pix, a.magicPHW);
+        const int rem = pix - b * PHW;
+        const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
+        const int px = rem - py * a.PW;
+        const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
+        const bool ok = (plane < NC8) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
+                        ((unsigned)ix < (unsigned)a.W);
+        a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + plane * 8) : -1;
+        a_ldst[k] = __builtin_amdgcn_readfirstlane((plane * a.NPIXP + (s64 - plane * p64n) * 64) * 16);
+    }
+
+    // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
+    constexpr int slab32 = T * NC8 * 32;
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + (size_t)(ntile * NBT) * a.nchunks * slab32;
+    int b_goff[MAXB];                         // uint4 offset at chunk 0, -1 = no copy
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) {
+        const int i = tid + k * 256;
+        const int sub = (NBT > 1 && i >= slab32) ? 1 : 0;
+        b_goff[k] = (i < NBT * slab32) ? (sub * a.nchunks * slab32 + (i - sub * slab32)) : -1;
+    }
+
+    auto stage = [&](int c, int buf) {
+        unsigned char* const Ab = smem + buf * STAGE;
+        unsigned char* const Bb = Ab + A_BYTES;
+        const f16* xc = a.x + c * (NC8 * 8);
+        if (!(a.ablate & 1)) {
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k)
+                if (a_goff[k] >= 0) GLDS16(xc + a_goff[k], Ab + a_ldst[k]);
+        }
+        const uint4* wc = wsrc + (size_t)c * slab32;
+        if (!(a.ablate & 2)) {
+#pragma unroll
+            for (int k = 0; k < MAXB; ++k)
+                if (b_goff[k] >= 0) GLDS16(wc + b_goff[k], Bb + (k * 256 + wave * 64) * 16);
+        }
+    };
+
+    // ---- per-lane operand bases: this lane's pixel in each of the wave's PXW 32-pixel subtiles
+    int pixb[PXW];
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) {
+        const int m = (wave * PXW + j) * 32 + l31;
+        const int tx = m & TWm;
+        const int ty = (m >> a.log2TW) & THm;
+        const int b = m >> (a.log2TW + a.log2TH);
+        pixb[j] = (b < a.NB) ? ((b * a.PH + ty) * a.PW + tx) * 16 : 0;
+    }
+
+    f32x16 acc[G][NBT][PXW];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < NBT; ++i)
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][i][j][r] = 0.f;
+
+    const int PS = a.NPIXP * 16;
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = smem + buf * STAGE;
+        const unsigned char* Bb = Ab + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < NC8 / 2; ++q) {
+            const int plane = 2 * q + hh;
+            const unsigned char* Ap = Ab + plane * PS;
+            if constexpr (G == 1) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int toff = (T == 9) ? ((t / 3) * a.PW + (t % 3)) * 16 : 0;
+                    f16x8 xa[PXW], wf[NBT];
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + toff);
+#pragma unroll
+                    for (int i = 0; i < NBT; ++i)
+                        wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
+#pragma unroll
+                    for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                        for (int j = 0; j < PXW; ++j)
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xa[j], acc[0][i][j], 0, 0, 0);
+                }
+            } else {
+                auto wfrag = [&](int t) {
+                    return *reinterpret_cast<const f16x8*>(Bb + (((t * NC8 + plane) * 32) + l31) * 16);
+                };
+                f16x8 xa[PXW];
+                // offset (0,0): taps 0..3 -> phases 0..3
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f16x8 wf = wfrag(t);
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j)
+                        acc[t][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[j], acc[t][0][j], 0, 0, 0);
+                }
+                // offset (0,1): taps 4,5 -> phases 1,3
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + 16);
+                {
+                    const f16x8 w4 = wfrag(4), w5 = wfrag(5);
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) {
+                        acc[1][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4, xa[j], acc[1][0][j], 0, 0, 0);
+                        acc[3][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w5, xa[j], acc[3][0][j], 0, 0, 0);
+                    }
+                }
+                // offset (1,0): taps 6,7 -> phases 2,3
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + a.PW * 16);
+                {
+                    const f16x8 w6 = wfrag(6), w7 = wfrag(7);
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) {
+                        acc[2][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w6, xa[j], acc[2][0][j], 0, 0, 0);
+                        acc[3][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w7, xa[j], acc[3][0][j], 0, 0, 0);
+                    }
+                }
+                // offset (1,1): tap 8 -> phase 3
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + (a.PW + 1) * 16);
+                {
+                    const f16x8 w8 = wfrag(8);
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j)
+                        acc[3][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8, xa[j], acc[3][0][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    __syncthreads();                       // zero fill done before any DMA lands
+    stage(c_begin, 0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        __syncthreads();                   // vmcnt(0): chunk c landed; every wave left stage cur^1
+        if (c + 1 < c_end) stage(c + 1, cur ^ 1);
+        if (!(a.ablate & 4)) compute(cur);
+    }
+    __syncthreads();                       // LDS is reused by the epilogue
+
+    // ---- epilogue
+    const int cout0 = ntile * BN;
+    auto out_row = [&](int j, int g, bool* ok) -> int {
+        const int m = (wave * PXW + j) * 32 + l31;
+        const int tx = m & TWm;
+        const int ty = (m >> a.log2TW) & THm;
+        const int b = m >> (a.log2TW + a.log2TH);
+        const int n = n0 + b, y = ty0 + ty, x = tx0 + tx;
+        *ok = (b < a.NB) && (n < a.N) && (y < a.H) && (x < a.W);
+        const int oy = (G == 4) ? 2 * y + (g >> 1) : y;
+        const int ox = (G == 4) ? 2 * x + (g & 1) : x;
+        return (n * a.HoA + oy) * a.WoA + ox;
+    };
+
+    if (a.partial) {
+        // split-K: raw fp32 partial sums, slab ks; lane holds 4 consecutive couts per register group
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) {
+                bool ok;
+                const int orw = out_row(j, g, &ok);
+                if (!ok) continue;
+                float* dst = a.partial + ((size_t)ks * a.Mtot + orw) * a.CoutP + cout0;
+#pragma unroll
+                for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int cl = i * 32 + 8 * q4 + 4 * hh;
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r];
+                        *reinterpret_cast<f32x4*>(dst + cl) = v;
+                    }
+            }
+        return;
+    }
+
+    // y = relu(acc*scale + shift + res) -> fp16 through a wave-private LDS transpose (64 pixel rows x BN
+    // channels per pass) so residual reads and output writes are whole 16-byte channel segments.
+    constexpr int ROWB = BN * 2 + 16;
+    constexpr int SEGS = BN / 8;
+    constexpr int LOG2SEGS = NBT == 1 ? 2 : 3;
+    unsigned char* const wreg = smem + wave * (64 * ROWB);
+    const int nseg_valid = min(SEGS, (a.Cout - cout0) >> 3);
+    const bool has_res = a.res != nullptr && !(a.ablate & 8);
+    const bool do_store = !(a.ablate & 16);
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int jp = 0; jp < PXW / 2; ++jp) {
+            int orow[2];
+            bool rowok[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) orow[jj] = out_row(2 * jp + jj, g, &rowok[jj]);
+            if (has_res) {
+#pragma unroll
+                for (int it = 0; it < SEGS; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
+                    const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
+                    const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
+                    const int orw = (row & 32) ? o1 : o0;
+                    const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (ok) v = *reinterpret_cast<const uint4*>(a.res + (size_t)orw * a.res_ld + a.res_coff + cout0 + seg * 8);
+                    *reinterpret_cast<uint4*>(wreg + row * ROWB + seg * 16) = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int cl = i * 32 + 8 * q4 + 4 * hh;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);
+                    const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        unsigned char* p = wreg + (jj * 32 + l31) * ROWB + cl * 2;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[g][i][2 * jp + jj][4 * q4 + r] * sc[r] + sf[r];
+                        if (has_res) {
+                            const f16x4 rr = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                        }
+                        f16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = v[r];
+                            if (a.relu) t = fmaxf(t, 0.f);
+                            t = fminf(fmaxf(t, -65504.f), 65504.f);
+                            o[r] = (f16)t;
+                        }
+                        *reinterpret_cast<f16x4*>(p) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < SEGS; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
+                const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
+                const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
+                const int orw = (row & 32) ? o1 : o0;
+                const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+                const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + seg * 16);
+                if (ok && do_store) *reinterpret_cast<uint4*>(a.y + (size_t)orw * a.y_ld + a.y_coff + cout0 + seg * 8) = v;
+            }
+        }
+    }
+}
+
+// split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts.
+__global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restrict__ partial, int ksplit, long long Mtot,
+                                                            int CoutP, int Cout, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const f16* __restrict__ res,
+                                                            int res_ld, int res_coff, f16* __restrict__ y, int y_ld, int y_coff,
+                                                            int relu) {
+    const int segs = Cout >> 3;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mtot * segs) return;
+    const long long row = i / segs;
+    const int seg = (int)(i - row * segs);
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float* p = partial + ((size_t)s * Mtot + row) * CoutP + seg * 8;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; }
+    }
+    f16x8 rr;
+    if (res) rr = *reinterpret_cast<const f16x8*>(res + (size_t)row * res_ld + res_coff + seg * 8);
+    f16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float t = v[r] * scale[seg * 8 + r] + shift[seg * 8 + r];
+        if (res) t += (float)rr[r];
+        if (relu) t = fmaxf(t, 0.f);
+        t = fminf(fmaxf(t, -65504.f), 65504.f);
+        o[r] = (f16)t;
+    }
+    *reinterpret_cast<f16x8*>(y + (size_t)row * y_ld + y_coff + seg * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+typedef void (*k3_kernel_t)(const K3Args);
+
+static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
+#define K3CASE(g, n, p, c, t) \
+    if (G == g && NBT == n && PXW == p && NC8 == c && T == t) return (k3_kernel_t)conv3_kernel<g, n, p, c, t>
+    K3CASE(1, 2, 4, 2, 9); K3CASE(1, 2, 2, 2, 9); K3CASE(1, 1, 4, 2, 9); K3CASE(1, 1, 2, 2, 9);
+    K3CASE(1, 2, 2, 4, 9); K3CASE(1, 1, 2, 4, 9);
+    K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
+    K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
+#undef K3CASE
+    return nullptr;
+}
+
+static int ceil_log2_(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static unsigned magic_u16_(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+
+#define HIPCHK3(expr)                                                                 \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(_e);        \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+constexpr int kMaxKSplit = 32;
+
+// Split-K factor of a launch with `base` blocks and `nchunks` channel chunks: only under-filled grids are
+// split, every split keeps >= 2 chunks.  Depends on the batch size through `base`: outputs of launches with
+// different splits differ by fp32 summation order only.
+static int k3_ksplit(long long base, int nchunks) {
+    if (base >= 200 || nchunks < 4) return 1;
+    int s = (int)((256 + base - 1) / base);
+    s = std::min(s, std::min(nchunks / 2, kMaxKSplit));
+    return std::max(s, 1);
+}
+
+size_t conv3_partial_bytes(const ConvPlan& p, int N, int H, int W) {
+    if (!p.v3) return 0;
+    int Ho = H, Wo = W;
+    if (p.v3_G == 4) { Ho = 2 * H; Wo = 2 * W; }
+    // generous bound: the largest split any batch <= N may choose
+    return (size_t)kMaxKSplit * N * Ho * Wo * p.CoutPad * sizeof(float);
+}
+
+int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err) {
+    K3Args a;
+    memset(&a, 0, sizeof(a));
+    const int G = p.v3_G, T = p.v3_T, NC8 = p.NC8;
+    a.x = io.x; a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift; a.res = io.res; a.y = io.y;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.x_ld = io.x_ld; a.x_coff = io.x_coff;
+    a.res_ld = io.res_ld; a.res_coff = io.res_coff;
+    a.y_ld = io.y_ld; a.y_coff = io.y_coff;
+    a.relu = io.relu;
+    a.Cout = p.lCout; a.CoutP = p.CoutPad;
+    int ext;
+    if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = 0; ext = 1; }
+    else { a.HoA = io.H; a.WoA = io.W; a.pad = (T == 9) ? 1 : 0; ext = (T == 9) ? 2 : 0; }
+    if (p.gemm_1x1_expand) {
+        if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }
+        if (io.y_ld != p.Cout || io.y_coff != 0) { if (err) *err = "1x1-expand output must be contiguous"; return -1; }
+        a.y_ld = p.lCout;
+    }
+    if ((a.x_ld & 7) || (a.x_coff & 7) || (a.y_ld & 7) || (a.y_coff & 7)) { if (err) *err = "conv3: channel strides/offsets must be multiples of 8"; return -1; }
+    if (io.res && ((io.res_ld | io.res_coff) & 7)) { if (err) *err = "conv3: residual stride/offset must be a multiple of 8"; return -1; }
+    if ((double)io.N * io.H * io.W * io.x_ld >= 2147483647.0 || (double)io.N * a.HoA * a.WoA >= 2147483647.0) {
+        if (err) *err = "tensor too large for 32-bit offsets"; return -1;
+    }
+    a.nchunks = (p.Cin / 8) / NC8;
+    a.Mtot = (long long)io.N * a.HoA * a.WoA;
+
+    // tile selection (does not change any output element's summation order)
+    int NBT = (G == 4) ? 1 : ((p.lCout >= 64) ? 2 : 1);
+    int PXW = (G == 1 && T == 9 && NC8 == 2) ? 4 : 2;
+    int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, NPIX64 = 0;
+    long long blocks = 0;
+    auto geom = [&](int pxw) -> bool {
+        const int M = 128 * pxw;
+        const int lm = ceil_log2_(M);
+        l2w = std::min(5, ceil_log2_(io.W));
+        l2h = std::min(lm - l2w, ceil_log2_(io.H));
+        NB = M >> (l2w + l2h);
+        NB = std::max(1, std::min(NB, io.N));
+        PH = (1 << l2h) + ext; PW = (1 << l2w) + ext;
+        // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
+        while (NB > 1 && NC8 * ((NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8) * 256) --NB;
+        npix = NB * PH * PW;
+        NPIX64 = (npix + 63) / 64 * 64;
+        const int tiles_x = (io.W + (1 << l2w) - 1) >> l2w, tiles_y = (io.H + (1 << l2h) - 1) >> l2h;
+        const int tiles_n = (io.N + NB - 1) / NB;
+        blocks = (long long)tiles_x * tiles_y * tiles_n;
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
+        return NC8 * NPIX64 <= k3_maxa(pxw, NC8) * 256 && npix < 65536;
+    };
+    bool fit = geom(PXW);
+    if (PXW == 4) {
+        const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
+        if (!fit || blocks * nt < 448) { PXW = 2; fit = geom(PXW); }
+    }
+    if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
+    if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128) NBT = 1;
+    const int BN = NBT * 32;
+    a.n_ntiles = (p.lCout + BN - 1) / BN;
+    const char* ev_split = getenv("LTK_SPLITK");      // 0: never split (batch-size independent summation order)
+    const char* ev_abl = getenv("LTK_ABLATE");
+    const int allow_split = ev_split ? atoi(ev_split) : 1;
+    const int ablate = ev_abl ? atoi(ev_abl) : 0;
+    a.ablate = ablate;
+    int ksplit = allow_split ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
+    if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
+        while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
+    }
+    a.ksplit = ksplit;
+    a.chunks_per_split = (a.nchunks + ksplit - 1) / ksplit;
+    if ((long long)a.chunks_per_split * (ksplit - 1) >= a.nchunks) {   // no empty split
+        ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+        a.ksplit = ksplit;
+    }
+    a.log2TW = l2w; a.log2TH = l2h; a.NB = NB; a.PH = PH; a.PW = PW; a.npix = npix; a.NPIX64 = NPIX64;
+    a.NPIXP = NPIX64;
+    a.magicPW = magic_u16_(PW); a.magicPHW = magic_u16_(PH * PW);
+
+    if (ksplit > 1) a.partial = io.partial;
+
+    const size_t a_bytes = (size_t)NC8 * a.NPIXP * 16, b_bytes = (size_t)T * NC8 * BN * 16;
+    const size_t epi_bytes = (size_t)4 * 64 * (BN * 2 + 16);
+    size_t lds = std::max(2 * (a_bytes + b_bytes), epi_bytes);
+    lds = (lds + 255) / 256 * 256;
+    if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
+    k3_kernel_t k = k3_pick(G, NBT, PXW, NC8, T);
+    if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
+    const long long nblk = blocks * a.n_ntiles * ksplit;
+    if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
+    static thread_local std::vector<const void*> configured;
+    if (std::find(configured.begin(), configured.end(), (const void*)k) == configured.end()) {
+        HIPCHK3(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured.push_back((const void*)k);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    HIPCHK3(hipGetLastError());
+    if (ksplit > 1) {
+        const long long items = a.Mtot * (p.lCout >> 3);
+        hipLaunchKernelGGL(conv3_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                           (const float*)io.partial, ksplit, a.Mtot, p.CoutPad, p.lCout, (const float*)p.d_scale,
+                           (const float*)p.d_shift, io.res, io.res_ld, io.res_coff, io.y, a.y_ld, a.y_coff, io.relu);
+        HIPCHK3(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace ltk

@@ -65,6 +65,10 @@ struct ConvPlan {
     int mode = 1;                         // 0 double-buffered LDS, 1 single-buffered + register prefetch
     int nphase = 1;
     int Tp = 0;
+    // conv3 (LDS-DMA staged, merged-phase convT, split-K): conv3_mfma.hip
+    bool v3 = false;
+    int v3_G = 1;                         // 1 = conv, 4 = merged transposed conv (4 sub-pixel phases per block)
+    int v3_T = 9;                         // taps: 9 (3x3 / merged convT) or 1 (1x1)
     ConvPhase phase[kMaxPhases];
     // device data
     f16* d_w = nullptr;
@@ -79,9 +83,11 @@ struct ConvPlan {
 // fp16 [ntile][chunk][tap][plane][cout][8]) and upload.  `weight` is
 // [Cout][Cin][kh][kw] (conv) or [Cin][Cout][kh][kw] (transposed).
 // Cin is padded up to a multiple of 8 with zero weights (CinPad = plan.Cin).
+// `hint_hw` = pixels per image of the map the layer runs on (0 = unknown): it only steers the
+// channel-chunk width, which is baked into the weight pack order.
 int conv_plan_create(ConvPlan* p, const float* weight, int Cin, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
-                     const float* scale, const float* shift, std::string* err);
+                     const float* scale, const float* shift, std::string* err, int hint_hw = 0);
 void conv_plan_destroy(ConvPlan* p);
 
 struct ConvIO {
@@ -89,9 +95,16 @@ struct ConvIO {
     f16* y; int y_ld, y_coff;
     const f16* res; int res_ld, res_coff;
     int relu;
+    float* partial = nullptr;      // split-K scratch (fp32 slabs) and its capacity in bytes; conv3 splits the
+    size_t partial_cap = 0;        // channel loop of under-filled launches only when this is large enough
 };
 
 // Enqueue the layer on `stream`.  Returns 0 or a negative error (message in *err).
 int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err);
+
+// conv3_mfma.hip
+int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err);
+// upper bound of the split-K scratch a launch of `N` images of H x W may use
+size_t conv3_partial_bytes(const ConvPlan& p, int N, int H, int W);
 
 }  // namespace ltk

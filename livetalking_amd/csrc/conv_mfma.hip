@@ -434,7 +434,7 @@ double ConvPlan::macs_per_image(int H, int W) const {
 
 int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
-                     const float* scale, const float* shift, std::string* err) {
+                     const float* scale, const float* shift, std::string* err, int hint_hw) {
     *p = ConvPlan();
     const int Cin = (CinReal + 7) / 8 * 8;
     p->kh = kh; p->kw = kw; p->sh = sh; p->sw = sw; p->ph = ph; p->pw = pw;
@@ -447,7 +447,17 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
     struct Tap { int ky, kx, dy, dx; };
     std::vector<std::vector<Tap>> phases;
     std::vector<std::pair<int, int>> phase_off;
-    if (!transposed) {
+    const bool v3_on = env_int("LTK_CONV_V3", 1) != 0;
+    const bool is_convT_s2 = transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && out_pad == 1;
+    if (v3_on && is_convT_s2 && Cin % 16 == 0) {
+        // conv3 merged transposed conv: ONE phase of 9 taps over a 2x2 input neighbourhood, in the tap order the
+        // kernel's static table expects (offset (0,0): phases 0..3, (0,1): 1,3, (1,0): 2,3, (1,1): 3)
+        p->v3 = true; p->v3_G = 4; p->v3_T = 9;
+        lsh = lsw = 1;
+        phases.push_back({{1, 1, 0, 0}, {1, 2, 0, 0}, {2, 1, 0, 0}, {2, 2, 0, 0},
+                          {1, 0, 0, 1}, {2, 0, 0, 1}, {0, 1, 1, 0}, {0, 2, 1, 0}, {0, 0, 1, 1}});
+        phase_off.push_back({0, 0});
+    } else if (!transposed) {
         std::vector<Tap> taps;
         for (int y = 0; y < kh; ++y)
             for (int x = 0; x < kw; ++x) taps.push_back({y, x, y, x});
@@ -477,6 +487,10 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         return -1;
     }
 
+    if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {
+        if (!transposed && kh == 3 && kw == 3 && ph == 1 && pw == 1) { p->v3 = true; p->v3_G = 1; p->v3_T = 9; }
+        if ((!transposed && kh == 1 && kw == 1 && ph == 0 && pw == 0) || p->gemm_1x1_expand) { p->v3 = true; p->v3_G = 1; p->v3_T = 1; }
+    }
     const int Cin8 = Cin / 8;
     int NC8, NBT;
     const int Tmax = (int)std::max_element(phases.begin(), phases.end(),
@@ -499,14 +513,22 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
             if (NC8 > 2) NC8 /= 2; else if (NBT > 1) NBT /= 2; else break;
         }
     }
+    if (p->v3) {
+        if (p->v3_T == 1) NC8 = (Cin % 64 == 0) ? 8 : 2;
+        else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
+        else NC8 = (Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4;
+        NBT = 2;
+    }
     p->NC8 = NC8; p->NBT = NBT;      // NBT here = the widest block the staging registers allow
     p->tt9 = (!transposed && kh == 3 && kw == 3 && NC8 >= 2);
     p->nphase = (int)phases.size();
     p->mode = env_int("LTK_CONV_MODE", 1);
     const int Tp = (NC8 == 1) ? ((Tmax + 1) / 2 * 2) : Tmax;
     p->Tp = Tp;
-    if (Tp * NC8 * NBT * 32 > kMaxBItems * 256) { if (err) *err = "weight slab too large for staging registers"; return -1; }
-    if (!pick_kernel(NC8, NBT, p->tt9, 1, 1)) { if (err) *err = "no kernel instantiation for this configuration"; return -1; }
+    if (!p->v3) {
+        if (Tp * NC8 * NBT * 32 > kMaxBItems * 256) { if (err) *err = "weight slab too large for staging registers"; return -1; }
+        if (!pick_kernel(NC8, NBT, p->tt9, 1, 1)) { if (err) *err = "no kernel instantiation for this configuration"; return -1; }
+    }
 
     const int CoutPad = (lCout + 127) / 128 * 128;   // any block width <= 128 tiles it evenly
     p->CoutPad = CoutPad;
@@ -579,6 +601,7 @@ void conv_plan_destroy(ConvPlan* p) {
 static unsigned magic_u16(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
 
 int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err) {
+    if (p.v3) return conv3_launch(p, io, stream, err);
     KArgs a;
     memset(&a, 0, sizeof(a));
     const int NC8 = p.NC8;

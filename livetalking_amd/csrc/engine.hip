@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -121,6 +122,7 @@ struct Layer {
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
     int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
     bool residual = false;
+    bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
     double macs = 0;  // per frame
 };
 
@@ -141,6 +143,11 @@ struct Scratch {
 struct ltk_engine {
     int device = 0;
     hipStream_t compute = nullptr;
+    hipStream_t aux = nullptr;            // audio encoder runs beside the face encoder (wav2lip_v2.py:132 vs :136-140)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* d_partial = nullptr;           // conv3 split-K scratch of the compute stream
+    float* d_partial_aux = nullptr;       // ... of the aux stream
+    size_t partial_cap = 0, partial_aux_cap = 0;
     std::mutex mu;            // enqueue order on `compute` + arena ownership
     std::mutex pool_mu;       // scratch / stream pools, avatar table
     // wav2lip
@@ -228,7 +235,10 @@ const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& n
     return nullptr;
 }
 
-int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L) {
+// `hint_hw`: pixels per image of the layer's input map.  `flat_ld` > 0: the k x k "valid" conv that collapses a
+// k x k map to 1x1 (face_encoder_blocks.7.0) is run as a 1x1 conv over the map viewed as ONE pixel of
+// k*k*flat_ld channels (pixel stride flat_ld >= cin; the gap channels get zero weights).
+int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0) {
     const std::string p = d.prefix;
     const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
     const float* w = find_tensor(sd, n, p + ".conv_block.0.weight", wcount);
@@ -247,8 +257,20 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
         sf[c] = (b[c] - mean[c]) * s + beta[c];
     }
     std::string err;
-    int rc = conv_plan_create(&L->plan, w, d.cin, d.cout, d.k, d.k, d.sh, d.sw, d.pad, d.pad, d.transposed, d.out_pad,
-                              sc.data(), sf.data(), &err);
+    int rc;
+    if (flat_ld > 0) {
+        const int kk = d.k * d.k;
+        const int cin_flat = (kk - 1) * flat_ld + d.cin;        // from the first real channel to the last
+        std::vector<float> wf((size_t)d.cout * cin_flat, 0.f);
+        for (int co = 0; co < d.cout; ++co)
+            for (int ci = 0; ci < d.cin; ++ci)
+                for (int t = 0; t < kk; ++t)
+                    wf[(size_t)co * cin_flat + (size_t)t * flat_ld + ci] = w[((size_t)co * d.cin + ci) * kk + t];
+        rc = conv_plan_create(&L->plan, wf.data(), cin_flat, d.cout, 1, 1, 1, 1, 0, 0, false, 0, sc.data(), sf.data(), &err, 1);
+    } else {
+        rc = conv_plan_create(&L->plan, w, d.cin, d.cout, d.k, d.k, d.sh, d.sw, d.pad, d.pad, d.transposed, d.out_pad,
+                              sc.data(), sf.data(), &err, hint_hw);
+    }
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
     L->name = p;
     L->cin_real = d.cin;
@@ -277,7 +299,8 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
         int H = 80, W = 16, in_buf = B_MEL, in_ld = 8, pp = 0;
         for (const LayerDef& d : kAudio) {
             Layer L;
-            if ((rc = build_layer(e, d, sd, n, &L))) return rc;
+            if ((rc = build_layer(e, d, sd, n, &L, H * W))) return rc;
+            L.audio = true;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = 0; L.H = H; L.W = W;
             L.plan.out_dims(H, W, &L.Ho, &L.Wo);
             L.out_buf = B_AT0 + pp; L.out_ld = d.cout; L.out_coff = 0;
@@ -296,9 +319,17 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             const BlockLayer& bl = kFaceEnc[li];
             const bool last = (li + 1 == nl) || kFaceEnc[li + 1].block != bl.block;
             Layer L;
-            if ((rc = build_layer(e, bl.d, sd, n, &L))) return rc;
+            // the 4x4 "valid" conv on the 4x4 map: a 1x1 conv over the flattened map (needs in_ld % 64 == 0)
+            const bool flat = !bl.d.transposed && bl.d.pad == 0 && bl.d.k > 1 && bl.d.k == H && bl.d.k == W &&
+                              in_ld % 64 == 0 && bl.d.cin % 64 == 0 && getenv("LTK_NO_FLATTEN") == nullptr;
+            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, flat ? in_ld : 0))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
-            L.plan.out_dims(H, W, &L.Ho, &L.Wo);
+            if (flat) {
+                L.Ho = 1; L.Wo = 1;
+                L.H = 1; L.W = 1; L.in_ld = bl.d.k * bl.d.k * in_ld;   // one "pixel" per image
+            } else {
+                L.plan.out_dims(H, W, &L.Ho, &L.Wo);
+            }
             if (last) {
                 const int k = 7 - bl.block;
                 L.out_buf = B_CAT0 + k; L.out_ld = kDecCh[k] + kFeatCh[bl.block]; L.out_coff = kDecCh[k];
@@ -320,7 +351,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             const BlockLayer& bl = kFaceDec[li];
             const bool last = (li + 1 == nl) || kFaceDec[li + 1].block != bl.block;
             Layer L;
-            if ((rc = build_layer(e, bl.d, sd, n, &L))) return rc;
+            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
             L.plan.out_dims(H, W, &L.Ho, &L.Wo);
             if (last) {
@@ -340,7 +371,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
     // ---- output block conv (wav2lip_v2.py:89,154)
     {
         Layer L;
-        if ((rc = build_layer(e, kOutConv, sd, n, &L))) return rc;
+        if ((rc = build_layer(e, kOutConv, sd, n, &L, 65536))) return rc;
         L.in_buf = B_CAT0 + 7; L.in_ld = 80; L.in_coff = 0; L.H = 256; L.W = 256; L.Ho = 256; L.Wo = 256;
         L.out_buf = B_OUT32; L.out_ld = 32; L.out_coff = 0;
         L.macs = 80.0 * 32 * 9 * 65536;
@@ -362,16 +393,32 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
 
 f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame0 * e->buf_halfs[id]; }
 
-// Enqueue the 54 conv/convT layers for frames [0, nf) of the arena on `s`.
+// Enqueue the 54 conv/convT layers for frames [0, nf) of the arena on `s`.  The audio encoder has no
+// dependency on the face encoder until decoder block 0 (wav2lip_v2.py:132-142): its 13 small launches run on
+// the aux stream beside the face encoder instead of in front of it.
 int run_convs(ltk_engine* e, int nf, hipStream_t s) {
     std::string err;
+    const bool fork = !e->capture && e->aux && getenv("LTK_NO_AUX_STREAM") == nullptr;
+    bool joined = !fork;
+    if (fork) {
+        CHK(hipEventRecord(e->ev_fork, s));
+        CHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+    }
     for (Layer& L : e->layers) {
+        const bool on_aux = fork && L.audio;
+        if (!on_aux && !joined && !L.audio && L.in_buf >= B_AT0 && L.in_buf <= B_AT1 && L.name.rfind("face_decoder", 0) == 0) {
+            CHK(hipEventRecord(e->ev_join, e->aux));
+            CHK(hipStreamWaitEvent(s, e->ev_join, 0));
+            joined = true;
+        }
         ConvIO io;
         io.x = e->buf[L.in_buf]; io.N = nf; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
         io.y = e->buf[L.out_buf]; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
         io.res = L.residual ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
         io.relu = 1;
-        int rc = conv_launch(L.plan, io, s, &err);
+        io.partial = on_aux ? e->d_partial_aux : e->d_partial;
+        io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;
+        int rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
         if (e->capture) {
             const int C = L.plan.Cout;
@@ -385,6 +432,10 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s) {
             CHK(hipFree(d_tmp));
             e->tap_shape[L.name] = {nf, C, L.Ho, L.Wo};
         }
+    }
+    if (!joined) {
+        CHK(hipEventRecord(e->ev_join, e->aux));
+        CHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
     return 0;
 }
@@ -446,6 +497,13 @@ int ltk_engine_create(int device, ltk_engine** out) {
     std::unique_ptr<ltk_engine> e(new ltk_engine());
     e->device = device;
     CHK(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
+    CHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+    CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    e->partial_cap = (size_t)128 << 20;
+    e->partial_aux_cap = (size_t)16 << 20;
+    CHK(hipMalloc((void**)&e->d_partial, e->partial_cap));
+    CHK(hipMalloc((void**)&e->d_partial_aux, e->partial_aux_cap));
     std::vector<float> basis;
     std::vector<int32_t> lohi;
     build_mel_basis(&basis, &lohi);
@@ -469,6 +527,11 @@ void ltk_engine_destroy(ltk_engine* e) {
     for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
     for (Scratch& s : e->scratch_free) (void)hipFree(s.d);
     for (hipStream_t s : e->stream_free) (void)hipStreamDestroy(s);
+    if (e->d_partial) (void)hipFree(e->d_partial);
+    if (e->d_partial_aux) (void)hipFree(e->d_partial_aux);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->compute) (void)hipStreamDestroy(e->compute);
     delete e;
 }
@@ -712,17 +775,22 @@ int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats)
 int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass) {
     if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
-    if (frames > e->micro_batch) return fail(LTK_E_INVALID, "frames exceeds the arena (micro-batch) size");
+    if (frames > e->max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
     CHK(hipSetDevice(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
     CHK(hipEventCreate(&t1));
-    int rc = run_convs(e, frames, e->compute);  // warm
+    auto pass = [&]() -> int {   // the same micro-batch schedule ltk_wav2lip_infer uses
+        int rc = 0;
+        for (int f0 = 0; f0 < frames && !rc; f0 += e->micro_batch) rc = run_convs(e, std::min(e->micro_batch, frames - f0), e->compute);
+        return rc;
+    };
+    int rc = pass();  // warm
     if (rc) return rc;
     CHK(hipEventRecord(t0, e->compute));
-    for (int i = 0; i < iters && !rc; ++i) rc = run_convs(e, frames, e->compute);
+    for (int i = 0; i < iters && !rc; ++i) rc = pass();
     if (rc) return rc;
     CHK(hipEventRecord(t1, e->compute));
     CHK(hipEventSynchronize(t1));
@@ -742,9 +810,10 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
     CHK(hipSetDevice(e->device));
     ConvPlan plan;
     std::string err;
-    int rc = conv_plan_create(&plan, weight, Cin, Cout, kh, kw, sh, sw, ph, pw, transposed != 0, out_pad, scale, shift, &err);
+    int rc = conv_plan_create(&plan, weight, Cin, Cout, kh, kw, sh, sw, ph, pw, transposed != 0, out_pad, scale, shift, &err, H * W);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
     ConvIO io;
+    io.partial = e->d_partial; io.partial_cap = e->partial_cap;
     io.x = (const f16*)d_x; io.N = N; io.H = H; io.W = W; io.x_ld = plan.Cin; io.x_coff = 0;
     io.y = (f16*)d_y; io.y_ld = Cout; io.y_coff = 0;
     io.res = (const f16*)d_res; io.res_ld = Cout; io.res_coff = 0;

@@ -28,6 +28,12 @@ LAYERS = [
     ("c7x7 6>16@256", 256, 256, 6, 16, 7, 1, 3, False, 0, False),
     ("s2 16>32@256", 256, 256, 16, 32, 3, 2, 1, False, 0, False),
     ("c32@128", 128, 128, 32, 32, 3, 1, 1, False, 0, True),
+    ("c256@16", 16, 16, 256, 256, 3, 1, 1, False, 0, True),
+    ("c512@4", 4, 4, 512, 512, 3, 1, 1, False, 0, True),
+    ("T1024>512@8", 8, 8, 1024, 512, 3, 2, 1, True, 1, False),
+    ("T1024>512@4", 4, 4, 1024, 512, 3, 2, 1, True, 1, False),
+    ("1x1 512@1", 1, 1, 512, 512, 1, 1, 0, False, 0, False),
+    ("T4x4 1024>512@1", 1, 1, 1024, 512, 4, 1, 0, True, 0, False),
 ]
 
 
@@ -42,12 +48,13 @@ def macs(l):
 
 def main():
     eng = Engine(0)
-    variants = []
-    for mode, nbt, nc8 in itertools.product((1, 0), (0, 2, 1), (0, 2)):
-        variants.append((mode, nbt, nc8))
+    # (LTK_CONV_V3, LTK_CONV_MODE, LTK_CONV_NBT, LTK_CONV_NC8)
+    variants = [(0, 1, 0, 0), (1, 1, 0, 0)]
+    if os.environ.get("SWEEP_FULL"):
+        variants = [(0, m, n, c) for m, n, c in itertools.product((1, 0), (0, 2, 1), (0, 2))] + [(1, 1, 0, 0)]
     only = os.environ.get("SWEEP_ONLY")
-    print(f"frames={N}")
-    hdr = "layer".ljust(16) + "".join(f" m{m}n{n}c{c}".rjust(10) for m, n, c in variants)
+    print(f"frames={N}   cell = us / TFLOP/s")
+    hdr = "layer".ljust(16) + "".join((("v3" if v else f"old m{m}n{n}c{c}")).rjust(14) for v, m, n, c in variants)
     print(hdr)
     for l in LAYERS:
         name, H, W, Cin, Cout, k, s, p, tr, op, res = l
@@ -57,15 +64,18 @@ def main():
         x = (torch.randn(N, H, W, cin_pad, device="cuda") * 0.5).half()
         wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
         w = (np.random.default_rng(0).standard_normal(wshape) * 0.05).astype(np.float32)
-        if tr:
+        if tr and s == 2:
             Ho, Wo = H * 2, W * 2
+        elif tr:
+            Ho, Wo = k, k
         else:
             Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float16, device="cuda")
         sc = np.ones(Cout, np.float32)
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
-        for mode, nbt, nc8 in variants:
+        for v3, mode, nbt, nc8 in variants:
+            os.environ["LTK_CONV_V3"] = str(v3)
             os.environ["LTK_CONV_MODE"] = str(mode)
             os.environ["LTK_CONV_NBT"] = str(nbt)
             os.environ["LTK_CONV_NC8"] = str(nc8)
@@ -73,9 +83,10 @@ def main():
                 ms = eng.conv2d_f16(x.data_ptr(), N, H, W, Cin, w, Cout, k, s, p, tr, op, sc, sf,
                                     x.data_ptr() if res else 0, True, y.data_ptr(), iters=10)
                 tf = 2 * macs(l) * N / ms / 1e9
-                row += f" {ms*1e3:6.0f}/{tf:3.0f}".rjust(10)
+                row += f" {ms*1e3:6.0f}/{tf:3.0f}".rjust(14)
             except Exception as ex:
-                row += " err".rjust(10)
+                row += " err".rjust(14)
+                print("   !", name, ex)
         print(row, flush=True)
     eng.close()
 

@@ -1,0 +1,13 @@
+#!/bin/bash
+# conv3 bring-up: parity, A/B sweep against conv_mfma, bench, per-layer trace
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests -m gpu -q -s > $O/pytest2.log 2>&1; echo "pytest exit $?" >> $O/pytest2.log
+grep -E "FAIL|EXC|passed|failed|error" $O/pytest2.log | head -40
+SWEEP_FRAMES=16 timeout 300 python scripts/conv_sweep.py > $O/sweep2_16.log 2>&1
+cat $O/sweep2_16.log
+timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench2_s1.json 2> $O/bench2_s1.err; cat $O/bench2_s1.json
+timeout 300 python bench.py --steps 10 --warmup 3 --sessions 16 --no-cpu-baseline > $O/bench2_s16.json 2> $O/bench2_s16.err; cat $O/bench2_s16.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof2_trace -o r -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/prof2_trace.log 2>&1

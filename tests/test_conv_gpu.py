@@ -57,7 +57,9 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else v
 
 
-def run_case(eng, case, seed):
+def run_case(eng, case, seed, v3=1):
+    import os
+    os.environ["LTK_CONV_V3"] = str(v3)   # read when the layer plan is created
     N, H, W, Cin, Cout, k, stride, pad, transposed, out_pad, residual = case
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g).half().float()
@@ -92,17 +94,55 @@ def run_case(eng, case, seed):
     return bad, float(torch.nan_to_num(err, nan=1e9).max()), float(ref.abs().max())
 
 
-@pytest.mark.gpu
-def test_conv_every_wav2lip_geometry(engine):
+# conv3 extras: batch sizes that exercise the 512-pixel tiles, the split-K path (small maps, deep K) with and
+# without residual, partial cout tiles and ragged maps
+CASES_V3 = [
+    (16, 64, 64, 64, 64, 3, 1, 1, False, 0, True),
+    (16, 32, 32, 128, 128, 3, 1, 1, False, 0, True),
+    (16, 8, 8, 512, 512, 3, 1, 1, False, 0, True),
+    (16, 4, 4, 512, 512, 3, 1, 1, False, 0, True),
+    (16, 16, 16, 256, 256, 3, 1, 1, False, 0, True),
+    (16, 1, 1, 512, 512, 1, 1, 0, False, 0, False),
+    (16, 1, 1, 1024, 512, 4, 1, 0, True, 0, False),
+    (16, 4, 4, 1024, 512, 3, 2, 1, True, 1, False),
+    (16, 8, 8, 1024, 512, 3, 2, 1, True, 1, False),
+    (7, 64, 64, 320, 128, 3, 2, 1, True, 1, False),
+    (5, 128, 128, 160, 64, 3, 2, 1, True, 1, False),
+    (4, 256, 256, 80, 32, 3, 1, 1, False, 0, False),
+    (3, 37, 21, 64, 96, 3, 1, 1, False, 0, False),
+    (3, 19, 45, 96, 40, 3, 2, 1, True, 1, False),
+    (2, 33, 17, 128, 72, 1, 1, 0, False, 0, False),
+]
+
+
+def _run_all(engine, cases, v3):
     report = []
-    for i, case in enumerate(CASES):
+    for i, case in enumerate(cases):
         try:
-            bad, maxerr, refmax = run_case(engine, case, 100 + i)
+            bad, maxerr, refmax = run_case(engine, case, 100 + i, v3)
         except Exception as ex:  # report all cases, not just the first
             report.append(f"case {i} {case}: EXC {ex}")
             continue
         status = "ok" if bad == 0 else "FAIL"
-        print(f"[conv] {status} case {i} {case}: bad={bad} maxerr={maxerr:.4g} refmax={refmax:.3g}")
+        print(f"[conv v3={v3}] {status} case {i} {case}: bad={bad} maxerr={maxerr:.4g} refmax={refmax:.3g}")
         if bad:
             report.append(f"case {i} {case}: {bad} elements out of tolerance, max err {maxerr:.4g} (ref max {refmax:.3g})")
+    return report
+
+
+@pytest.mark.gpu
+def test_conv_every_wav2lip_geometry(engine):
+    """Default kernel selection (conv3 where eligible, conv_mfma for the 7x7 / strided layers)."""
+    report = _run_all(engine, CASES + CASES_V3, 1)
+    assert not report, "\n".join(report)
+
+
+@pytest.mark.gpu
+def test_conv_first_generation_kernel(engine):
+    """conv_mfma.hip alone (LTK_CONV_V3=0) stays correct: it is the fallback for every geometry."""
+    try:
+        report = _run_all(engine, CASES, 0)
+    finally:
+        import os
+        os.environ["LTK_CONV_V3"] = "1"
     assert not report, "\n".join(report)
