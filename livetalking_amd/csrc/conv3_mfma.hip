@@ -17,6 +17,14 @@
 //     fp32 partial slabs + conv3_finish (fixed summation order -> deterministic).
 // MFMA operand roles, folded-BN epilogue, channel-offset I/O and the weight pack order
 // ([cout/32][chunk][tap][plane][32][8 halfs]) are those of conv_mfma.hip.
+//
+// Activation layout (all kernels): channel-blocked [N][C/16][H][W][16] fp16 ("CB16").  One MFMA k16 step
+// consumes exactly one channel block; a patch row, an output row and a residual row are contiguous runs of
+// 32 B per pixel, so the LDS-DMA, the residual read and the store all move whole 128-B lines (measured with
+// scripts/ubench/glds_bw.hip: 126 GB/s/CU for whole lines against 17 GB/s/CU when a lane takes 16 B of a
+// line, which is what pixel-interleaved NHWC costs a 16-channel chunk).
+// A-patch image in LDS, per channel block: [patch pixel][2 x 16 B], the two halves swapped where bit 3 of the
+// pixel slot is set, so the 16-lane groups of ds_read_b128 (32-B lane stride) hit 16 distinct 16-B slots.
 #include "conv_mfma.h"
 
 #include <hip/hip_fp16.h>
@@ -36,12 +44,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct K3Args {
     const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
     float* partial;                  // split-K slabs [ksplit][Mtot][CoutP] or nullptr
-    int N, H, W, x_ld, x_coff;
-    int y_ld, y_coff, HoA, WoA;      // output pixel (n,oy,ox) -> ((n*HoA+oy)*WoA+ox)
-    int res_ld, res_coff;
+    int N, H, W, x_cbt, x_cb0;       // input: channel blocks in the buffer, first block of this tensor
+    int y_cbt, y_cb0, HoA, WoA;      // output pixel (n,oy,ox) of block cb -> ((n*y_cbt + y_cb0+cb)*HoA + oy)*WoA + ox
+    int res_cbt, res_cb0;
     int Cout, CoutP;                 // logical output channels; CoutP = padded (scale/shift/partial pitch)
     int pad;                         // 1 for 3x3, 0 for 1x1 / transposed
-    int PH, PW, NPIXP, NPIX64, npix;
+    int PH, PW, SLOTS, npix;         // SLOTS: 16-byte slots per channel-block image (2 per patch pixel, 64-padded)
     int log2TW, log2TH, NB;
     int tiles_x, tiles_y, tiles_n, n_ntiles;
     unsigned magicPW, magicPHW;
@@ -98,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
 
-    const int A_BYTES = NC8 * a.NPIXP * 16;
+    constexpr int NCB = NC8 / 2;           // channel blocks (k16 steps) per chunk
+    const int A_BYTES = NCB * a.SLOTS * 16;
     constexpr int B_BYTES = T * NC8 * BN * 16;
     const int STAGE = A_BYTES + B_BYTES;
 
@@ -116,24 +125,27 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         }
     }
 
-    // ---- A staging descriptors: item (k, wave) = 64 consecutive pixel slots of one channel plane
-    const int p64n = a.NPIX64 >> 6;          // 64-slot groups per plane
-    int a_goff[MAXA];                         // element offset of this lane's pixel (chunk 0), -1 = no copy
+    // ---- A staging descriptors: item (k, wave) = 64 consecutive 16-byte slots (32 patch pixels) of one channel block
+    const int p64n = a.SLOTS >> 6;
+    const int HW16 = a.H * a.W * 16;          // halfs per channel block plane
+    int a_goff[MAXA];                         // element offset of this lane's 8 channels (chunk 0), -1 = no copy
     int a_ldst[MAXA];                         // wave-uniform LDS byte offset inside a stage
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
         const int s64 = k * 4 + wave;                       // wave-uniform
-        const int plane = s64 / p64n;
-        const int pix = (s64 - plane * p64n) * 64 + lane;
+        const int cbj = s64 / p64n;
+        const int slot = (s64 - cbj * p64n) * 64 + lane;
+        const int pix = slot >> 1;
+        const int half = (slot & 1) ^ ((pix >> 3) & 1);
         const int b = (PHW == 1) ? pix : (int)__umulhi((unsigned)pix, a.magicPHW);
         const int rem = pix - b * PHW;
         const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
         const int px = rem - py * a.PW;
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
-        const bool ok = (plane < NC8) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
+        const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
-        a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + plane * 8) : -1;
-        a_ldst[k] = __builtin_amdgcn_readfirstlane((plane * a.NPIXP + (s64 - plane * p64n) * 64) * 16);
+        a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + cbj) * a.H + iy) * a.W + ix) * 16 + half * 8) : -1;
+        a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
     }
 
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     auto stage = [&](int c, int buf) {
         unsigned char* const Ab = smem + buf * STAGE;
         unsigned char* const Bb = Ab + A_BYTES;
-        const f16* xc = a.x + c * (NC8 * 8);
+        const f16* xc = a.x + (size_t)c * NCB * HW16;
         if (!(a.ablate & 1)) {
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         const int tx = m & TWm;
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
-        pixb[j] = (b < a.NB) ? ((b * a.PH + ty) * a.PW + tx) * 16 : 0;
+        pixb[j] = (b < a.NB) ? ((b * a.PH + ty) * a.PW + tx) : 0;     // patch pixel slot
     }
 
     f32x16 acc[G][NBT][PXW];
@@ -185,21 +197,23 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][i][j][r] = 0.f;
 
-    const int PS = a.NPIXP * 16;
+    const int PS = a.SLOTS * 16;
+    // byte address of lane's operand (pixel slot p, k-half hh) inside a channel-block image
+    auto aoff = [&](int p) -> int { return p * 32 + ((((p >> 3) & 1) ^ hh) << 4); };
     auto compute = [&](int buf) {
         const unsigned char* Ab = smem + buf * STAGE;
         const unsigned char* Bb = Ab + A_BYTES;
 #pragma unroll
-        for (int q = 0; q < NC8 / 2; ++q) {
+        for (int q = 0; q < NCB; ++q) {
             const int plane = 2 * q + hh;
-            const unsigned char* Ap = Ab + plane * PS;
+            const unsigned char* Ap = Ab + q * PS;
             if constexpr (G == 1) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    const int toff = (T == 9) ? ((t / 3) * a.PW + (t % 3)) * 16 : 0;
+                    const int toff = (T == 9) ? ((t / 3) * a.PW + (t % 3)) : 0;
                     f16x8 xa[PXW], wf[NBT];
 #pragma unroll
-                    for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + toff);
+                    for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + toff));
 #pragma unroll
                     for (int i = 0; i < NBT; ++i)
                         wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                 f16x8 xa[PXW];
                 // offset (0,0): taps 0..3 -> phases 0..3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j]);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j]));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const f16x8 wf = wfrag(t);
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                 }
                 // offset (0,1): taps 4,5 -> phases 1,3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + 16);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + 1));
                 {
                     const f16x8 w4 = wfrag(4), w5 = wfrag(5);
 #pragma unroll
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                 }
                 // offset (1,0): taps 6,7 -> phases 2,3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + a.PW * 16);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + a.PW));
                 {
                     const f16x8 w6 = wfrag(6), w7 = wfrag(7);
 #pragma unroll
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                 }
                 // offset (1,1): tap 8 -> phase 3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + pixb[j] + (a.PW + 1) * 16);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + a.PW + 1));
                 {
                     const f16x8 w8 = wfrag(8);
 #pragma unroll
@@ -271,16 +285,19 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 
     // ---- epilogue
     const int cout0 = ntile * BN;
-    auto out_row = [&](int j, int g, bool* ok) -> int {
+    const int HWo = a.HoA * a.WoA;
+    // output pixel of this lane in subtile j / phase g: image n and pixel index inside the output plane
+    auto out_px = [&](int j, int g, int* n_out, bool* ok) -> int {
         const int m = (wave * PXW + j) * 32 + l31;
         const int tx = m & TWm;
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
         const int n = n0 + b, y = ty0 + ty, x = tx0 + tx;
         *ok = (b < a.NB) && (n < a.N) && (y < a.H) && (x < a.W);
+        *n_out = n;
         const int oy = (G == 4) ? 2 * y + (g >> 1) : y;
         const int ox = (G == 4) ? 2 * x + (g & 1) : x;
-        return (n * a.HoA + oy) * a.WoA + ox;
+        return oy * a.WoA + ox;
     };
 
     if (a.partial) {
@@ -290,9 +307,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 #pragma unroll
             for (int j = 0; j < PXW; ++j) {
                 bool ok;
-                const int orw = out_row(j, g, &ok);
+                int n;
+                const int opx = out_px(j, g, &n, &ok);
                 if (!ok) continue;
-                float* dst = a.partial + ((size_t)ks * a.Mtot + orw) * a.CoutP + cout0;
+                float* dst = a.partial + ((size_t)ks * a.Mtot + (size_t)n * HWo + opx) * a.CoutP + cout0;
 #pragma unroll
                 for (int i = 0; i < NBT; ++i)
 #pragma unroll
@@ -308,35 +326,39 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     }
 
     // y = relu(acc*scale + shift + res) -> fp16 through a wave-private LDS transpose (64 pixel rows x BN
-    // channels per pass) so residual reads and output writes are whole 16-byte channel segments.
+    // channels per pass): residual reads and output writes then are 32 pixels x 32 B = one contiguous KiB per
+    // wave instruction in the channel-blocked layout.
     constexpr int ROWB = BN * 2 + 16;
-    constexpr int SEGS = BN / 8;
-    constexpr int LOG2SEGS = NBT == 1 ? 2 : 3;
+    constexpr int CBN = BN / 16;            // channel blocks per block
     unsigned char* const wreg = smem + wave * (64 * ROWB);
-    const int nseg_valid = min(SEGS, (a.Cout - cout0) >> 3);
+    const int ncb_valid = min(CBN, (a.Cout - cout0) >> 4);
     const bool has_res = a.res != nullptr && !(a.ablate & 8);
     const bool do_store = !(a.ablate & 16);
+    const int cbo = cout0 >> 4;
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int jp = 0; jp < PXW / 2; ++jp) {
-            int orow[2];
-            bool rowok[2];
+            int obase[2], rbase[2];      // element offset of (pixel, channel block cbo) in y / res, -1 = outside
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) orow[jj] = out_row(2 * jp + jj, g, &rowok[jj]);
+            for (int jj = 0; jj < 2; ++jj) {
+                bool ok;
+                int n;
+                const int opx = out_px(2 * jp + jj, g, &n, &ok);
+                obase[jj] = ok ? (((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16) : -1;
+                rbase[jj] = ok ? (((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16) : -1;
+            }
             if (has_res) {
 #pragma unroll
-                for (int it = 0; it < SEGS; ++it) {
+                for (int it = 0; it < 2 * CBN; ++it) {
                     const int idx = it * 64 + lane;
-                    const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
-                    const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
-                    const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
-                    const int orw = (row & 32) ? o1 : o0;
-                    const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+                    const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
+                    const int r0 = __shfl(rbase[0], px & 31), r1 = __shfl(rbase[1], px & 31);
+                    const int rb = (px & 32) ? r1 : r0;
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok) v = *reinterpret_cast<const uint4*>(a.res + (size_t)orw * a.res_ld + a.res_coff + cout0 + seg * 8);
-                    *reinterpret_cast<uint4*>(wreg + row * ROWB + seg * 16) = v;
+                    if (rb >= 0 && cbl < ncb_valid) v = *reinterpret_cast<const uint4*>(a.res + rb + cbl * (HWo * 16) + half * 8);
+                    *reinterpret_cast<uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2) = v;
                 }
             }
 #pragma unroll
@@ -370,52 +392,55 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                 }
             }
 #pragma unroll
-            for (int it = 0; it < SEGS; ++it) {
+            for (int it = 0; it < 2 * CBN; ++it) {
                 const int idx = it * 64 + lane;
-                const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
-                const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
-                const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
-                const int orw = (row & 32) ? o1 : o0;
-                const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
-                const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + seg * 16);
-                if (ok && do_store) *reinterpret_cast<uint4*>(a.y + (size_t)orw * a.y_ld + a.y_coff + cout0 + seg * 8) = v;
+                const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
+                const int o0 = __shfl(obase[0], px & 31), o1 = __shfl(obase[1], px & 31);
+                const int ob = (px & 32) ? o1 : o0;
+                const uint4 v = *reinterpret_cast<const uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2);
+                if (ob >= 0 && cbl < ncb_valid && do_store) *reinterpret_cast<uint4*>(a.y + ob + cbl * (HWo * 16) + half * 8) = v;
             }
         }
     }
 }
 
-// split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts.
-__global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restrict__ partial, int ksplit, long long Mtot,
+// split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts;
+// consecutive threads = the two halves of a channel block, then consecutive pixels.
+__global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restrict__ partial, int ksplit, long long Mtot, int HWo,
                                                             int CoutP, int Cout, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const f16* __restrict__ res,
-                                                            int res_ld, int res_coff, f16* __restrict__ y, int y_ld, int y_coff,
+                                                            int res_cbt, int res_cb0, f16* __restrict__ y, int y_cbt, int y_cb0,
                                                             int relu) {
-    const int segs = Cout >> 3;
+    const int ncb = Cout >> 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Mtot * segs) return;
-    const long long row = i / segs;
-    const int seg = (int)(i - row * segs);
+    if (i >= Mtot * ncb * 2) return;
+    const int half = (int)(i & 1);
+    const long long r2 = i >> 1;
+    const long long row = r2 % Mtot;
+    const int cb = (int)(r2 / Mtot);
+    const int n = (int)(row / HWo), opx = (int)(row - (long long)n * HWo);
+    const int c0 = cb * 16 + half * 8;
     float v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = 0.f;
     for (int s = 0; s < ksplit; ++s) {
-        const float* p = partial + ((size_t)s * Mtot + row) * CoutP + seg * 8;
+        const float* p = partial + ((size_t)s * Mtot + row) * CoutP + c0;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; }
     }
     f16x8 rr;
-    if (res) rr = *reinterpret_cast<const f16x8*>(res + (size_t)row * res_ld + res_coff + seg * 8);
+    if (res) rr = *reinterpret_cast<const f16x8*>(res + (((size_t)n * res_cbt + res_cb0 + cb) * HWo + opx) * 16 + half * 8);
     f16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        float t = v[r] * scale[seg * 8 + r] + shift[seg * 8 + r];
+        float t = v[r] * scale[c0 + r] + shift[c0 + r];
         if (res) t += (float)rr[r];
         if (relu) t = fmaxf(t, 0.f);
         t = fminf(fmaxf(t, -65504.f), 65504.f);
         o[r] = (f16)t;
     }
-    *reinterpret_cast<f16x8*>(y + (size_t)row * y_ld + y_coff + seg * 8) = o;
+    *reinterpret_cast<f16x8*>(y + (((size_t)n * y_cbt + y_cb0 + cb) * HWo + opx) * 16 + half * 8) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -471,9 +496,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     memset(&a, 0, sizeof(a));
     const int G = p.v3_G, T = p.v3_T, NC8 = p.NC8;
     a.x = io.x; a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift; a.res = io.res; a.y = io.y;
-    a.N = io.N; a.H = io.H; a.W = io.W; a.x_ld = io.x_ld; a.x_coff = io.x_coff;
-    a.res_ld = io.res_ld; a.res_coff = io.res_coff;
-    a.y_ld = io.y_ld; a.y_coff = io.y_coff;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
+    a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
+    int y_ld = io.y_ld;
     a.relu = io.relu;
     a.Cout = p.lCout; a.CoutP = p.CoutPad;
     int ext;
@@ -482,10 +507,11 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     if (p.gemm_1x1_expand) {
         if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }
         if (io.y_ld != p.Cout || io.y_coff != 0) { if (err) *err = "1x1-expand output must be contiguous"; return -1; }
-        a.y_ld = p.lCout;
+        y_ld = p.lCout;     // [N][k*k*Cout/16][1][1][16] == [N][k][k][Cout] == a 1-pixel NHWC map: the caller re-views it
     }
-    if ((a.x_ld & 7) || (a.x_coff & 7) || (a.y_ld & 7) || (a.y_coff & 7)) { if (err) *err = "conv3: channel strides/offsets must be multiples of 8"; return -1; }
-    if (io.res && ((io.res_ld | io.res_coff) & 7)) { if (err) *err = "conv3: residual stride/offset must be a multiple of 8"; return -1; }
+    a.y_cbt = y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
+    if ((io.x_ld | io.x_coff | y_ld | io.y_coff | p.lCout) & 15) { if (err) *err = "conv3: channel counts/offsets must be multiples of 16"; return -1; }
+    if (io.res && ((io.res_ld | io.res_coff) & 15)) { if (err) *err = "conv3: residual channel count/offset must be a multiple of 16"; return -1; }
     if ((double)io.N * io.H * io.W * io.x_ld >= 2147483647.0 || (double)io.N * a.HoA * a.WoA >= 2147483647.0) {
         if (err) *err = "tensor too large for 32-bit offsets"; return -1;
     }
@@ -495,7 +521,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     // tile selection (does not change any output element's summation order)
     int NBT = (G == 4) ? 1 : ((p.lCout >= 64) ? 2 : 1);
     int PXW = (G == 1 && T == 9 && NC8 == 2) ? 4 : 2;
-    int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, NPIX64 = 0;
+    int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0;
     long long blocks = 0;
     auto geom = [&](int pxw) -> bool {
         const int M = 128 * pxw;
@@ -506,14 +532,14 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         NB = std::max(1, std::min(NB, io.N));
         PH = (1 << l2h) + ext; PW = (1 << l2w) + ext;
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
-        while (NB > 1 && NC8 * ((NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8) * 256) --NB;
+        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8) * 256) --NB;
         npix = NB * PH * PW;
-        NPIX64 = (npix + 63) / 64 * 64;
+        SLOTS = (2 * npix + 63) / 64 * 64;
         const int tiles_x = (io.W + (1 << l2w) - 1) >> l2w, tiles_y = (io.H + (1 << l2h) - 1) >> l2h;
         const int tiles_n = (io.N + NB - 1) / NB;
         blocks = (long long)tiles_x * tiles_y * tiles_n;
         a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
-        return NC8 * NPIX64 <= k3_maxa(pxw, NC8) * 256 && npix < 65536;
+        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8) * 256 && npix < 32768;
     };
     bool fit = geom(PXW);
     if (PXW == 4) {
@@ -539,13 +565,12 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         ksplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
         a.ksplit = ksplit;
     }
-    a.log2TW = l2w; a.log2TH = l2h; a.NB = NB; a.PH = PH; a.PW = PW; a.npix = npix; a.NPIX64 = NPIX64;
-    a.NPIXP = NPIX64;
+    a.log2TW = l2w; a.log2TH = l2h; a.NB = NB; a.PH = PH; a.PW = PW; a.npix = npix; a.SLOTS = SLOTS;
     a.magicPW = magic_u16_(PW); a.magicPHW = magic_u16_(PH * PW);
 
     if (ksplit > 1) a.partial = io.partial;
 
-    const size_t a_bytes = (size_t)NC8 * a.NPIXP * 16, b_bytes = (size_t)T * NC8 * BN * 16;
+    const size_t a_bytes = (size_t)(NC8 / 2) * a.SLOTS * 16, b_bytes = (size_t)T * NC8 * BN * 16;
     const size_t epi_bytes = (size_t)4 * 64 * (BN * 2 + 16);
     size_t lds = std::max(2 * (a_bytes + b_bytes), epi_bytes);
     lds = (lds + 255) / 256 * 256;
@@ -564,8 +589,8 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     if (ksplit > 1) {
         const long long items = a.Mtot * (p.lCout >> 3);
         hipLaunchKernelGGL(conv3_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
-                           (const float*)io.partial, ksplit, a.Mtot, p.CoutPad, p.lCout, (const float*)p.d_scale,
-                           (const float*)p.d_shift, io.res, io.res_ld, io.res_coff, io.y, a.y_ld, a.y_coff, io.relu);
+                           (const float*)io.partial, ksplit, a.Mtot, a.HoA * a.WoA, p.CoutPad, p.lCout, (const float*)p.d_scale,
+                           (const float*)p.d_shift, io.res, a.res_cbt, a.res_cb0, io.y, a.y_cbt, a.y_cb0, io.relu);
         HIPCHK3(hipGetLastError());
     }
     return 0;

@@ -48,9 +48,9 @@ struct PhaseMeta {
 struct KArgs {
     const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
     const PhaseMeta* phases;
-    int N, H, W, x_ld, x_coff;
-    int Ho, Wo, y_ld, y_coff, HoA, WoA, osy, osx;
-    int res_ld, res_coff;
+    int N, H, W, x_cbt, x_cb0;        // channel-blocked [N][C/16][H][W][16]: blocks in the buffer, first block
+    int Ho, Wo, y_cbt, y_cb0, HoA, WoA, osy, osx;
+    int res_cbt, res_cb0;
     int Cin8, Cout;
     int sh, sw, pad_y, pad_x;
     int PH, PW, NPIXP;
@@ -65,7 +65,7 @@ struct KArgs {
 __host__ __device__ constexpr int max_a_items(int NC8, int NBT) {
     return NC8 == 4 ? 6 : (NC8 == 1 ? 5 : (NBT == 4 ? 3 : 10));
 }
-constexpr int kMaxBItems = 9;
+constexpr int kMaxBItems = 9;   // 16-byte weight items a thread stages per chunk
 constexpr int kTapTableBytes = 128;
 constexpr int kLdsLimit = 160 * 1024;
 
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         const int px = rem - py * a.PW;
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
         const bool ok = (i < nitemsA) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
-        a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + c8 * 8) : -1;
+        if constexpr (NC8 == 1)   // the two network inputs (packed face crops, mel windows) are plain [N][H][W][8]
+            a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * 8) : -1;
+        else
+            a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + (c8 >> 1)) * a.H + iy) * a.W + ix) * 16 + (c8 & 1) * 8) : -1;
     }
 
     // weights are packed per 32-cout sub-slab: [cout/32][chunk][tap][plane][32][8 halfs]; a block
@@ -151,14 +154,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
     uint4 ra[MAXA];
     uint4 rb[MAXB];
 
+    const int HW16 = a.H * a.W * 16;
     auto load_chunk = [&](int c) {
         const int cbase = c * NC8;
+        const size_t coff = (size_t)c * (NC8 / 2) * HW16;     // chunk = NC8/2 channel blocks
 #pragma unroll
         for (int k = 0; k < MAXA; ++k) {
             const int c8 = (tid + k * 256) & (NC8 - 1);
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (a_goff[k] >= 0 && cbase + c8 < a.Cin8)
-                v = *reinterpret_cast<const uint4*>(a.x + a_goff[k] + cbase * 8);
+                v = *reinterpret_cast<const uint4*>(a.x + a_goff[k] + coff);
             ra[k] = v;
         }
         const uint4* ws = wsrc + (size_t)c * slab32;
@@ -194,8 +199,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 
     // ---- per-lane operand bases: this lane's output pixel in each 32-pixel subtile
     int pixb[2];
-    bool rowok[2];
-    int orow[2];  // output pixel linear index (n, oyA, oxA) or -1
+    int obase[2], rbase[2];  // element offset of (output pixel, first channel block of this cout tile) in y / res, -1 = none
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = wave * 64 + j * 32 + l31;
@@ -205,8 +209,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         const bool inb = b < a.NB;
         pixb[j] = inb ? ((b * a.PH + ty * a.sh) * a.PW + tx * a.sw) * 16 : 0;
         const int n = n0 + b, oy = ty0 + ty, ox = tx0 + tx;
-        rowok[j] = inb && n < a.N && oy < a.Ho && ox < a.Wo;
-        orow[j] = (n * a.HoA + oy * a.osy + ooy) * a.WoA + ox * a.osx + oox;
+        const bool rowok = inb && n < a.N && oy < a.Ho && ox < a.Wo;
+        const int opx = (oy * a.osy + ooy) * a.WoA + ox * a.osx + oox;
+        const int cbo = (ntile * BN) >> 4;
+        obase[j] = rowok ? (((n * a.y_cbt + a.y_cb0 + cbo) * (a.HoA * a.WoA) + opx) * 16) : -1;
+        rbase[j] = rowok ? (((n * a.res_cbt + a.res_cb0 + cbo) * (a.HoA * a.WoA) + opx) * 16) : -1;
     }
 
     f32x16 acc[NBT][2];
@@ -298,25 +305,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
     // segments of a pixel row (8-byte scattered accesses from the MFMA C layout were
     // issue-bound).  The main loop ended with a barrier: the front of LDS is free.
     constexpr int ROWB = BN * 2 + 16;   // bytes per pixel row in the transpose region (+16: bank spread)
-    constexpr int SEGS = BN / 8;        // 16-byte segments per pixel row
-    constexpr int LOG2SEGS = NBT == 1 ? 2 : (NBT == 2 ? 3 : 4);
+    constexpr int CBN = BN / 16;        // channel blocks per block (BN = 32: 2)
     unsigned char* const wreg = smem + wave * (64 * ROWB);
     const int cout0 = ntile * BN;
-    const int nseg_valid = min(SEGS, (a.Cout - cout0) >> 3);
+    const int ncb_valid = min(CBN, (a.Cout - cout0) >> 4);
     const bool has_res = a.res != nullptr;
+    const int HWo16 = a.HoA * a.WoA * 16;
 
     if (has_res) {
 #pragma unroll
-        for (int it = 0; it < SEGS; ++it) {
+        for (int it = 0; it < 2 * CBN; ++it) {
             const int idx = it * 64 + lane;
-            const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
-            const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
-            const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
-            const int orw = (row & 32) ? o1 : o0;
-            const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
+            const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
+            const int r0 = __shfl(rbase[0], px & 31), r1 = __shfl(rbase[1], px & 31);
+            const int rb = (px & 32) ? r1 : r0;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = *reinterpret_cast<const uint4*>(a.res + (size_t)orw * a.res_ld + a.res_coff + cout0 + seg * 8);
-            *reinterpret_cast<uint4*>(wreg + row * ROWB + seg * 16) = v;
+            if (rb >= 0 && cbl < ncb_valid) v = *reinterpret_cast<const uint4*>(a.res + rb + cbl * HWo16 + half * 8);
+            *reinterpret_cast<uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2) = v;
         }
     }
 #pragma unroll
@@ -350,15 +355,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         }
     }
 #pragma unroll
-    for (int it = 0; it < SEGS; ++it) {
+    for (int it = 0; it < 2 * CBN; ++it) {
         const int idx = it * 64 + lane;
-        const int row = idx >> LOG2SEGS, seg = idx & (SEGS - 1);
-        const int o0 = __shfl(orow[0], row & 31), o1 = __shfl(orow[1], row & 31);
-        const int k0 = __shfl((int)rowok[0], row & 31), k1 = __shfl((int)rowok[1], row & 31);
-        const int orw = (row & 32) ? o1 : o0;
-        const bool ok = ((row & 32) ? k1 : k0) && seg < nseg_valid;
-        const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + seg * 16);
-        if (ok) *reinterpret_cast<uint4*>(a.y + (size_t)orw * a.y_ld + a.y_coff + cout0 + seg * 8) = v;
+        const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
+        const int o0 = __shfl(obase[0], px & 31), o1 = __shfl(obase[1], px & 31);
+        const int ob = (px & 32) ? o1 : o0;
+        const uint4 v = *reinterpret_cast<const uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2);
+        if (ob >= 0 && cbl < ncb_valid) *reinterpret_cast<uint4*>(a.y + ob + cbl * HWo16 + half * 8) = v;
     }
 }
 
@@ -436,7 +439,8 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
                      const float* scale, const float* shift, std::string* err, int hint_hw) {
     *p = ConvPlan();
-    const int Cin = (CinReal + 7) / 8 * 8;
+    // channel-blocked layout: whole 16-channel blocks; inputs of <= 8 channels are plain [N][H][W][8]
+    const int Cin = CinReal <= 8 ? 8 : (CinReal + 15) / 16 * 16;
     p->kh = kh; p->kw = kw; p->sh = sh; p->sw = sw; p->ph = ph; p->pw = pw;
     p->transposed = transposed; p->out_pad = out_pad;
     p->Cin = Cin; p->Cout = Cout;
@@ -566,7 +570,12 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
                             const int lco = nt * 32 + n;
                             if (lco >= lCout) continue;
                             int co = lco, ky = phases[pi][t].ky, kx = phases[pi][t].kx;
-                            if (p->gemm_1x1_expand) { co = lco % Cout; const int pos = lco / Cout; ky = pos / kw; kx = pos % kw; }
+                            if (p->gemm_1x1_expand) {
+                                // output channel order (cout block, position, 16): the result [N][k*k*Cout/16][1][1][16]
+                                // IS the channel-blocked k x k map [N][Cout/16][k][k][16]
+                                const int c16 = lco & 15, tt = lco >> 4, pos = tt % (kh * kw);
+                                co = (tt / (kh * kw)) * 16 + c16; ky = pos / kw; kx = pos % kw;
+                            }
                             f16* dst = base + ((((size_t)(nt * nchunks + c) * Tp + t) * NC8 + pl) * 32 + n) * 8;
                             for (int j = 0; j < 8; ++j) dst[j] = (f16)wval(co, c8 * 8 + j, ky, kx);
                         }
@@ -575,7 +584,10 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
 
     // folded BN parameters (padded to CoutPad; replicated per position for the 1x1-expand case)
     std::vector<float> sc(CoutPad, 0.f), sf(CoutPad, 0.f);
-    for (int i = 0; i < lCout; ++i) { sc[i] = scale ? scale[i % Cout] : 1.f; sf[i] = shift ? shift[i % Cout] : 0.f; }
+    for (int i = 0; i < lCout; ++i) {
+        const int co = p->gemm_1x1_expand ? ((i >> 4) / (kh * kw)) * 16 + (i & 15) : i;
+        sc[i] = scale ? scale[co] : 1.f; sf[i] = shift ? shift[co] : 0.f;
+    }
 
     p->w_bytes = packed.size() * sizeof(f16);
     HIPCHK(hipMalloc((void**)&p->d_w, p->w_bytes + metas.size() * sizeof(PhaseMeta) + 256));
@@ -609,17 +621,17 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     p.out_dims(io.H, io.W, &HoA, &WoA);
     a.x = io.x; a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift; a.res = io.res; a.y = io.y;
     a.phases = reinterpret_cast<const PhaseMeta*>((const char*)p.d_w + (p.w_bytes + 15) / 16 * 16);
-    a.N = io.N; a.H = io.H; a.W = io.W; a.x_ld = io.x_ld; a.x_coff = io.x_coff;
-    a.res_ld = io.res_ld; a.res_coff = io.res_coff;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
+    a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
     a.Cin8 = p.Cin / 8;
     a.relu = io.relu;
-    a.y_ld = io.y_ld; a.y_coff = io.y_coff;
+    int y_ld = io.y_ld;
     int kext_y, kext_x;
     if (p.gemm_1x1_expand) {
         if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }
         if (io.y_ld != p.Cout || io.y_coff != 0) { if (err) *err = "1x1-expand output must be contiguous"; return -1; }
         a.Ho = 1; a.Wo = 1; a.HoA = 1; a.WoA = 1; a.osy = 1; a.osx = 1;
-        a.y_ld = p.kh * p.kw * p.Cout;
+        y_ld = p.kh * p.kw * p.Cout;
         a.Cout = p.kh * p.kw * p.Cout;
         a.sh = a.sw = 1; a.pad_y = a.pad_x = 0; kext_y = kext_x = 1;
     } else if (p.transposed) {
@@ -629,11 +641,12 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
         a.Ho = HoA; a.Wo = WoA; a.HoA = HoA; a.WoA = WoA; a.osy = 1; a.osx = 1;
         a.Cout = p.Cout; a.sh = p.sh; a.sw = p.sw; a.pad_y = p.ph; a.pad_x = p.pw; kext_y = p.kh; kext_x = p.kw;
     }
-    if ((a.x_ld | a.x_coff | a.y_ld | a.y_coff) & 3 || (a.x_ld & 7) || (a.x_coff & 7)) {
-        if (err) *err = "channel strides/offsets must be multiples of 8 (input) / 4 (output)";
+    a.y_cbt = y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
+    if (((NC8 == 1 ? 0 : (io.x_ld | io.x_coff)) | y_ld | io.y_coff | a.Cout) & 15 || (NC8 == 1 && (io.x_ld != 8 || io.x_coff != 0))) {
+        if (err) *err = "channel counts/offsets must be multiples of 16 (channel-blocked layout)";
         return -1;
     }
-    if (io.res && ((io.res_ld | io.res_coff) & 3)) { if (err) *err = "residual stride/offset must be a multiple of 4"; return -1; }
+    if (io.res && ((io.res_ld | io.res_coff) & 15)) { if (err) *err = "residual channel count/offset must be a multiple of 16"; return -1; }
 
     // tile: TW x TH output pixels x NB images, 256 rows
     int l2w = std::min(5, ceil_log2(a.Wo));

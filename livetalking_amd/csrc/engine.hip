@@ -237,7 +237,7 @@ const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& n
 
 // `hint_hw`: pixels per image of the layer's input map.  `flat_ld` > 0: the k x k "valid" conv that collapses a
 // k x k map to 1x1 (face_encoder_blocks.7.0) is run as a 1x1 conv over the map viewed as ONE pixel of
-// k*k*flat_ld channels (pixel stride flat_ld >= cin; the gap channels get zero weights).
+// k*k*cin channels (a channel-blocked k x k map is contiguous per channel block).
 int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0) {
     const std::string p = d.prefix;
     const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
@@ -259,13 +259,14 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
     std::string err;
     int rc;
     if (flat_ld > 0) {
+        // channel-blocked map [n][cb][k*k][16] read as ONE pixel of cin*k*k channels: flat channel = ((cb*kk + t)*16 + c16)
         const int kk = d.k * d.k;
-        const int cin_flat = (kk - 1) * flat_ld + d.cin;        // from the first real channel to the last
+        const int cin_flat = kk * d.cin;
         std::vector<float> wf((size_t)d.cout * cin_flat, 0.f);
         for (int co = 0; co < d.cout; ++co)
             for (int ci = 0; ci < d.cin; ++ci)
                 for (int t = 0; t < kk; ++t)
-                    wf[(size_t)co * cin_flat + (size_t)t * flat_ld + ci] = w[((size_t)co * d.cin + ci) * kk + t];
+                    wf[(size_t)co * cin_flat + ((size_t)(ci >> 4) * kk + t) * 16 + (ci & 15)] = w[((size_t)co * d.cin + ci) * kk + t];
         rc = conv_plan_create(&L->plan, wf.data(), cin_flat, d.cout, 1, 1, 1, 1, 0, 0, false, 0, sc.data(), sf.data(), &err, 1);
     } else {
         rc = conv_plan_create(&L->plan, w, d.cin, d.cout, d.k, d.k, d.sh, d.sw, d.pad, d.pad, d.transposed, d.out_pad,
@@ -321,12 +322,13 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             Layer L;
             // the 4x4 "valid" conv on the 4x4 map: a 1x1 conv over the flattened map (needs in_ld % 64 == 0)
             const bool flat = !bl.d.transposed && bl.d.pad == 0 && bl.d.k > 1 && bl.d.k == H && bl.d.k == W &&
-                              in_ld % 64 == 0 && bl.d.cin % 64 == 0 && getenv("LTK_NO_FLATTEN") == nullptr;
+                              bl.d.cin % 64 == 0 && getenv("LTK_NO_FLATTEN") == nullptr;
             if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, flat ? in_ld : 0))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
             if (flat) {
                 L.Ho = 1; L.Wo = 1;
-                L.H = 1; L.W = 1; L.in_ld = bl.d.k * bl.d.k * in_ld;   // one "pixel" per image
+                L.H = 1; L.W = 1;                                      // one "pixel" per image
+                L.in_ld = bl.d.k * bl.d.k * in_ld; L.in_coff = bl.d.k * bl.d.k * in_coff;
             } else {
                 L.plan.out_dims(H, W, &L.Ho, &L.Wo);
             }

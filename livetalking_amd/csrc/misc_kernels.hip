@@ -64,7 +64,7 @@ void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_
 // output head: nn.Conv2d(32,3,1) + Sigmoid (wav2lip_v2.py:90-91), *255 + uint8 truncation
 // (wav2lip_avatar.py:138,145).  One thread = 4 consecutive pixels -> 12 output bytes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_ld,
+__global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_cbt,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     const OutPtrs outs, int have_u8, float* __restrict__ out_f32) {
     constexpr int hw = 65536;
@@ -78,11 +78,11 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, in
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + k;
-        const f16* px = x + ((size_t)f * hw + r) * x_ld;
+        // channel-blocked [N][cb][H*W][16]: channels 8v..8v+7 of pixel r sit in block v/2, half v&1
         float acc0 = sw[96], acc1 = sw[97], acc2 = sw[98];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const f16x8 h = *reinterpret_cast<const f16x8*>(px + v * 8);
+            const f16x8 h = *reinterpret_cast<const f16x8*>(x + (((size_t)f * x_cbt + (v >> 1)) * hw + r) * 16 + (v & 1) * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xv = (float)h[j];
@@ -115,7 +115,7 @@ void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, cons
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s) {
     OutPtrs none;
     if (!out_u8) for (int i = 0; i < nframes; ++i) none.p[i] = nullptr;
-    hipLaunchKernelGGL(head_kernel, dim3(64, nframes), dim3(256), 0, s, x32, x_ld, w3x32, b3,
+    hipLaunchKernelGGL(head_kernel, dim3(64, nframes), dim3(256), 0, s, x32, x_ld >> 4, w3x32, b3,
                        out_u8 ? *out_u8 : none, out_u8 ? 1 : 0, out_f32_nchw);
 }
 
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict
     const int p = (int)(i % HW);
     const int c = (int)((i / HW) % C);
     const int n = (int)(i / ((size_t)HW * C));
-    out[i] = (float)x[((size_t)n * HW + p) * ld + coff + c];
+    const int cc = coff + c;   // channel-blocked [N][ld/16][HW][16]
+    out[i] = (float)x[(((size_t)n * (ld >> 4) + (cc >> 4)) * HW + p) * 16 + (cc & 15)];
 }
 
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s) {

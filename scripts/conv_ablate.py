@@ -33,7 +33,7 @@ def main():
         wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
         w = (np.random.default_rng(0).standard_normal(wshape) * 0.05).astype(np.float32)
         Ho, Wo = (H * 2, W * 2) if tr else (H, W)
-        y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float16, device="cuda")
+        y = torch.empty(N, Ho, Wo, (Cout + 15) // 16 * 16, dtype=torch.float16, device="cuda")
         sc = np.ones(Cout, np.float32)
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
