@@ -55,6 +55,10 @@ struct K3Args {
     unsigned magicPW, magicPHW;
     int nchunks, ksplit, chunks_per_split;
     int relu;
+    int stagger;                     // cycles the second resident block of each CU idles before it starts, so the
+                                     // two blocks of a CU run out of phase (one in its MFMA loop while the other
+                                     // is in its prologue / epilogue)
+    int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
     int ablate;                      // measurement only (LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no residual read,
                                      // 16 no output store, 32 no LDS zero fill
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
@@ -88,6 +92,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hh = lane >> 5;
+
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)a.stagger) __builtin_amdgcn_s_sleep(16);
+    }
 
     // ---- block -> (k split, image tile, y tile, x tile, cout tile); XCD-contiguous logical ids
     int bid = blockIdx.x;
@@ -148,6 +157,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
     }
 
+    // ---- folded-BN scale/shift of this block's BN output channels -> LDS (read by the epilogue)
+    if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid - which * BN;
+        reinterpret_cast<float*>(smem + a.lds_scale_off)[tid] = (which ? a.shift : a.scale)[ntile * BN + c];
+    }
+
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
     constexpr int slab32 = T * NC8 * 32;
     const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + (size_t)(ntile * NBT) * a.nchunks * slab32;
@@ -203,25 +218,42 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     auto compute = [&](int buf) {
         const unsigned char* Ab = smem + buf * STAGE;
         const unsigned char* Bb = Ab + A_BYTES;
+        // keep hipcc from hoisting the 9 x PXW swizzled operand addresses out of the chunk loop: they would
+        // pin ~70 VGPRs and leave no room for the double-buffered fragments
+#pragma unroll
+        for (int j = 0; j < PXW; ++j) asm volatile("" : "+v"(pixb[j]));
 #pragma unroll
         for (int q = 0; q < NCB; ++q) {
             const int plane = 2 * q + hh;
             const unsigned char* Ap = Ab + q * PS;
             if constexpr (G == 1) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
+                // software pipeline over the taps: the fragments of tap t+1 are read from LDS while the MFMAs of
+                // tap t run (left to itself hipcc reads a fragment right before its first use and waits
+                // lgkmcnt(0): one exposed LDS round trip per four MFMAs)
+                f16x8 xa[2][PXW], wf[2][NBT];
+                auto load_tap = [&](int t, int sl) {
                     const int toff = (T == 9) ? ((t / 3) * a.PW + (t % 3)) : 0;
-                    f16x8 xa[PXW], wf[NBT];
-#pragma unroll
-                    for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + toff));
 #pragma unroll
                     for (int i = 0; i < NBT; ++i)
-                        wf[i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
+                        wf[sl][i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) xa[sl][j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + toff));
+                };
+                load_tap(0, 0);
+                if (T > 1) __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);       // reads of tap 0
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int sl = t & 1;
+                    if (t + 1 < T) load_tap(t + 1, sl ^ 1);
 #pragma unroll
                     for (int i = 0; i < NBT; ++i)
 #pragma unroll
                         for (int j = 0; j < PXW; ++j)
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xa[j], acc[0][i][j], 0, 0, 0);
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[sl][i], xa[sl][j], acc[0][i][j], 0, 0, 0);
+                    if (t + 1 < T) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);   // DS reads of tap t+1 first
+                        __builtin_amdgcn_sched_group_barrier(0x008, NBT * PXW, 0);   // then the MFMAs of tap t
+                    }
                 }
             } else {
                 auto wfrag = [&](int t) {
@@ -281,8 +313,19 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         if (c + 1 < c_end) stage(c + 1, cur ^ 1);
         if (!(a.ablate & 4)) compute(cur);
     }
-    __syncthreads();                       // LDS is reused by the epilogue
 
+    if (a.ablate & 64) return;             // measurement: no epilogue at all
+    if (a.ablate & 128) {                  // measurement: epilogue arithmetic only keeps acc alive
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) t += acc[g][i][j][0] + acc[g][i][j][7];
+        if (t == 12345.678f) a.y[0] = (f16)t;
+        return;
+    }
     // ---- epilogue
     const int cout0 = ntile * BN;
     const int HWo = a.HoA * a.WoA;
@@ -325,57 +368,44 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         return;
     }
 
-    // y = relu(acc*scale + shift + res) -> fp16 through a wave-private LDS transpose (64 pixel rows x BN
-    // channels per pass): residual reads and output writes then are 32 pixels x 32 B = one contiguous KiB per
-    // wave instruction in the channel-blocked layout.
-    constexpr int ROWB = BN * 2 + 16;
-    constexpr int CBN = BN / 16;            // channel blocks per block
-    unsigned char* const wreg = smem + wave * (64 * ROWB);
-    const int ncb_valid = min(CBN, (a.Cout - cout0) >> 4);
+    // y = relu(acc*scale + shift + res) -> fp16, stored straight from the MFMA accumulator layout: a lane holds
+    // 4 consecutive output channels of one pixel per register group; v_permlane32_swap pairs the two lane
+    // halves so that every lane owns 8 consecutive channels (16 B) of its pixel, lanes 0-31 the first half of a
+    // channel block and lanes 32-63 the second: one wave store = 32 pixels x 32 B = one contiguous KiB of the
+    // channel-blocked output.  No LDS round trip (the ds_write_b64 transposes cost more than the MFMAs on the
+    // 64-channel layers).
+    const int ncb_valid = min(BN / 16, (a.Cout - cout0) >> 4);
     const bool has_res = a.res != nullptr && !(a.ablate & 8);
     const bool do_store = !(a.ablate & 16);
     const int cbo = cout0 >> 4;
+    const int HWo16 = HWo * 16;
+    const float* const sbase = reinterpret_cast<const float*>(smem + a.lds_scale_off);   // [2][BN] staged in the prologue
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int jp = 0; jp < PXW / 2; ++jp) {
-            int obase[2], rbase[2];      // element offset of (pixel, channel block cbo) in y / res, -1 = outside
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                bool ok;
-                int n;
-                const int opx = out_px(2 * jp + jj, g, &n, &ok);
-                obase[jj] = ok ? (((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16) : -1;
-                rbase[jj] = ok ? (((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16) : -1;
-            }
-            if (has_res) {
-#pragma unroll
-                for (int it = 0; it < 2 * CBN; ++it) {
-                    const int idx = it * 64 + lane;
-                    const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
-                    const int r0 = __shfl(rbase[0], px & 31), r1 = __shfl(rbase[1], px & 31);
-                    const int rb = (px & 32) ? r1 : r0;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (rb >= 0 && cbl < ncb_valid) v = *reinterpret_cast<const uint4*>(a.res + rb + cbl * (HWo * 16) + half * 8);
-                    *reinterpret_cast<uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2) = v;
-                }
-            }
+        for (int j = 0; j < PXW; ++j) {
+            bool ok;
+            int n;
+            const int opx = out_px(j, g, &n, &ok);
+            const int obase = ((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16 + hh * 8;
+            const int rbase = ((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16 + hh * 4;
 #pragma unroll
             for (int i = 0; i < NBT; ++i) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int cl = i * 32 + 8 * q4 + 4 * hh;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);
-                    const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
+                for (int pr = 0; pr < 2; ++pr) {        // channel block 2i+pr of this block's BN
+                    unsigned pk[2][2];
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        unsigned char* p = wreg + (jj * 32 + l31) * ROWB + cl * 2;
+                    for (int eo = 0; eo < 2; ++eo) {    // q4 = 2pr+eo: channels 8*q4 + 4*hh .. +3 of the 32-cout tile i
+                        const int q4 = 2 * pr + eo;
+                        const int cl = i * 32 + 8 * q4 + 4 * hh;
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(sbase + cl);
+                        const f32x4 sf = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[g][i][2 * jp + jj][4 * q4 + r] * sc[r] + sf[r];
-                        if (has_res) {
-                            const f16x4 rr = *reinterpret_cast<const f16x4*>(p);
+                        for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[r] + sf[r];
+                        if (has_res && ok && (2 * i + pr) < ncb_valid) {
+                            const f16x4 rr = *reinterpret_cast<const f16x4*>(a.res + rbase + (2 * i + pr) * HWo16 + eo * 8);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
                         }
@@ -387,18 +417,17 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                             t = fminf(fmaxf(t, -65504.f), 65504.f);
                             o[r] = (f16)t;
                         }
-                        *reinterpret_cast<f16x4*>(p) = o;
+                        const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                        pk[eo][0] = u.x; pk[eo][1] = u.y;
                     }
+                    // lanes 0-31 keep eo=0 (channels 0-3) and receive the partner's eo=0 (channels 4-7);
+                    // lanes 32-63 end with the eo=1 pair
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (ok && do_store && (2 * i + pr) < ncb_valid)
+                        *reinterpret_cast<uint4*>(a.y + obase + (2 * i + pr) * HWo16) = out;
                 }
-            }
-#pragma unroll
-            for (int it = 0; it < 2 * CBN; ++it) {
-                const int idx = it * 64 + lane;
-                const int cbl = idx >> 7, px = (idx >> 1) & 63, half = idx & 1;
-                const int o0 = __shfl(obase[0], px & 31), o1 = __shfl(obase[1], px & 31);
-                const int ob = (px & 32) ? o1 : o0;
-                const uint4 v = *reinterpret_cast<const uint4*>(wreg + px * ROWB + (cbl * 16 + half * 8) * 2);
-                if (ob >= 0 && cbl < ncb_valid && do_store) *reinterpret_cast<uint4*>(a.y + ob + cbl * (HWo * 16) + half * 8) = v;
             }
         }
     }
@@ -553,6 +582,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     const char* ev_split = getenv("LTK_SPLITK");      // 0: never split (batch-size independent summation order)
     const char* ev_abl = getenv("LTK_ABLATE");
     const int allow_split = ev_split ? atoi(ev_split) : 1;
+    const char* ev_stag = getenv("LTK_STAGGER");
     const int ablate = ev_abl ? atoi(ev_abl) : 0;
     a.ablate = ablate;
     int ksplit = allow_split ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
@@ -571,9 +601,10 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     if (ksplit > 1) a.partial = io.partial;
 
     const size_t a_bytes = (size_t)(NC8 / 2) * a.SLOTS * 16, b_bytes = (size_t)T * NC8 * BN * 16;
-    const size_t epi_bytes = (size_t)4 * 64 * (BN * 2 + 16);
-    size_t lds = std::max(2 * (a_bytes + b_bytes), epi_bytes);
+    size_t lds = 2 * (a_bytes + b_bytes);
     lds = (lds + 255) / 256 * 256;
+    a.lds_scale_off = (int)lds;
+    lds += 2 * BN * sizeof(float);
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
     k3_kernel_t k = k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
@@ -584,6 +615,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         HIPCHK3(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured.push_back((const void*)k);
     }
+    a.stagger = ev_stag ? atoi(ev_stag) : 0;
+    if (a.stagger < 0) a.stagger = (a.chunks_per_split * (G == 4 ? 1400 : 2300) * (PXW == 4 ? 2 : 1) / 2 + 3000) / 2 * (-a.stagger) / 100;
+    if (nblk < 512) a.stagger = 0;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, stream, a);
     HIPCHK3(hipGetLastError());
     if (ksplit > 1) {

@@ -122,6 +122,7 @@ struct Layer {
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
     int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
     bool residual = false;
+    bool res_folded = false;   // the identity branch lives in the centre tap of the packed weights
     bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
     double macs = 0;  // per frame
 };
@@ -258,6 +259,25 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
     }
     std::string err;
     int rc;
+    // Residual blocks (conv.py:16-17: out = relu(bn(conv(x)) + x), x = the block's own input): with
+    // y = s*conv(x) + t + x the identity is the centre tap of a k x k kernel, w[co][co][c][c] += 1/s[co].
+    // The accumulation is fp32 and the fp16 rounding of (w + 1/s) perturbs the identity term by one fp16 ulp of
+    // x - the same error x already carries - while the separate residual read (one extra pass over the
+    // activation) disappears.  Not applied when a scale is too small for 1/s to be a sane fp16 weight.
+    std::vector<float> wfold;
+    L->res_folded = false;
+    if (d.residual && !d.transposed && d.cin == d.cout && (d.k & 1) && d.sh == 1 && d.sw == 1 && d.pad == d.k / 2 &&
+        getenv("LTK_NO_FOLD_RESIDUAL") == nullptr) {
+        bool ok = true;
+        for (int c = 0; c < d.cout; ++c) ok = ok && fabsf(sc[c]) >= 1e-3f;
+        if (ok) {
+            wfold.assign(w, w + wcount);
+            const int kk = d.k * d.k, ctr = (d.k / 2) * d.k + d.k / 2;
+            for (int c = 0; c < d.cout; ++c) wfold[((size_t)c * d.cin + c) * kk + ctr] += 1.0f / sc[c];
+            w = wfold.data();
+            L->res_folded = true;
+        }
+    }
     if (flat_ld > 0) {
         // channel-blocked map [n][cb][k*k][16] read as ONE pixel of cin*k*k channels: flat channel = ((cb*kk + t)*16 + c16)
         const int kk = d.k * d.k;
@@ -406,7 +426,22 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s) {
         CHK(hipEventRecord(e->ev_fork, s));
         CHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
     }
-    for (Layer& L : e->layers) {
+    // enqueue order: the first two face-encoder launches go out before the 13 audio launches, so the main
+    // stream is busy while the host is still issuing the small audio kernels (each launch costs the host
+    // a few microseconds); stream order per stream is unchanged
+    std::vector<Layer*> order;
+    if (fork) {
+        size_t first_face = 0;
+        while (first_face < e->layers.size() && e->layers[first_face].audio) ++first_face;
+        const size_t head = std::min(e->layers.size(), first_face + 2);
+        for (size_t i = first_face; i < head; ++i) order.push_back(&e->layers[i]);
+        for (size_t i = 0; i < first_face; ++i) order.push_back(&e->layers[i]);
+        for (size_t i = head; i < e->layers.size(); ++i) order.push_back(&e->layers[i]);
+    } else {
+        for (Layer& L : e->layers) order.push_back(&L);
+    }
+    for (Layer* Lp : order) {
+        Layer& L = *Lp;
         const bool on_aux = fork && L.audio;
         if (!on_aux && !joined && !L.audio && L.in_buf >= B_AT0 && L.in_buf <= B_AT1 && L.name.rfind("face_decoder", 0) == 0) {
             CHK(hipEventRecord(e->ev_join, e->aux));
@@ -416,7 +451,7 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s) {
         ConvIO io;
         io.x = e->buf[L.in_buf]; io.N = nf; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
         io.y = e->buf[L.out_buf]; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
-        io.res = L.residual ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
+        io.res = (L.residual && !L.res_folded) ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
         io.relu = 1;
         io.partial = on_aux ? e->d_partial_aux : e->d_partial;
         io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;

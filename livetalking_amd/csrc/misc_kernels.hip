@@ -69,53 +69,47 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, in
                                                     const OutPtrs outs, int have_u8, float* __restrict__ out_f32) {
     constexpr int hw = 65536;
     __shared__ float sw[3 * 32 + 3];
+    __shared__ unsigned obytes[192];          // 256 pixels x 3 bytes
     if (threadIdx.x < 96) sw[threadIdx.x] = w[threadIdx.x];
     if (threadIdx.x < 3) sw[96 + threadIdx.x] = b[threadIdx.x];
     __syncthreads();
     const int f = blockIdx.y;
-    const int r0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // first of 4 consecutive pixels of frame f
-    unsigned bytes[3] = {0u, 0u, 0u};
+    const int r = blockIdx.x * 256 + threadIdx.x;     // one pixel per thread: a wave reads 64 x 32 B contiguous per block
+    float acc0 = sw[96], acc1 = sw[97], acc2 = sw[98];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = r0 + k;
+    for (int v = 0; v < 4; ++v) {
         // channel-blocked [N][cb][H*W][16]: channels 8v..8v+7 of pixel r sit in block v/2, half v&1
-        float acc0 = sw[96], acc1 = sw[97], acc2 = sw[98];
+        const f16x8 h = *reinterpret_cast<const f16x8*>(x + (((size_t)f * x_cbt + (v >> 1)) * hw + r) * 16 + (v & 1) * 8);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const f16x8 h = *reinterpret_cast<const f16x8*>(x + (((size_t)f * x_cbt + (v >> 1)) * hw + r) * 16 + (v & 1) * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xv = (float)h[j];
-                acc0 += xv * sw[v * 8 + j];
-                acc1 += xv * sw[32 + v * 8 + j];
-                acc2 += xv * sw[64 + v * 8 + j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (float)h[j];
+            acc0 += xv * sw[v * 8 + j];
+            acc1 += xv * sw[32 + v * 8 + j];
+            acc2 += xv * sw[64 + v * 8 + j];
         }
-        const float s0 = 1.f / (1.f + __expf(-acc0));
-        const float s1 = 1.f / (1.f + __expf(-acc1));
-        const float s2 = 1.f / (1.f + __expf(-acc2));
-        if (out_f32) {
-            float* o = out_f32 + (size_t)f * 3 * hw + r;
-            o[0] = s0; o[(size_t)hw] = s1; o[(size_t)2 * hw] = s2;
-        }
-        // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
-        const unsigned u0 = (unsigned)(s0 * 255.f), u1 = (unsigned)(s1 * 255.f), u2 = (unsigned)(s2 * 255.f);
-        const int bo = k * 3;
-        bytes[(bo + 0) >> 2] |= u0 << (((bo + 0) & 3) * 8);
-        bytes[(bo + 1) >> 2] |= u1 << (((bo + 1) & 3) * 8);
-        bytes[(bo + 2) >> 2] |= u2 << (((bo + 2) & 3) * 8);
     }
-    if (have_u8 && outs.p[f]) {
-        unsigned* o = reinterpret_cast<unsigned*>(outs.p[f] + (size_t)r0 * 3);
-        o[0] = bytes[0]; o[1] = bytes[1]; o[2] = bytes[2];
+    const float s0 = 1.f / (1.f + __expf(-acc0));
+    const float s1 = 1.f / (1.f + __expf(-acc1));
+    const float s2 = 1.f / (1.f + __expf(-acc2));
+    if (out_f32) {
+        float* o = out_f32 + (size_t)f * 3 * hw + r;
+        o[0] = s0; o[(size_t)hw] = s1; o[(size_t)2 * hw] = s2;
     }
+    // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
+    unsigned char* ob = reinterpret_cast<unsigned char*>(obytes) + threadIdx.x * 3;
+    ob[0] = (unsigned char)(unsigned)(s0 * 255.f);
+    ob[1] = (unsigned char)(unsigned)(s1 * 255.f);
+    ob[2] = (unsigned char)(unsigned)(s2 * 255.f);
+    __syncthreads();
+    if (have_u8 && outs.p[f] && threadIdx.x < 192)
+        reinterpret_cast<unsigned*>(outs.p[f] + (size_t)blockIdx.x * 768)[threadIdx.x] = obytes[threadIdx.x];
 }
 
 void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s) {
     OutPtrs none;
     if (!out_u8) for (int i = 0; i < nframes; ++i) none.p[i] = nullptr;
-    hipLaunchKernelGGL(head_kernel, dim3(64, nframes), dim3(256), 0, s, x32, x_ld >> 4, w3x32, b3,
+    hipLaunchKernelGGL(head_kernel, dim3(256, nframes), dim3(256), 0, s, x32, x_ld >> 4, w3x32, b3,
                        out_u8 ? *out_u8 : none, out_u8 ? 1 : 0, out_f32_nchw);
 }
 

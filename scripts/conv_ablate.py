@@ -20,7 +20,7 @@ LAYERS = [
     ("T160>64@128", 128, 128, 160, 64, 3, 2, 1, True, 1, False),
     ("T320>128@64", 64, 64, 320, 128, 3, 2, 1, True, 1, False),
 ]
-MASKS = [0, 1, 2, 3, 4, 8, 16, 24, 28, 27, 31, 7]
+MASKS = [int(m) for m in os.environ.get("ABLATE_MASKS", "0,3,4,24,27,31,63,95,127,64,128,132").split(",")]
 
 
 def main():
@@ -38,6 +38,9 @@ def main():
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
         for m in MASKS:
+            if os.environ.get("ABLATE_STAGGER"):
+                os.environ["LTK_STAGGER"] = str(m)
+                m = 0
             os.environ["LTK_ABLATE"] = str(m)
             ms = eng.conv2d_f16(x.data_ptr(), N, H, W, Cin, w, Cout, k, s, p, tr, op, sc, sf,
                                 x.data_ptr() if res else 0, True, y.data_ptr(), iters=10)
