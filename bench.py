@@ -38,7 +38,7 @@ def cpu_baseline(batch: int, budget_s: float = 20.0):
     import torch
     from livetalking_amd import synth
     from oracle import mel_oracle, plugin_oracle   # the checker, timed here as the CPU baseline only
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))   # more threads only add contention on this model size
     sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(1234).items()}
     frames, faces, coords = synth.wav2lip_avatar(n_frames=8, full_hw=(360, 640), box=160, seed=0)
     audio = synth.synthetic_audio(2.0)
@@ -125,10 +125,21 @@ def main():
     total_frames = world * args.steps * frames_per_step
     value = total_frames / elapsed
 
-    # dominant kernel family (conv_mfma_kernel): HIP events on the engine's stream around the
-    # conv stack only (no gather/pack, no head), averaged over launches of the same workload
+    # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass): HIP events on
+    # the engine's own stream around the conv stack only (no gather/pack, no head), averaged over 10 passes
+    # of the same workload.  One "launch" below = one pass of the conv stack over frames_per_step frames.
     conv_ms, conv_macs = eng.time_convs(frames_per_step, 10)
     achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
+    # HBM bytes per pass from the committed rocprofv3 PMC summary of this same command
+    # (scripts/gpu_profile.sh -> scripts/make_profile_summary.py): separate --pmc passes, FETCH_SIZE doubled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            pm = json.load(f)
+        if int(pm.get("frames_per_pass", -1)) == frames_per_step:
+            traffic = float(pm["hbm_bytes_per_pass"])
+    except Exception:  # noqa: BLE001 - the summary is optional
+        traffic = None
 
     if rank == 0:
         out = {
@@ -148,8 +159,9 @@ def main():
                        "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": frames_per_step,
                        "parallelism": f"session-sharded x{world} (no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
-                         "kernel": "conv_mfma_kernel (54 launches per pass)",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc.json)",
+                         "kernel": "conv3_kernel + conv_mfma_kernel (the 54 conv/convT layers = one pass)",
                          "conv_stack_ms": round(conv_ms, 4), "flops_per_frame": 2 * (MACS_PER_FRAME - HEAD_MACS)},
         }
         if not args.no_cpu_baseline:

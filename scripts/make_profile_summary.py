@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Turn one scripts/gpu_profile.sh output directory (gpurun_out/<tag>) into the committed summaries under
+profiles/: per-kernel stats (rocprofv3 --kernel-trace --stats), per-launch timeline of one inference pass, and
+the PMC-derived HBM traffic / MFMA utilisation of the conv kernels.
+
+    python scripts/make_profile_summary.py gpurun_out/r01 profiles/r01 [--passes 19]
+
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
+the bytes of a wide coalesced stream (TCC_EA0_RDREQ tallied at 64 B for 128-B requests), so reads are doubled;
+WRITE_SIZE is taken as reported (checked here against a layer whose output size is known exactly).
+"""
+import argparse
+import collections
+import json
+import os
+import re
+import sqlite3
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("void ", "").replace("ltk::", "")
+
+
+def counters(path):
+    if not os.path.exists(path):
+        return {}
+    db = sqlite3.connect(path)
+    out = collections.defaultdict(dict)
+    for k, c, v, n in db.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
+        out[short(k)][c] = (v, n)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst_prefix")
+    ap.add_argument("--passes", type=int, default=19, help="conv-stack passes in the profiled command (8 inference + 11 timing)")
+    ap.add_argument("--frames", type=int, default=16)
+    a = ap.parse_args()
+    os.makedirs(os.path.dirname(a.dst_prefix) or ".", exist_ok=True)
+    db = sqlite3.connect(os.path.join(a.src, "trace", "r_results.db"))
+    rows = db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, stream_id from kernels order by start").fetchall()
+    stats = collections.OrderedDict()
+    for r in rows:
+        s = stats.setdefault(short(r[0]), [0, 0.0, 1e30, 0.0, r[6], r[7]])
+        d = (r[2] - r[1]) / 1e3
+        s[0] += 1; s[1] += d; s[2] = min(s[2], d); s[3] = max(s[3], d)
+    tot = sum(s[1] for s in stats.values())
+    with open(a.dst_prefix + "_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline  (wav2lip256, 1 session, 16-frame batch)\n")
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us,pct,vgpr,sgpr\n")
+        for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"\"{k}\",{s[0]},{s[1]:.1f},{s[1]/s[0]:.2f},{s[2]:.2f},{s[3]:.2f},{100*s[1]/tot:.2f},{s[4]},{s[5]}\n")
+    # one inference pass
+    idx = [i for i, r in enumerate(rows) if "pack_faces" in r[0]]
+    conv_us = 0.0
+    with open(a.dst_prefix + "_pass_timeline.txt", "w") as f:
+        f.write("# last inference pass of the profiled run: start_us dur_us stream grid lds_bytes kernel\n")
+        if idx:
+            t0 = rows[idx[-1]][1]
+            for r in rows[idx[-1]:]:
+                n = short(r[0])
+                f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{r[8]} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
+                if "conv" in n:
+                    conv_us += (r[2] - r[1]) / 1e3
+                if "head_kernel" in n:
+                    f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us\n")
+                    break
+    fetch = counters(os.path.join(a.src, "pmc_fetch", "r_results.db"))
+    write = counters(os.path.join(a.src, "pmc_write", "r_results.db"))
+    sq = counters(os.path.join(a.src, "pmc_sq", "r_results.db"))
+    l2 = counters(os.path.join(a.src, "pmc_l2", "r_results.db"))
+    conv = [k for k in stats if k.startswith("conv")]
+    rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
+    wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024
+    mfma = sum(sq.get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0] for k in conv)
+    gui = sum(l2.get(k, {}).get("GRBM_GUI_ACTIVE", (0, 0))[0] for k in conv)       # summed over the 8 XCDs
+    hit = sum(l2.get(k, {}).get("TCC_HIT_sum", (0, 0))[0] for k in conv)
+    miss = sum(l2.get(k, {}).get("TCC_MISS_sum", (0, 0))[0] for k in conv)
+    summary = {
+        "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline",
+        "conv_passes_in_run": a.passes,
+        "frames_per_pass": a.frames,
+        "hbm_read_bytes_per_pass": rd / a.passes,
+        "hbm_write_bytes_per_pass": wr / a.passes,
+        "hbm_bytes_per_pass": (rd + wr) / a.passes,
+        "hbm_bytes_per_frame": (rd + wr) / a.passes / a.frames,
+        "fetch_size_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
+        "mfma_busy_cycles_per_pass": mfma / a.passes,
+        "mfma_util_conv_kernels": (mfma / 1024.0) / (gui / 8.0) if gui else None,
+        "l2_hit_rate_conv_kernels": hit / (hit + miss) if hit + miss else None,
+        "conv_kernel_us_last_pass": conv_us,
+    }
+    with open(a.dst_prefix + "_pmc.json", "w") as f:
+        json.dump(summary, f, indent=1)
+    with open(a.dst_prefix + "_pmc_per_kernel.csv", "w") as f:
+        f.write("kernel,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE,TCC_HIT,TCC_MISS,LDS_BANK_CONFLICT,LDS_IDX_ACTIVE\n")
+        for k in conv:
+            g = lambda d, c: d.get(k, {}).get(c, (0, 0))[0]
+            f.write(f"\"{k}\",{stats[k][0]},{g(fetch,'FETCH_SIZE'):.0f},{g(write,'WRITE_SIZE'):.0f},{g(sq,'SQ_VALU_MFMA_BUSY_CYCLES'):.0f},"
+                    f"{g(l2,'GRBM_GUI_ACTIVE'):.0f},{g(l2,'TCC_HIT_sum'):.0f},{g(l2,'TCC_MISS_sum'):.0f},{g(sq,'SQ_LDS_BANK_CONFLICT'):.0f},{g(sq,'SQ_LDS_IDX_ACTIVE'):.0f}\n")
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
