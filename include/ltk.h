@@ -99,7 +99,55 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
 int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out,
                    int out_is_device, void* stream);
 
+/* =========================== MuseTalk path (avatars/musetalk_avatar.py) =========================== */
+
+/* avatars/musetalk_avatar.py:57-67 load_model + avatars/musetalk/utils/utils.py:16-37 load_all_model: the
+ * conditional U-Net (diffusers UNet2DConditionModel state_dict, MuseTalk-1.5 config) and the AutoencoderKL
+ * decoder of sd-vae (state_dict keys "post_quant_conv.*", "decoder.*"), both fp32 host tensors under their
+ * diffusers names.  The timestep-0 embedding, attention scale, VAE scaling factor and the sinusoidal
+ * PositionalEncoding (avatars/musetalk/models/unet.py:12-27) are folded / precomputed here; arenas are sized
+ * for `max_frames` frames per launch. */
+int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd,
+                      int n_vae, int max_frames);
+
+/* avatars/musetalk_avatar.py:69-91 load_avatar.  latents: fp32 [n][8][32][32] (input_latent_list_cycle,
+ * latents.pt); full_bank uint8 [n][H][W][3] BGR; face_boxes int32 [n][4] = (x1,y1,x2,y2) (coords.pkl,
+ * musetalk_avatar.py:157); crop_boxes int32 [n][4] = (x_s,y_s,x_e,y_e) (mask_coords.pkl); masks: the n blend
+ * masks (mask/<i>.png, uint8 [h_i][w_i][3] with h_i = y_e-y_s, w_i = x_e-x_s) concatenated, mask i starting at
+ * byte mask_offsets[i] (n+1 offsets).  Boxes must lie inside the frame.  Host pointers. */
+int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint8_t* full_bank, const int32_t* face_boxes,
+                                 const int32_t* crop_boxes, const uint8_t* masks, const int64_t* mask_offsets, int n,
+                                 int H, int W, int* avatar_id);
+
+typedef struct ltk_mt_req {
+    int avatar;            /* id returned by ltk_musetalk_avatar_register */
+    int index;             /* running frame index (mirror_index over the latent bank) */
+    int batch;
+    const void* d_feat;    /* device, float32 [batch][50][384]: the whisper chunks of WhisperASR (before PE) */
+    void* d_pred;          /* device, uint8 [batch][256][256][3] BGR */
+} ltk_mt_req;
+
+/* avatars/musetalk_avatar.py:130-152 MuseReal.inference_batch for `nreq` sessions at once: latent gather,
+ * positional encoding, U-Net (timestep 0), vae.decode_latents incl. the uint8 rounding and RGB->BGR flip. */
+int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* stream);
+
+/* avatars/musetalk_avatar.py:154-164 paste_back_frame + avatars/musetalk/myutil.py:4-25 get_image_blending:
+ * resize the 256x256 prediction to the face box, paste into the crop region and cv2.blendLinear it with the
+ * cached frame under the avatar's mask.  out: uint8 [H][W][3] (device or host, as ltk_paste_back). */
+int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream);
+
 /* ---- test / measurement hooks (not on the production call path) ---- */
+
+/* U-Net + VAE decoder on explicit inputs: latents host fp32 [B][8][32][32], feat host fp32 [B][50][384] (before
+ * the positional encoding).  Outputs (any may be NULL): unet_out fp32 [B][4][32][32], image fp32 [B][3][256][256]
+ * (AutoencoderKL.decode sample, RGB), frames uint8 [B][256][256][3] BGR. */
+int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* feat, int B, float* unet_out, float* image,
+                              uint8_t* frames);
+/* copy a named intermediate of the last MuseTalk forward as NCHW float32 (first `frames` frames) */
+int ltk_musetalk_debug_get(ltk_engine* e, const char* name, int frames, float* out, size_t n_floats);
+/* average milliseconds of one U-Net + VAE pass over `frames` frames, and its conv/linear MACs */
+int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
+
 
 /* Run Wav2Lip.forward on explicit inputs: mel host float32 [B][80][16], face6
  * host float32 [B][6][256][256] in [0,1] (as wav2lip_avatar.py:133-134 builds

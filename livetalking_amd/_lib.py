@@ -28,6 +28,10 @@ class W2lReq(C.Structure):
                 ("d_pred", C.c_void_p)]
 
 
+class MtReq(C.Structure):
+    _fields_ = [("avatar", C.c_int), ("index", C.c_int), ("batch", C.c_int), ("d_feat", C.c_void_p), ("d_pred", C.c_void_p)]
+
+
 # every symbol include/ltk.h declares: (restype, argtypes)
 SYMBOLS = {
     "ltk_last_error": (C.c_char_p, []),
@@ -42,6 +46,14 @@ SYMBOLS = {
     "ltk_mel_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p]),
     "ltk_paste_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_musetalk_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int, C.POINTER(NamedTensor), C.c_int, C.c_int]),
+    "ltk_musetalk_avatar_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "ltk_musetalk_infer": (C.c_int, [C.c_void_p, C.POINTER(MtReq), C.c_int, C.c_void_p]),
+    "ltk_paste_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_musetalk_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ltk_musetalk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "ltk_musetalk_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "ltk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -54,7 +54,8 @@ struct K3Args {
     int tiles_x, tiles_y, tiles_n, n_ntiles;
     unsigned magicPW, magicPHW;
     int nchunks, ksplit, chunks_per_split;
-    int relu;
+    int relu;                        // activation: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU
+    int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
     int stagger;                     // cycles the second resident block of each CU idles before it starts, so the
                                      // two blocks of a CU run out of phase (one in its MFMA loop while the other
                                      // is in its prologue / epilogue)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 
     // ---- A staging descriptors: item (k, wave) = 64 consecutive 16-byte slots (32 patch pixels) of one channel block
     const int p64n = a.SLOTS >> 6;
-    const int HW16 = a.H * a.W * 16;          // halfs per channel block plane
+    const int HW16 = (a.H >> a.ups) * (a.W >> a.ups) * 16;          // halfs per (source) channel block plane
     int a_goff[MAXA];                         // element offset of this lane's 8 channels (chunk 0), -1 = no copy
     int a_ldst[MAXA];                         // wave-uniform LDS byte offset inside a stage
 #pragma unroll
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
-        a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + cbj) * a.H + iy) * a.W + ix) * 16 + half * 8) : -1;
+        a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) : -1;
         a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
     }
 
@@ -413,7 +414,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float t = v[r];
-                            if (a.relu) t = fmaxf(t, 0.f);
+                            if (a.relu == 1) t = fmaxf(t, 0.f);
+                            else if (a.relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                            else if (a.relu == 3) t = t / (1.f + __expf(-t));
                             t = fminf(fmaxf(t, -65504.f), 65504.f);
                             o[r] = (f16)t;
                         }
@@ -465,7 +468,9 @@ __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restri
     for (int r = 0; r < 8; ++r) {
         float t = v[r] * scale[c0 + r] + shift[c0 + r];
         if (res) t += (float)rr[r];
-        if (relu) t = fmaxf(t, 0.f);
+        if (relu == 1) t = fmaxf(t, 0.f);
+        else if (relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+        else if (relu == 3) t = t / (1.f + __expf(-t));
         t = fminf(fmaxf(t, -65504.f), 65504.f);
         o[r] = (f16)t;
     }
@@ -528,7 +533,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     a.N = io.N; a.H = io.H; a.W = io.W; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
     a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
     int y_ld = io.y_ld;
-    a.relu = io.relu;
+    a.relu = io.relu ? 1 : io.act;
+    a.ups = io.ups ? 1 : 0;
+    if (io.ups && ((io.H | io.W) & 1)) { if (err) *err = "conv3: upsampled input needs even H, W"; return -1; }
     a.Cout = p.lCout; a.CoutP = p.CoutPad;
     int ext;
     if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = 0; ext = 1; }
@@ -624,7 +631,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         const long long items = a.Mtot * (p.lCout >> 3);
         hipLaunchKernelGGL(conv3_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
                            (const float*)io.partial, ksplit, a.Mtot, a.HoA * a.WoA, p.CoutPad, p.lCout, (const float*)p.d_scale,
-                           (const float*)p.d_shift, io.res, a.res_cbt, a.res_cb0, io.y, a.y_cbt, a.y_cb0, io.relu);
+                           (const float*)p.d_shift, io.res, a.res_cbt, a.res_cb0, io.y, a.y_cbt, a.y_cb0, a.relu);
         HIPCHK3(hipGetLastError());
     }
     return 0;

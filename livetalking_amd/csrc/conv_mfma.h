@@ -94,7 +94,10 @@ struct ConvIO {
     const f16* x; int N, H, W; int x_ld, x_coff;
     f16* y; int y_ld, y_coff;
     const f16* res; int res_ld, res_coff;
-    int relu;
+    int relu;                      // 1: ReLU epilogue (shorthand for act == 1)
+    int act = 0;                   // epilogue activation when relu == 0: 0 none, 2 GELU (erf), 3 SiLU
+    int ups = 0;                   // conv3 only: the input map is H/2 x W/2 and is read through a nearest-neighbour
+                                   // 2x upsample (diffusers Upsample2D: F.interpolate(scale_factor=2) then conv)
     float* partial = nullptr;      // split-K scratch (fp32 slabs) and its capacity in bytes; conv3 splits the
     size_t partial_cap = 0;        // channel loop of under-filled launches only when this is large enough
 };

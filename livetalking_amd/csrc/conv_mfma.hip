@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = v[r];
-                    if (a.relu) t = fmaxf(t, 0.f);
+                    if (a.relu == 1) t = fmaxf(t, 0.f);
+                    else if (a.relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                    else if (a.relu == 3) t = t / (1.f + __expf(-t));
                     t = fminf(fmaxf(t, -65504.f), 65504.f);
                     o[r] = (f16)t;
                 }
@@ -624,7 +626,8 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     a.N = io.N; a.H = io.H; a.W = io.W; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
     a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
     a.Cin8 = p.Cin / 8;
-    a.relu = io.relu;
+    a.relu = io.relu ? 1 : io.act;
+    if (io.ups) { if (err) *err = "input upsampling is a conv3 feature (3x3 s1 p1 / 1x1 layers)"; return -1; }
     int y_ld = io.y_ld;
     int kext_y, kext_x;
     if (p.gemm_1x1_expand) {

@@ -22,6 +22,8 @@
 #include "../../include/ltk.h"
 #include "conv_mfma.h"
 #include "misc_kernels.h"
+#include "musetalk.h"
+#include "nn_kernels.h"
 
 using namespace ltk;
 
@@ -139,6 +141,16 @@ struct Scratch {
     size_t cap = 0;
 };
 
+// MuseTalk avatar bank (musetalk_avatar.py:69-91)
+struct MtAvatar {
+    float* d_latents = nullptr;      // [n][8][32][32]
+    uint8_t* d_full = nullptr;       // [n][H][W][3]
+    uint8_t* d_masks = nullptr;      // concatenated
+    std::vector<int64_t> mask_off;
+    std::vector<int32_t> face_box, crop_box;
+    int n = 0, H = 0, W = 0;
+};
+
 }  // namespace
 
 struct ltk_engine {
@@ -170,6 +182,13 @@ struct ltk_engine {
     // mel
     float* d_basis = nullptr;
     int32_t* d_lohi = nullptr;
+    // musetalk
+    MtGraph* mt = nullptr;
+    int mt_max_frames = 0;
+    float* d_pe = nullptr;                // PositionalEncoding table [50][384]
+    float* d_mt_feat = nullptr;           // staging: fp32 [max_frames][50][384]
+    float* d_mt_lat = nullptr;            // staging for the host-input hook: fp32 [max_frames][8][32][32]
+    std::map<int, MtAvatar> mt_avatars;
     // pools
     std::vector<Scratch> scratch_free;
     std::vector<hipStream_t> stream_free;
@@ -562,6 +581,11 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_basis) (void)hipFree(e->d_basis);
     if (e->d_lohi) (void)hipFree(e->d_lohi);
     for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
+    for (auto& kv : e->mt_avatars) { (void)hipFree(kv.second.d_latents); (void)hipFree(kv.second.d_full); (void)hipFree(kv.second.d_masks); }
+    if (e->mt) mt_graph_delete(e->mt);
+    if (e->d_pe) (void)hipFree(e->d_pe);
+    if (e->d_mt_feat) (void)hipFree(e->d_mt_feat);
+    if (e->d_mt_lat) (void)hipFree(e->d_mt_lat);
     for (Scratch& s : e->scratch_free) (void)hipFree(s.d);
     for (hipStream_t s : e->stream_free) (void)hipStreamDestroy(s);
     if (e->d_partial) (void)hipFree(e->d_partial);
@@ -874,6 +898,268 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
     conv_plan_destroy(&plan);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
     if (he != hipSuccess) return fail(LTK_E_HIP, std::string("conv kernel: ") + hipGetErrorString(he));
+    return LTK_OK;
+}
+
+// ================================================================================ MuseTalk
+int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae,
+                      int max_frames) {
+    if (!e || !unet_sd || !vae_sd || n_unet <= 0 || n_vae <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (max_frames < 1 || max_frames > 64) return fail(LTK_E_INVALID, "max_frames must be in [1, 64] for MuseTalk");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->mt) return fail(LTK_E_STATE, "a MuseTalk model is already loaded in this engine");
+    CHK(hipSetDevice(e->device));
+    MtGraph* mg = mt_graph_new();
+    const int rc = mt_build(mg, unet_sd, n_unet, vae_sd, n_vae, max_frames);
+    if (rc) {
+        const std::string msg = mt_graph_error(mg);
+        mt_graph_delete(mg);
+        return fail(rc == -4 ? LTK_E_NOMEM : LTK_E_INVALID, "musetalk: " + msg);
+    }
+    // avatars/musetalk/models/unet.py:12-27 PositionalEncoding(d_model=384), first 50 positions
+    std::vector<float> pe(50 * 384);
+    for (int pos = 0; pos < 50; ++pos)
+        for (int i = 0; i < 384; i += 2) {
+            const float div = expf((float)i * (-logf(10000.0f) / 384.0f));
+            pe[pos * 384 + i] = sinf((float)pos * div);
+            pe[pos * 384 + i + 1] = cosf((float)pos * div);
+        }
+    CHK(hipMalloc((void**)&e->d_pe, pe.size() * sizeof(float)));
+    CHK(hipMemcpy(e->d_pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    CHK(hipMalloc((void**)&e->d_mt_feat, (size_t)max_frames * 50 * 384 * sizeof(float)));
+    CHK(hipMalloc((void**)&e->d_mt_lat, (size_t)max_frames * 8 * 1024 * sizeof(float)));
+    e->mt = mg;
+    e->mt_max_frames = max_frames;
+    return LTK_OK;
+}
+
+int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint8_t* full_bank, const int32_t* face_boxes,
+                                 const int32_t* crop_boxes, const uint8_t* masks, const int64_t* mask_offsets, int n, int H,
+                                 int W, int* avatar_id) {
+    if (!e || !latents || !full_bank || !face_boxes || !crop_boxes || !masks || !mask_offsets || !avatar_id || n <= 0 || H <= 0 || W <= 0)
+        return fail(LTK_E_INVALID, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+        const int32_t* f = face_boxes + 4 * i;   // (x1,y1,x2,y2), musetalk_avatar.py:157
+        const int32_t* c = crop_boxes + 4 * i;   // (x_s,y_s,x_e,y_e), myutil.py:7
+        if (c[0] < 0 || c[1] < 0 || c[2] > W || c[3] > H || c[2] <= c[0] || c[3] <= c[1])
+            return fail(LTK_E_INVALID, "crop box outside the frame (the reference's slicing is undefined there)");
+        if (f[0] < c[0] || f[1] < c[1] || f[2] > c[2] || f[3] > c[3] || f[2] <= f[0] || f[3] <= f[1])
+            return fail(LTK_E_INVALID, "face box must lie inside its crop box");
+        if (mask_offsets[i + 1] - mask_offsets[i] != (int64_t)(c[3] - c[1]) * (c[2] - c[0]) * 3)
+            return fail(LTK_E_INVALID, "mask size does not match its crop box");
+    }
+    CHK(hipSetDevice(e->device));
+    MtAvatar a;
+    a.n = n; a.H = H; a.W = W;
+    a.face_box.assign(face_boxes, face_boxes + 4 * (size_t)n);
+    a.crop_box.assign(crop_boxes, crop_boxes + 4 * (size_t)n);
+    a.mask_off.assign(mask_offsets, mask_offsets + n + 1);
+    const size_t lb = (size_t)n * 8 * 1024 * sizeof(float), ub = (size_t)n * H * W * 3, mb = (size_t)mask_offsets[n];
+    CHK(hipMalloc((void**)&a.d_latents, lb));
+    CHK(hipMalloc((void**)&a.d_full, ub));
+    CHK(hipMalloc((void**)&a.d_masks, mb));
+    CHK(hipMemcpy(a.d_latents, latents, lb, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(a.d_full, full_bank, ub, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(a.d_masks, masks, mb, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> g(e->pool_mu);
+    const int id = e->next_avatar++;
+    e->mt_avatars[id] = a;
+    *avatar_id = id;
+    return LTK_OK;
+}
+
+// latents already gathered into the graph's latent tensor; d_feat = fp32 [nf][50][384] on the device
+static int mt_run_locked(ltk_engine* e, const float* d_feat, int nf, const OutList64* outs, float* d_image_f32) {
+    hipStream_t s = e->compute;
+    int cbt;
+    f16* ctx = mt_ctx_in(e->mt, &cbt);
+    launch_tokens_to_cb16(d_feat, nf, 50, 384, e->d_pe, ctx, cbt, 0, s);
+    const int rc = mt_run(e->mt, nf, e->d_partial, e->partial_cap, s);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    if (outs || d_image_f32) {
+        OutList64 none;
+        for (int i = 0; i < 64; ++i) none.p[i] = nullptr;
+        f16* img = mt_vae_out(e->mt, &cbt);
+        launch_vae_post(img, cbt, nf, 65536, outs ? *outs : none, d_image_f32, s);
+    }
+    CHK(hipGetLastError());
+    return 0;
+}
+
+int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* stream) {
+    if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    CHK(hipSetDevice(e->device));
+    std::vector<const float*> lptr, fptr;
+    std::vector<uint8_t*> optr;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        for (int r = 0; r < nreq; ++r) {
+            auto it = e->mt_avatars.find(reqs[r].avatar);
+            if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
+            if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_feat || !reqs[r].d_pred) return fail(LTK_E_INVALID, "bad request");
+            const MtAvatar& a = it->second;
+            for (int i = 0; i < reqs[r].batch; ++i) {
+                const int idx = mirror_index(a.n, reqs[r].index + i);   // musetalk_avatar.py:137-139
+                lptr.push_back(a.d_latents + (size_t)idx * 8 * 1024);
+                fptr.push_back((const float*)reqs[r].d_feat + (size_t)i * 50 * 384);
+                optr.push_back((uint8_t*)reqs[r].d_pred + (size_t)i * 65536 * 3);
+            }
+        }
+    }
+    const int total = (int)lptr.size();
+    hipEvent_t done;
+    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (stream) {
+            hipEvent_t ready;
+            CHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            CHK(hipEventRecord(ready, (hipStream_t)stream));
+            CHK(hipStreamWaitEvent(e->compute, ready, 0));
+            CHK(hipEventDestroy(ready));
+        }
+        for (int f0 = 0; f0 < total && !rc; f0 += e->mt_max_frames) {
+            const int nf = std::min(e->mt_max_frames, total - f0);
+            PtrList64 lp;
+            OutList64 op;
+            for (int i = 0; i < 64; ++i) { lp.p[i] = nullptr; op.p[i] = nullptr; }
+            for (int i = 0; i < nf; ++i) {
+                lp.p[i] = lptr[f0 + i];
+                op.p[i] = optr[f0 + i];
+                // the feature rows of one request are contiguous, but requests are not: gather into the staging buffer
+                if (hipMemcpyAsync(e->d_mt_feat + (size_t)i * 50 * 384, fptr[f0 + i], 50 * 384 * sizeof(float), hipMemcpyDeviceToDevice,
+                                   e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "feature gather failed");
+            }
+            if (rc) break;
+            int cbt;
+            f16* lat = mt_latent_in(e->mt, &cbt);
+            launch_gather_latents(lp, nf, 8, 1024, lat, cbt, e->compute);
+            rc = mt_run_locked(e, e->d_mt_feat, nf, &op, nullptr);
+        }
+        if (!rc && hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
+    }
+    if (!rc) {
+        if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
+        if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+    }
+    (void)hipEventDestroy(done);
+    return rc;
+}
+
+int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream) {
+    if (!e || !d_pred || !out) return fail(LTK_E_INVALID, "bad arguments");
+    const uint8_t *full, *mask;
+    int H, W;
+    int32_t fb[4], cb[4];
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        auto it = e->mt_avatars.find(avatar_id);
+        if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
+        const MtAvatar& a = it->second;
+        if (idx < 0 || idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
+        H = a.H; W = a.W;
+        full = a.d_full + (size_t)idx * H * W * 3;
+        mask = a.d_masks + a.mask_off[idx];
+        for (int k = 0; k < 4; ++k) { fb[k] = a.face_box[4 * idx + k]; cb[k] = a.crop_box[4 * idx + k]; }
+    }
+    CHK(hipSetDevice(e->device));
+    const size_t bytes = (size_t)H * W * 3;
+    StreamLease sl(e, stream);
+    if (out_is_device) {
+        launch_paste_blend(full, H, W, (const uint8_t*)d_pred, fb[0], fb[1], fb[2], fb[3], cb[0], cb[1], cb[2], cb[3], mask, (uint8_t*)out, sl.s);
+        CHK(hipGetLastError());
+        CHK(hipStreamSynchronize(sl.s));
+        return LTK_OK;
+    }
+    ScratchLease sc(e, bytes);
+    if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
+    launch_paste_blend(full, H, W, (const uint8_t*)d_pred, fb[0], fb[1], fb[2], fb[3], cb[0], cb[1], cb[2], cb[3], mask, (uint8_t*)sc.s.d, sl.s);
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(out, sc.s.d, bytes, hipMemcpyDeviceToHost, sl.s));
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
+int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* feat, int B, float* unet_out, float* image,
+                              uint8_t* frames) {
+    if (!e || !latents || !feat || B <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    if (B > e->mt_max_frames) return fail(LTK_E_INVALID, "B exceeds max_frames");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = e->compute;
+    CHK(hipMemcpyAsync(e->d_mt_lat, latents, (size_t)B * 8 * 1024 * sizeof(float), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(e->d_mt_feat, feat, (size_t)B * 50 * 384 * sizeof(float), hipMemcpyHostToDevice, s));
+    int cbt;
+    f16* lat = mt_latent_in(e->mt, &cbt);
+    launch_nchw_to_cb16(e->d_mt_lat, B, 8, 1024, lat, cbt, 0, s);
+    float* d_img = nullptr;
+    uint8_t* d_frames = nullptr;
+    if (image) CHK(hipMalloc((void**)&d_img, (size_t)B * 3 * 65536 * sizeof(float)));
+    if (frames) CHK(hipMalloc((void**)&d_frames, (size_t)B * 65536 * 3));
+    OutList64 op;
+    for (int i = 0; i < 64; ++i) op.p[i] = (frames && i < B) ? d_frames + (size_t)i * 65536 * 3 : nullptr;
+    int rc = mt_run_locked(e, e->d_mt_feat, B, &op, d_img);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(LTK_E_HIP, "stream sync failed");
+    if (!rc && unet_out) {
+        int C, ld, coff, H, W;
+        f16* t = mt_named(e->mt, "conv_out", &C, &ld, &coff, &H, &W);
+        float* d_tmp = nullptr;
+        CHK(hipMalloc((void**)&d_tmp, (size_t)B * 4 * 1024 * sizeof(float)));
+        launch_nhwc_to_nchw_f32(t, B, H, W, ld, coff, 4, d_tmp, s);
+        CHK(hipStreamSynchronize(s));
+        CHK(hipMemcpy(unet_out, d_tmp, (size_t)B * 4 * 1024 * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(d_tmp);
+    }
+    if (!rc && image) CHK(hipMemcpy(image, d_img, (size_t)B * 3 * 65536 * sizeof(float), hipMemcpyDeviceToHost));
+    if (!rc && frames) CHK(hipMemcpy(frames, d_frames, (size_t)B * 65536 * 3, hipMemcpyDeviceToHost));
+    if (d_img) (void)hipFree(d_img);
+    if (d_frames) (void)hipFree(d_frames);
+    return rc;
+}
+
+int ltk_musetalk_debug_get(ltk_engine* e, const char* name, int frames, float* out, size_t n_floats) {
+    if (!e || !name || !out || frames <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    int C, ld, coff, H, W;
+    f16* t = mt_named(e->mt, name, &C, &ld, &coff, &H, &W);
+    if (!t) return fail(LTK_E_STATE, std::string("no MuseTalk tensor named ") + name);
+    const size_t cnt = (size_t)frames * C * H * W;
+    if (cnt != n_floats) return fail(LTK_E_INVALID, "size mismatch: tensor has " + std::to_string(cnt) + " floats for these frames");
+    float* d_tmp = nullptr;
+    CHK(hipMalloc((void**)&d_tmp, cnt * sizeof(float)));
+    launch_nhwc_to_nchw_f32(t, frames, H, W, ld, coff, C, d_tmp, e->compute);
+    CHK(hipStreamSynchronize(e->compute));
+    CHK(hipMemcpy(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_tmp);
+    return LTK_OK;
+}
+
+int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass) {
+    if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    if (frames > e->mt_max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    hipEvent_t t0, t1;
+    CHK(hipEventCreate(&t0));
+    CHK(hipEventCreate(&t1));
+    int rc = mt_run(e->mt, frames, e->d_partial, e->partial_cap, e->compute);
+    if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    CHK(hipEventRecord(t0, e->compute));
+    for (int i = 0; i < iters && !rc; ++i) rc = mt_run(e->mt, frames, e->d_partial, e->partial_cap, e->compute);
+    if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    CHK(hipEventRecord(t1, e->compute));
+    CHK(hipEventSynchronize(t1));
+    float ms = 0.f;
+    CHK(hipEventElapsedTime(&ms, t0, t1));
+    *ms_per_pass = ms / iters;
+    if (macs_per_pass) *macs_per_pass = mt_macs_per_frame(e->mt) * frames;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     return LTK_OK;
 }
 

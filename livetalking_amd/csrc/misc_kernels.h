@@ -52,4 +52,8 @@ void launch_mel(const float* pcm, int n_samples, const int32_t* win_start, int n
 void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
                   uint8_t* out, hipStream_t s);
 
+// musetalk_avatar.py:154-164 paste_back_frame (resize + paste into the crop + cv2.blendLinear under the mask).
+void launch_paste_blend(const uint8_t* full, int H, int W, const uint8_t* pred256, int x1, int y1, int x2, int y2, int xs, int ys,
+                        int xe, int ye, const uint8_t* mask, uint8_t* out, hipStream_t s);
+
 }  // namespace ltk

@@ -274,6 +274,72 @@ __global__ __launch_bounds__(256) void paste_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// MuseTalk paste-back: avatars/musetalk_avatar.py:154-164 + avatars/musetalk/myutil.py:4-25.
+// face_large = body[crop].copy(); face_large[face box] = cv2.resize(pred, box); mask = gray(mask)/255 (the mask
+// PNG has B=G=R, so gray == channel); body[crop] = cv2.blendLinear(face_large, body[crop], mask, 1-mask), i.e.
+// dst = saturate_cast<uchar>((s1*w1 + s2*w2) / (w1 + w2 + 1e-5f)) in float32 with round-half-even.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned resized_pred(const uint8_t* __restrict__ pred, int dy, int dx, int dh, int dw, int c) {
+    if (dw == 256 && dh == 256) return pred[(dy * 256 + dx) * 3 + c];
+    if (dw == 128 && dh == 128) {
+        const uint8_t* p = pred + ((2 * dy) * 256 + 2 * dx) * 3 + c;
+        return (p[0] + p[3] + p[768] + p[771] + 2) >> 2;
+    }
+    const AxisTap tx = axis_tap(dx, dw, 256, true);
+    const AxisTap ty = axis_tap(dy, dh, 256, false);
+    const uint8_t* r0 = pred + (size_t)ty.s0 * 768 + c;
+    const uint8_t* r1 = pred + (size_t)ty.s1 * 768 + c;
+    const int S0 = r0[tx.s0 * 3] * tx.a0 + r0[tx.s1 * 3] * tx.a1;
+    const int S1 = r1[tx.s0 * 3] * tx.a0 + r1[tx.s1 * 3] * tx.a1;
+    const int o = (((ty.a0 * (S0 >> 4)) >> 16) + ((ty.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    return (unsigned)min(max(o, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void paste_blend_kernel(const uint8_t* __restrict__ full, int H, int W,
+                                                           const uint8_t* __restrict__ pred, int x1, int y1, int x2, int y2,
+                                                           int xs, int ys, int xe, int ye, const uint8_t* __restrict__ mask,
+                                                           uint8_t* __restrict__ out) {
+    const size_t total = (size_t)H * W * 3;
+    const size_t b0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (b0 >= total) return;
+    const int dh = y2 - y1, dw = x2 - x1, mw = xe - xs;
+    const int rowbytes = W * 3;
+    unsigned word = 0;
+    const int nb = (int)min((size_t)4, total - b0);
+    for (int k = 0; k < nb; ++k) {
+        const size_t bi = b0 + k;
+        const int y = (int)(bi / rowbytes);
+        const int rb = (int)(bi - (size_t)y * rowbytes);
+        const int x = rb / 3, c = rb - x * 3;
+        unsigned v = full[bi];
+        if (y >= ys && y < ye && x >= xs && x < xe) {
+            unsigned fl = v;
+            if (y >= y1 && y < y2 && x >= x1 && x < x2) fl = resized_pred(pred, y - y1, x - x1, dh, dw, c);
+            const float w1 = (float)((double)mask[((size_t)(y - ys) * mw + (x - xs)) * 3] / 255.0);
+            const float w2 = __fsub_rn(1.0f, w1);
+            const float den = __fadd_rn(__fadd_rn(w1, w2), 1e-5f);
+            const float num = __fadd_rn(__fmul_rn((float)fl, w1), __fmul_rn((float)v, w2));
+            const float q = __fdiv_rn(num, den);
+            v = (unsigned)min(max((int)rintf(q), 0), 255);
+        }
+        word |= v << (8 * k);
+    }
+    if (nb == 4) {
+        *reinterpret_cast<unsigned*>(out + b0) = word;
+    } else {
+        for (int k = 0; k < nb; ++k) out[b0 + k] = (uint8_t)(word >> (8 * k));
+    }
+}
+
+void launch_paste_blend(const uint8_t* full, int H, int W, const uint8_t* pred256, int x1, int y1, int x2, int y2, int xs, int ys,
+                        int xe, int ye, const uint8_t* mask, uint8_t* out, hipStream_t s) {
+    const size_t total = (size_t)H * W * 3;
+    const size_t words = (total + 3) / 4;
+    hipLaunchKernelGGL(paste_blend_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, full, H, W, pred256, x1, y1, x2, y2,
+                       xs, ys, xe, ye, mask, out);
+}
+
 void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
                   uint8_t* out, hipStream_t s) {
     const size_t total = (size_t)H * W * 3;

@@ -1,0 +1,30 @@
+// MuseTalk device program (musetalk.hip): graph construction from diffusers-named state dicts and execution.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/ltk.h"
+#include "conv_mfma.h"
+
+namespace ltk {
+
+struct MtGraph;
+struct MtTensor;
+
+MtGraph* mt_graph_new();
+void mt_graph_delete(MtGraph* g);
+const char* mt_graph_error(const MtGraph* g);
+// builds U-Net then VAE decoder; returns 0 or a negative code
+int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames);
+// tensors the engine feeds / reads
+f16* mt_latent_in(MtGraph* g, int* cbt);       // [N][1][1024][16] (8 real channels)
+f16* mt_ctx_in(MtGraph* g, int* cbt);          // [N][24][50][16]
+f16* mt_unet_out(MtGraph* g, int* cbt);        // [N][1][1024][16] (4 real channels)
+f16* mt_vae_out(MtGraph* g, int* cbt);         // [N][1][65536][16] (3 real channels, RGB)
+int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s);
+// named intermediate (debug / parity): returns device pointer + geometry, or null
+f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, int* W);
+double mt_macs_per_frame(const MtGraph* g);
+
+}  // namespace ltk

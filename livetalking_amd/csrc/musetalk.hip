@@ -1,0 +1,649 @@
+// MuseTalk per-frame generator on the HIP engine: conditional U-Net + VAE decoder as a static launch program.
+//
+// Reference call sites: avatars/musetalk_avatar.py:130-152 (MuseReal.inference_batch),
+// avatars/musetalk/models/unet.py:12-46 (PositionalEncoding, diffusers UNet2DConditionModel),
+// avatars/musetalk/models/vae.py:96-108 (decode_latents).  The diffusers graph itself is restated in
+// oracle/musetalk_oracle.py (the checker); this file is its device program: every conv / linear is one launch of
+// the MFMA conv kernels (conv3_mfma.hip / conv_mfma.hip: a Linear over channels is a 1x1 conv on the token map),
+// GroupNorm / LayerNorm / attention / GEGLU are nn_kernels.hip.  Load-time folding:
+//   * the timestep is the constant 0 (musetalk_avatar.py:61,148-150): time_embedding and every resnet's
+//     time_emb_proj collapse into the bias of that resnet's conv1;
+//   * the attention scale d^-0.5 goes into to_q; heads of 40 channels are padded to 48 (three channel blocks)
+//     by permuting to_q/to_k/to_v rows and to_out columns;
+//   * 1/scaling_factor (vae.py:103) goes into post_quant_conv;
+//   * torch.cat([h, skip]) of the up path is a channel-block range of one buffer.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ltk.h"
+#include "conv_mfma.h"
+#include "musetalk.h"
+#include "nn_kernels.h"
+
+namespace ltk {
+
+namespace {
+
+struct SD {
+    const ltk_named_tensor* t;
+    int n;
+    std::string err;
+    const float* get(const std::string& name, size_t expect) {
+        for (int i = 0; i < n; ++i)
+            if (name == t[i].name) {
+                size_t cnt = 1;
+                for (int d = 0; d < t[i].ndim; ++d) cnt *= (size_t)t[i].shape[d];
+                if (cnt != expect) { err = "tensor " + name + " has " + std::to_string(cnt) + " elements, expected " + std::to_string(expect); return nullptr; }
+                return t[i].data;
+            }
+        err = "state_dict is missing " + name;
+        return nullptr;
+    }
+    bool has(const std::string& name) const {
+        for (int i = 0; i < n; ++i) if (name == t[i].name) return true;
+        return false;
+    }
+};
+
+int up16(int c) { return (c + 15) / 16 * 16; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ graph
+struct MtTensor {
+    int buf = -1;
+    int C = 0;        // channels of this view (multiple of 16)
+    int ld = 0;       // channels of the underlying buffer
+    int coff = 0;     // first channel of the view
+    int H = 1, W = 1;
+    int P() const { return H * W; }
+};
+
+enum MtOpType { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU };
+
+struct MtOp {
+    MtOpType type;
+    std::string name;
+    MtTensor x, y, r, k, v;     // r: residual; attention: x = q, k, v
+    int plan = -1;
+    int act = 0, ups = 0;
+    int gamma = -1, beta = -1;  // indices into MtGraph::vecs
+    int groups = 32, silu = 0;
+    float eps = 1e-5f;
+    int heads = 1, d16 = 0;
+    int Tk = 0;
+};
+
+struct MtGraph {
+    std::vector<size_t> buf_halfs;           // per frame
+    std::vector<f16*> bufs;
+    std::vector<ConvPlan> plans;
+    std::vector<float*> vecs;                // device fp32 vectors (norm affine)
+    std::vector<MtOp> ops;
+    std::map<std::string, MtTensor> named;
+    float* gn_partial = nullptr;
+    size_t gn_partial_floats = 0;
+    f16* vt = nullptr;                        // transposed values scratch
+    size_t vt_halfs = 0;                      // per frame
+    int frames = 0;
+    double macs = 0;                          // conv / linear MACs per frame (attention excluded)
+    std::string err;
+    MtTensor *t_latent = nullptr, *t_ctx = nullptr, *t_unet_out = nullptr, *t_vae_out = nullptr;
+
+    MtTensor alloc(int C, int H, int W) {
+        MtTensor t;
+        t.buf = (int)buf_halfs.size();
+        t.C = up16(C); t.ld = t.C; t.coff = 0; t.H = H; t.W = W;
+        buf_halfs.push_back((size_t)t.C * H * W);
+        return t;
+    }
+    static MtTensor view(const MtTensor& b, int coff, int C) {
+        MtTensor t = b;
+        t.coff = b.coff + coff; t.C = C;
+        return t;
+    }
+    int add_vec(const float* host, int n, int pad_to = 0) {
+        const int m = std::max(n, pad_to);
+        std::vector<float> tmp(m, 0.f);
+        memcpy(tmp.data(), host, n * sizeof(float));
+        float* d = nullptr;
+        if (hipMalloc((void**)&d, m * sizeof(float)) != hipSuccess) { err = "hipMalloc failed"; return -1; }
+        (void)hipMemcpy(d, tmp.data(), m * sizeof(float), hipMemcpyHostToDevice);
+        vecs.push_back(d);
+        return (int)vecs.size() - 1;
+    }
+    // conv / linear: weight [Cout][Cin][k][k] fp32 host, bias [Cout] or null
+    int add_conv(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int k, int stride, int pad,
+                 const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
+        const int CoutP = up16(Cout);
+        const int CinR = Cin;
+        Cin = up16(Cin);                    // whole channel blocks on both sides (zero weights for the padding)
+        std::vector<float> wp;
+        const float* wuse = w;
+        if (CoutP != Cout || Cin != CinR) {
+            wp.assign((size_t)CoutP * Cin * k * k, 0.f);
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < CinR; ++ci)
+                    memcpy(&wp[((size_t)co * Cin + ci) * k * k], &w[((size_t)co * CinR + ci) * k * k], (size_t)k * k * sizeof(float));
+            wuse = wp.data();
+        }
+        macs += (double)CinR * Cout * k * k * (stride == 2 ? y.P() : (ups ? x.P() : y.P()));
+        std::vector<float> sc(CoutP, 1.f), sf(CoutP, 0.f);
+        if (bias) memcpy(sf.data(), bias, Cout * sizeof(float));
+        ConvPlan p;
+        std::string e;
+        int rc = conv_plan_create(&p, wuse, Cin, CoutP, k, k, stride, stride, pad, pad, false, 0, sc.data(), sf.data(), &e, x.P());
+        if (rc) { err = name + ": " + e; return -1; }
+        plans.push_back(p);
+        MtOp op;
+        op.type = OP_CONV; op.name = name; op.x = x; op.y = y; op.plan = (int)plans.size() - 1; op.act = act; op.ups = ups;
+        if (res) op.r = *res;
+        if (up16(Cin) != x.C || CoutP != y.C) { err = name + ": channel mismatch (" + std::to_string(Cin) + "->" + std::to_string(Cout) + ")"; return -1; }
+        ops.push_back(op);
+        named[name] = y;
+        return 0;
+    }
+    int add_gn(const std::string& name, SD& sd, const std::string& prefix, const MtTensor& x, const MtTensor& y, float eps, int silu) {
+        const float* g = sd.get(prefix + ".weight", x.C);
+        const float* b = sd.get(prefix + ".bias", x.C);
+        if (!g || !b) { err = sd.err; return -1; }
+        MtOp op;
+        op.type = OP_GN; op.name = name; op.x = x; op.y = y; op.eps = eps; op.silu = silu; op.groups = 32;
+        op.gamma = add_vec(g, x.C); op.beta = add_vec(b, x.C);
+        ops.push_back(op);
+        named[name] = y;
+        return 0;
+    }
+    int add_ln(const std::string& name, SD& sd, const std::string& prefix, const MtTensor& x, const MtTensor& y, float eps) {
+        const float* g = sd.get(prefix + ".weight", x.C);
+        const float* b = sd.get(prefix + ".bias", x.C);
+        if (!g || !b) { err = sd.err; return -1; }
+        MtOp op;
+        op.type = OP_LN; op.name = name; op.x = x; op.y = y; op.eps = eps;
+        op.gamma = add_vec(g, x.C); op.beta = add_vec(b, x.C);
+        ops.push_back(op);
+        named[name] = y;
+        return 0;
+    }
+    void add_attn(const std::string& name, const MtTensor& q, const MtTensor& k, const MtTensor& v, const MtTensor& o, int heads, int d16) {
+        MtOp op;
+        op.type = OP_ATTN; op.name = name; op.x = q; op.k = k; op.v = v; op.y = o; op.heads = heads; op.d16 = d16; op.Tk = k.P();
+        vt_halfs = std::max(vt_halfs, (size_t)heads * attn_dv32(d16) * attn_tkp(k.P()));
+        ops.push_back(op);
+        named[name + ".attn"] = o;
+    }
+    void add_geglu(const std::string& name, const MtTensor& x, const MtTensor& y) {
+        MtOp op;
+        op.type = OP_GEGLU; op.name = name; op.x = x; op.y = y;
+        ops.push_back(op);
+        named[name] = y;
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ weight transforms
+// Linear [Cout][Cin] whose OUTPUT channels are per-head slices of d channels -> heads padded to d16 (zero rows)
+std::vector<float> pad_heads_rows(const float* w, int C, int Cin, int heads, int d, int d16, float scale) {
+    std::vector<float> o((size_t)heads * d16 * Cin, 0.f);
+    for (int h = 0; h < heads; ++h)
+        for (int j = 0; j < d; ++j) {
+            const float* src = w + (size_t)(h * d + j) * Cin;
+            float* dst = o.data() + (size_t)(h * d16 + j) * Cin;
+            for (int i = 0; i < Cin; ++i) dst[i] = src[i] * scale;
+        }
+    (void)C;
+    return o;
+}
+std::vector<float> pad_heads_vec(const float* b, int heads, int d, int d16, float scale) {
+    std::vector<float> o((size_t)heads * d16, 0.f);
+    if (b)
+        for (int h = 0; h < heads; ++h)
+            for (int j = 0; j < d; ++j) o[h * d16 + j] = b[h * d + j] * scale;
+    return o;
+}
+// Linear [Cout][C] whose INPUT channels are per-head slices -> padded input columns
+std::vector<float> pad_heads_cols(const float* w, int Cout, int heads, int d, int d16) {
+    std::vector<float> o((size_t)Cout * heads * d16, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int h = 0; h < heads; ++h)
+            for (int j = 0; j < d; ++j) o[(size_t)co * heads * d16 + h * d16 + j] = w[(size_t)co * heads * d + h * d + j];
+    return o;
+}
+
+float silu_h(float v) { return v / (1.f + expf(-v)); }
+
+// UNet2DConditionModel time_proj(flip_sin_to_cos=True, freq_shift=0) + time_embedding at timestep t, then SiLU
+// (what every ResnetBlock2D feeds its time_emb_proj): fp32 [1280]
+int time_embedding_silu(SD& sd, float t, std::vector<float>* out) {
+    const int dim = 320, td = 1280;
+    const float* w1 = sd.get("time_embedding.linear_1.weight", (size_t)td * dim);
+    const float* b1 = sd.get("time_embedding.linear_1.bias", td);
+    const float* w2 = sd.get("time_embedding.linear_2.weight", (size_t)td * td);
+    const float* b2 = sd.get("time_embedding.linear_2.bias", td);
+    if (!w1 || !b1 || !w2 || !b2) return -1;
+    std::vector<float> emb(dim);
+    const int half = dim / 2;
+    for (int i = 0; i < half; ++i) {
+        const float f = expf(-logf(10000.f) * (float)i / (float)half);
+        emb[i] = cosf(t * f);            // flip_sin_to_cos: cos first
+        emb[half + i] = sinf(t * f);
+    }
+    std::vector<float> h1(td), h2(td);
+    for (int o = 0; o < td; ++o) {
+        double a = b1[o];
+        for (int i = 0; i < dim; ++i) a += (double)w1[(size_t)o * dim + i] * emb[i];
+        h1[o] = silu_h((float)a);
+    }
+    for (int o = 0; o < td; ++o) {
+        double a = b2[o];
+        for (int i = 0; i < td; ++i) a += (double)w2[(size_t)o * td + i] * h1[i];
+        h2[o] = silu_h((float)a);
+    }
+    *out = h2;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ blocks
+// diffusers ResnetBlock2D; temb_silu (or null) is folded into conv1's bias
+int build_resnet(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& out, int Cin, int Cout,
+                 const std::vector<float>* temb_silu, float eps) {
+    const int H = x.H, W = x.W;
+    MtTensor t1 = g.alloc(Cin, H, W);
+    if (g.add_gn(p + ".norm1", sd, p + ".norm1", x, t1, eps, 1)) return -1;
+    const float* w1 = sd.get(p + ".conv1.weight", (size_t)Cout * Cin * 9);
+    const float* b1 = sd.get(p + ".conv1.bias", Cout);
+    if (!w1 || !b1) { g.err = sd.err; return -1; }
+    std::vector<float> bias1(b1, b1 + Cout);
+    if (temb_silu) {
+        const int td = (int)temb_silu->size();
+        const float* wt = sd.get(p + ".time_emb_proj.weight", (size_t)Cout * td);
+        const float* bt = sd.get(p + ".time_emb_proj.bias", Cout);
+        if (!wt || !bt) { g.err = sd.err; return -1; }
+        for (int o = 0; o < Cout; ++o) {
+            double a = bt[o];
+            for (int i = 0; i < td; ++i) a += (double)wt[(size_t)o * td + i] * (*temb_silu)[i];
+            bias1[o] += (float)a;
+        }
+    }
+    MtTensor h = g.alloc(Cout, H, W);
+    if (g.add_conv(p + ".conv1", w1, bias1.data(), Cin, Cout, 3, 1, 1, t1, h, nullptr, 0, 0)) return -1;
+    MtTensor t2 = g.alloc(Cout, H, W);
+    if (g.add_gn(p + ".norm2", sd, p + ".norm2", h, t2, eps, 1)) return -1;
+    MtTensor skip = x;
+    if (sd.has(p + ".conv_shortcut.weight")) {
+        const float* ws = sd.get(p + ".conv_shortcut.weight", (size_t)Cout * Cin);
+        const float* bs = sd.get(p + ".conv_shortcut.bias", Cout);
+        if (!ws || !bs) { g.err = sd.err; return -1; }
+        skip = g.alloc(Cout, H, W);
+        if (g.add_conv(p + ".conv_shortcut", ws, bs, Cin, Cout, 1, 1, 0, x, skip, nullptr, 0, 0)) return -1;
+    } else if (Cin != Cout) {
+        g.err = p + ": missing conv_shortcut"; return -1;
+    }
+    const float* w2 = sd.get(p + ".conv2.weight", (size_t)Cout * Cout * 9);
+    const float* b2 = sd.get(p + ".conv2.bias", Cout);
+    if (!w2 || !b2) { g.err = sd.err; return -1; }
+    return g.add_conv(p + ".conv2", w2, b2, Cout, Cout, 3, 1, 1, t2, out, &skip, 0, 0);
+}
+
+// diffusers Attention (to_q / to_k / to_v / to_out.0), q from x (C channels), k/v from ctx (Cctx channels);
+// out = to_out(attn) + res
+int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& ctx, int C, int Cctx, int heads,
+                    bool qkv_bias, const MtTensor& res, const MtTensor& out) {
+    const int d = C / heads, d16 = up16(d), Cp = heads * d16;
+    const float scale = 1.0f / sqrtf((float)d);
+    const float* wq = sd.get(p + ".to_q.weight", (size_t)C * C);
+    const float* wk = sd.get(p + ".to_k.weight", (size_t)C * Cctx);
+    const float* wv = sd.get(p + ".to_v.weight", (size_t)C * Cctx);
+    const float* wo = sd.get(p + ".to_out.0.weight", (size_t)C * C);
+    const float* bo = sd.get(p + ".to_out.0.bias", C);
+    if (!wq || !wk || !wv || !wo || !bo) { g.err = sd.err; return -1; }
+    const float *bq = nullptr, *bk = nullptr, *bv = nullptr;
+    if (qkv_bias) {
+        bq = sd.get(p + ".to_q.bias", C); bk = sd.get(p + ".to_k.bias", C); bv = sd.get(p + ".to_v.bias", C);
+        if (!bq || !bk || !bv) { g.err = sd.err; return -1; }
+    }
+    const std::vector<float> wqp = pad_heads_rows(wq, C, C, heads, d, d16, scale), bqp = pad_heads_vec(bq, heads, d, d16, scale);
+    const std::vector<float> wkp = pad_heads_rows(wk, C, Cctx, heads, d, d16, 1.f), bkp = pad_heads_vec(bk, heads, d, d16, 1.f);
+    const std::vector<float> wvp = pad_heads_rows(wv, C, Cctx, heads, d, d16, 1.f), bvp = pad_heads_vec(bv, heads, d, d16, 1.f);
+    const std::vector<float> wop = pad_heads_cols(wo, C, heads, d, d16);
+    MtTensor q = g.alloc(Cp, x.H, x.W), k = g.alloc(Cp, ctx.H, ctx.W), v = g.alloc(Cp, ctx.H, ctx.W), o = g.alloc(Cp, x.H, x.W);
+    if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
+    if (g.add_conv(p + ".to_k", wkp.data(), bkp.data(), Cctx, Cp, 1, 1, 0, ctx, k, nullptr, 0, 0)) return -1;
+    if (g.add_conv(p + ".to_v", wvp.data(), bvp.data(), Cctx, Cp, 1, 1, 0, ctx, v, nullptr, 0, 0)) return -1;
+    g.add_attn(p, q, k, v, o, heads, d16);
+    return g.add_conv(p + ".to_out.0", wop.data(), bo, Cp, C, 1, 1, 0, o, out, &res, 0, 0);
+}
+
+// diffusers Transformer2DModel (conv proj_in/out) with one BasicTransformerBlock (GEGLU feed-forward)
+int build_transformer(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& ctx, const MtTensor& out, int C) {
+    const int H = x.H, W = x.W;
+    MtTensor t = g.alloc(C, H, W);
+    if (g.add_gn(p + ".norm", sd, p + ".norm", x, t, 1e-6f, 0)) return -1;
+    const float* wi = sd.get(p + ".proj_in.weight", (size_t)C * C);
+    const float* bi = sd.get(p + ".proj_in.bias", C);
+    if (!wi || !bi) { g.err = sd.err; return -1; }
+    MtTensor h0 = g.alloc(C, H, W);
+    if (g.add_conv(p + ".proj_in", wi, bi, C, C, 1, 1, 0, t, h0, nullptr, 0, 0)) return -1;
+    const std::string b = p + ".transformer_blocks.0";
+    MtTensor n1 = g.alloc(C, H, W), h1 = g.alloc(C, H, W);
+    if (g.add_ln(b + ".norm1", sd, b + ".norm1", h0, n1, 1e-5f)) return -1;
+    if (build_attention(g, sd, b + ".attn1", n1, n1, C, C, 8, false, h0, h1)) return -1;
+    MtTensor n2 = g.alloc(C, H, W), h2 = g.alloc(C, H, W);
+    if (g.add_ln(b + ".norm2", sd, b + ".norm2", h1, n2, 1e-5f)) return -1;
+    if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2)) return -1;
+    MtTensor n3 = g.alloc(C, H, W), f1 = g.alloc(8 * C, H, W), gg = g.alloc(4 * C, H, W), h3 = g.alloc(C, H, W);
+    if (g.add_ln(b + ".norm3", sd, b + ".norm3", h2, n3, 1e-5f)) return -1;
+    const float* w1 = sd.get(b + ".ff.net.0.proj.weight", (size_t)8 * C * C);
+    const float* b1 = sd.get(b + ".ff.net.0.proj.bias", 8 * C);
+    const float* w2 = sd.get(b + ".ff.net.2.weight", (size_t)C * 4 * C);
+    const float* b2 = sd.get(b + ".ff.net.2.bias", C);
+    if (!w1 || !b1 || !w2 || !b2) { g.err = sd.err; return -1; }
+    if (g.add_conv(b + ".ff.net.0.proj", w1, b1, C, 8 * C, 1, 1, 0, n3, f1, nullptr, 0, 0)) return -1;
+    g.add_geglu(b + ".ff.geglu", f1, gg);
+    if (g.add_conv(b + ".ff.net.2", w2, b2, 4 * C, C, 1, 1, 0, gg, h3, &h2, 0, 0)) return -1;
+    const float* wo = sd.get(p + ".proj_out.weight", (size_t)C * C);
+    const float* bo = sd.get(p + ".proj_out.bias", C);
+    if (!wo || !bo) { g.err = sd.err; return -1; }
+    return g.add_conv(p + ".proj_out", wo, bo, C, C, 1, 1, 0, h3, out, &x, 0, 0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ U-Net
+int mt_build_unet(MtGraph& g, const ltk_named_tensor* t, int n, MtTensor* latent_in, MtTensor* ctx_in, MtTensor* out) {
+    SD sd{t, n, ""};
+    const int ch[4] = {320, 640, 1280, 1280};
+    const bool down_attn[4] = {true, true, true, false};
+    const bool up_attn[4] = {false, true, true, true};
+    std::vector<float> temb;
+    if (time_embedding_silu(sd, 0.f, &temb)) { g.err = sd.err; return -1; }
+
+    *latent_in = g.alloc(8, 32, 32);         // 16-channel block, 8 real
+    *ctx_in = g.alloc(384, 50, 1);
+    g.named["latent_in"] = *latent_in;
+
+    // skip tensors live inside the cat buffers of the up path: plan those first (pop order of down_block_res_samples)
+    struct SkipSpec { int C, HW; };
+    const SkipSpec skips[12] = {{320, 32}, {320, 32}, {320, 32}, {320, 16}, {640, 16}, {640, 16}, {640, 8}, {1280, 8}, {1280, 8}, {1280, 4}, {1280, 4}, {1280, 4}};
+    // channels of h entering each up resnet (block i, resnet j)
+    const int up_h[4][3] = {{1280, 1280, 1280}, {1280, 1280, 1280}, {1280, 640, 640}, {640, 320, 320}};
+    MtTensor cat[4][3], skip_dst[12];
+    {
+        int si = 11;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j, --si) {
+                cat[i][j] = g.alloc(up_h[i][j] + skips[si].C, skips[si].HW, skips[si].HW);
+                skip_dst[si] = MtGraph::view(cat[i][j], up_h[i][j], skips[si].C);
+            }
+    }
+    int si = 0;
+    const float* wci = sd.get("conv_in.weight", (size_t)320 * 8 * 9);
+    const float* bci = sd.get("conv_in.bias", 320);
+    if (!wci || !bci) { g.err = sd.err; return -1; }
+    if (g.add_conv("conv_in", wci, bci, 8, 320, 3, 1, 1, *latent_in, skip_dst[si], nullptr, 0, 0)) return -1;
+    g.named["conv_in"] = skip_dst[si];
+    MtTensor h = skip_dst[si++];
+    int C = 320;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+            MtTensor dst = skip_dst[si++];
+            if (down_attn[i]) {
+                MtTensor r = g.alloc(ch[i], h.H, h.W);
+                if (build_resnet(g, sd, rp, h, r, C, ch[i], &temb, 1e-5f)) return -1;
+                if (build_transformer(g, sd, "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), r, *ctx_in, dst, ch[i])) return -1;
+            } else {
+                if (build_resnet(g, sd, rp, h, dst, C, ch[i], &temb, 1e-5f)) return -1;
+            }
+            C = ch[i];
+            h = dst;
+            g.named["down_blocks." + std::to_string(i) + "." + std::to_string(j)] = h;
+        }
+        if (i < 3) {
+            const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
+            const float* w = sd.get(dp + ".weight", (size_t)C * C * 9);
+            const float* b = sd.get(dp + ".bias", C);
+            if (!w || !b) { g.err = sd.err; return -1; }
+            MtTensor dst = skip_dst[si++];
+            if (g.add_conv(dp, w, b, C, C, 3, 2, 1, h, dst, nullptr, 0, 0)) return -1;
+            h = dst;
+            g.named["down_blocks." + std::to_string(i) + ".down"] = h;
+        }
+    }
+    {
+        MtTensor r0 = g.alloc(C, h.H, h.W), a0 = g.alloc(C, h.H, h.W);
+        if (build_resnet(g, sd, "mid_block.resnets.0", h, r0, C, C, &temb, 1e-5f)) return -1;
+        if (build_transformer(g, sd, "mid_block.attentions.0", r0, *ctx_in, a0, C)) return -1;
+        MtTensor dst = MtGraph::view(cat[0][0], 0, up_h[0][0]);
+        if (build_resnet(g, sd, "mid_block.resnets.1", a0, dst, C, C, &temb, 1e-5f)) return -1;
+        g.named["mid_block"] = dst;
+    }
+    const int rev[4] = {1280, 1280, 640, 320};
+    MtTensor hup;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            const MtTensor& in = cat[i][j];                    // [h | skip]
+            // where this resnet(+attention) writes: the h half of the next cat buffer, or a fresh tensor
+            MtTensor dst;
+            const bool last_in_block = (j == 2);
+            if (!last_in_block) dst = MtGraph::view(cat[i][j + 1], 0, up_h[i][j + 1]);
+            else dst = g.alloc(rev[i], in.H, in.W);
+            const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+            if (up_attn[i]) {
+                MtTensor r = g.alloc(rev[i], in.H, in.W);
+                if (build_resnet(g, sd, rp, in, r, in.C, rev[i], &temb, 1e-5f)) return -1;
+                if (build_transformer(g, sd, "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), r, *ctx_in, dst, rev[i])) return -1;
+            } else {
+                if (build_resnet(g, sd, rp, in, dst, in.C, rev[i], &temb, 1e-5f)) return -1;
+            }
+            g.named["up_blocks." + std::to_string(i) + "." + std::to_string(j)] = dst;
+            hup = dst;
+        }
+        if (i < 3) {
+            const std::string up = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+            const float* w = sd.get(up + ".weight", (size_t)rev[i] * rev[i] * 9);
+            const float* b = sd.get(up + ".bias", rev[i]);
+            if (!w || !b) { g.err = sd.err; return -1; }
+            MtTensor dst = MtGraph::view(cat[i + 1][0], 0, up_h[i + 1][0]);
+            MtTensor xin = hup;
+            xin.H *= 2; xin.W *= 2;                               // logical (upsampled) size the conv runs on
+            if (g.add_conv(up, w, b, rev[i], rev[i], 3, 1, 1, xin, dst, nullptr, 0, 1)) return -1;
+            g.named["up_blocks." + std::to_string(i) + ".up"] = dst;
+        }
+    }
+    MtTensor tn = g.alloc(320, 32, 32);
+    if (g.add_gn("conv_norm_out", sd, "conv_norm_out", hup, tn, 1e-5f, 1)) return -1;
+    const float* wo = sd.get("conv_out.weight", (size_t)4 * 320 * 9);
+    const float* bo = sd.get("conv_out.bias", 4);
+    if (!wo || !bo) { g.err = sd.err; return -1; }
+    *out = g.alloc(4, 32, 32);
+    if (g.add_conv("conv_out", wo, bo, 320, 4, 3, 1, 1, tn, *out, nullptr, 0, 0)) return -1;
+    g.named["conv_out"] = *out;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ VAE decoder
+int mt_build_vae(MtGraph& g, const ltk_named_tensor* t, int n, const MtTensor& z, MtTensor* out) {
+    SD sd{t, n, ""};
+    const float kScaling = 0.18215f;       // AutoencoderKL config.scaling_factor of sd-vae-ft-mse (vae.py:35,103)
+    const float* wq = sd.get("post_quant_conv.weight", 16);
+    const float* bq = sd.get("post_quant_conv.bias", 4);
+    if (!wq || !bq) { g.err = sd.err; return -1; }
+    std::vector<float> wqs(16);
+    for (int i = 0; i < 16; ++i) wqs[i] = wq[i] / kScaling;
+    MtTensor pq = g.alloc(4, 32, 32);
+    if (g.add_conv("post_quant_conv", wqs.data(), bq, 4, 4, 1, 1, 0, z, pq, nullptr, 0, 0)) return -1;
+    const float* wi = sd.get("decoder.conv_in.weight", (size_t)512 * 4 * 9);
+    const float* bi = sd.get("decoder.conv_in.bias", 512);
+    if (!wi || !bi) { g.err = sd.err; return -1; }
+    MtTensor h = g.alloc(512, 32, 32);
+    if (g.add_conv("decoder.conv_in", wi, bi, 4, 512, 3, 1, 1, pq, h, nullptr, 0, 0)) return -1;
+    g.named["decoder.conv_in"] = h;
+    {
+        MtTensor r0 = g.alloc(512, 32, 32);
+        if (build_resnet(g, sd, "decoder.mid_block.resnets.0", h, r0, 512, 512, nullptr, 1e-6f)) return -1;
+        const std::string a = "decoder.mid_block.attentions.0";
+        MtTensor gn = g.alloc(512, 32, 32), ao = g.alloc(512, 32, 32);
+        if (g.add_gn(a + ".group_norm", sd, a + ".group_norm", r0, gn, 1e-6f, 0)) return -1;
+        if (build_attention(g, sd, a, gn, gn, 512, 512, 1, true, r0, ao)) return -1;
+        MtTensor r1 = g.alloc(512, 32, 32);
+        if (build_resnet(g, sd, "decoder.mid_block.resnets.1", ao, r1, 512, 512, nullptr, 1e-6f)) return -1;
+        h = r1;
+        g.named["decoder.mid_block"] = h;
+    }
+    const int chs[4] = {512, 512, 256, 128};
+    int C = 512;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            MtTensor r = g.alloc(chs[i], h.H, h.W);
+            if (build_resnet(g, sd, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h, r, C, chs[i], nullptr, 1e-6f)) return -1;
+            C = chs[i];
+            h = r;
+        }
+        g.named["decoder.up_blocks." + std::to_string(i)] = h;
+        if (i < 3) {
+            const std::string up = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+            const float* w = sd.get(up + ".weight", (size_t)C * C * 9);
+            const float* b = sd.get(up + ".bias", C);
+            if (!w || !b) { g.err = sd.err; return -1; }
+            MtTensor xin = h;
+            xin.H *= 2; xin.W *= 2;
+            MtTensor dst = g.alloc(C, xin.H, xin.W);
+            if (g.add_conv(up, w, b, C, C, 3, 1, 1, xin, dst, nullptr, 0, 1)) return -1;
+            h = dst;
+        }
+    }
+    MtTensor tn = g.alloc(128, 256, 256);
+    if (g.add_gn("decoder.conv_norm_out", sd, "decoder.conv_norm_out", h, tn, 1e-6f, 1)) return -1;
+    const float* wo = sd.get("decoder.conv_out.weight", (size_t)3 * 128 * 9);
+    const float* bo = sd.get("decoder.conv_out.bias", 3);
+    if (!wo || !bo) { g.err = sd.err; return -1; }
+    *out = g.alloc(3, 256, 256);
+    if (g.add_conv("decoder.conv_out", wo, bo, 128, 3, 3, 1, 1, tn, *out, nullptr, 0, 0)) return -1;
+    g.named["decoder.conv_out"] = *out;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ allocate / run / free
+int mt_graph_alloc(MtGraph& g, int frames) {
+    g.frames = frames;
+    g.bufs.assign(g.buf_halfs.size(), nullptr);
+    for (size_t i = 0; i < g.buf_halfs.size(); ++i) {
+        const size_t bytes = g.buf_halfs[i] * frames * sizeof(f16) + 256;
+        if (hipMalloc((void**)&g.bufs[i], bytes) != hipSuccess) { g.err = "activation allocation failed"; return -4; }
+        (void)hipMemset(g.bufs[i], 0, bytes);
+    }
+    // GroupNorm partial stats: [N][C/16][segs][32] floats, C <= 2560, segs <= 64 -> bound by the op list
+    size_t need = 0;
+    for (const MtOp& op : g.ops)
+        if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * gn_segments(frames, op.x.C, op.x.P()) * 32);
+    // the segment count is chosen per launch from the launch's frame count: size for the worst case (1 frame)
+    for (const MtOp& op : g.ops)
+        if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 64 * 32);
+    g.gn_partial_floats = need;
+    if (hipMalloc((void**)&g.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+    if (g.vt_halfs) {
+        if (hipMalloc((void**)&g.vt, g.vt_halfs * frames * sizeof(f16)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+    }
+    return 0;
+}
+
+void mt_graph_free(MtGraph& g) {
+    for (f16* b : g.bufs) if (b) (void)hipFree(b);
+    for (ConvPlan& p : g.plans) conv_plan_destroy(&p);
+    for (float* v : g.vecs) if (v) (void)hipFree(v);
+    if (g.gn_partial) (void)hipFree(g.gn_partial);
+    if (g.vt) (void)hipFree(g.vt);
+    g.bufs.clear(); g.plans.clear(); g.vecs.clear();
+}
+
+f16* mt_ptr(const MtGraph& g, const MtTensor& t) { return g.bufs[t.buf]; }
+
+int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStream_t s, int op_begin, int op_end) {
+    if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
+    if (op_end < 0) op_end = (int)g.ops.size();
+    for (int oi = op_begin; oi < op_end; ++oi) {
+        const MtOp& op = g.ops[oi];
+        switch (op.type) {
+            case OP_CONV: {
+                ConvIO io;
+                io.x = g.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
+                io.y = g.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
+                io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
+                io.relu = 0; io.act = op.act; io.ups = op.ups;
+                io.partial = partial; io.partial_cap = partial_cap;
+                std::string e;
+                const int rc = conv_launch(g.plans[op.plan], io, s, &e);
+                if (rc) { g.err = op.name + ": " + e; return rc; }
+                break;
+            }
+            case OP_GN: {
+                const int P = op.x.P();
+                const int segs = gn_segments(nf, op.x.C, P);
+                launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
+                launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+                break;
+            }
+            case OP_LN:
+                launch_layernorm(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), op.eps, g.vecs[op.gamma],
+                                 g.vecs[op.beta], g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+                break;
+            case OP_ATTN: {
+                launch_v_transpose(g.bufs[op.v.buf], nf, op.v.ld / 16, op.v.coff / 16, op.heads, op.d16, op.Tk, g.vt, s);
+                const int rc = launch_attention(g.bufs[op.x.buf], op.x.ld / 16, op.x.coff / 16, op.x.P(), g.bufs[op.k.buf], op.k.ld / 16,
+                                                op.k.coff / 16, op.Tk, g.vt, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, nf, op.heads,
+                                                op.d16, s);
+                if (rc) { g.err = op.name + ": attention launch failed (head dim " + std::to_string(op.d16) + ")"; return rc; }
+                break;
+            }
+            case OP_GEGLU:
+                launch_geglu(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), g.bufs[op.y.buf], op.y.ld / 16,
+                             op.y.coff / 16, s);
+                break;
+        }
+    }
+    if (hipGetLastError() != hipSuccess) { g.err = "a MuseTalk kernel launch failed"; return -2; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ public wrappers
+MtGraph* mt_graph_new() { return new MtGraph(); }
+void mt_graph_delete(MtGraph* g) {
+    if (!g) return;
+    mt_graph_free(*g);
+    delete g->t_latent; delete g->t_ctx; delete g->t_unet_out; delete g->t_vae_out;
+    delete g;
+}
+const char* mt_graph_error(const MtGraph* g) { return g->err.c_str(); }
+
+int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames) {
+    g->t_latent = new MtTensor(); g->t_ctx = new MtTensor(); g->t_unet_out = new MtTensor(); g->t_vae_out = new MtTensor();
+    if (mt_build_unet(*g, unet_sd, n_unet, g->t_latent, g->t_ctx, g->t_unet_out)) return -1;
+    if (mt_build_vae(*g, vae_sd, n_vae, *g->t_unet_out, g->t_vae_out)) return -1;
+    return mt_graph_alloc(*g, frames);
+}
+static f16* tptr(MtGraph* g, const MtTensor* t, int* cbt) { if (cbt) *cbt = t->ld / 16; return g->bufs[t->buf]; }
+f16* mt_latent_in(MtGraph* g, int* cbt) { return tptr(g, g->t_latent, cbt); }
+f16* mt_ctx_in(MtGraph* g, int* cbt) { return tptr(g, g->t_ctx, cbt); }
+f16* mt_unet_out(MtGraph* g, int* cbt) { return tptr(g, g->t_unet_out, cbt); }
+f16* mt_vae_out(MtGraph* g, int* cbt) { return tptr(g, g->t_vae_out, cbt); }
+int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s) { return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1); }
+f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, int* W) {
+    auto it = g->named.find(name);
+    if (it == g->named.end()) return nullptr;
+    const MtTensor& t = it->second;
+    *C = t.C; *ld = t.ld; *coff = t.coff; *H = t.H; *W = t.W;
+    return g->bufs[t.buf];
+}
+double mt_macs_per_frame(const MtGraph* g) { return g->macs; }
+
+}  // namespace ltk

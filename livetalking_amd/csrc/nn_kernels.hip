@@ -1,0 +1,517 @@
+// Non-convolution kernels of the MuseTalk path (gfx950).  See nn_kernels.h.
+//
+// Reference behaviour restated by these kernels (diffusers is a third-party dependency of the reference,
+// requirements.txt:41; call sites avatars/musetalk/models/unet.py:36-46, vae.py:96-108):
+//   GroupNorm + SiLU   ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out
+//   LayerNorm          BasicTransformerBlock.norm1/2/3
+//   attention          Attention / AttnProcessor2_0 (scaled_dot_product_attention)
+//   GEGLU              FeedForward.net[0]
+// In-tree statements of the same blocks: avatars/musetalk/models/syncnet.py:71-181.
+#include "nn_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+namespace ltk {
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =============================================================================================== GroupNorm
+int gn_segments(int N, int C, int P) {
+    const long long blocks = (long long)N * (C / 16);
+    int segs = 1;
+    while (blocks * segs < 512 && P / (segs * 2) >= 256 && segs < 64) segs *= 2;
+    return segs;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x, int cbt, int cb0, int CB, int P, int segs,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[4][2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = tid & 1, pl = tid >> 1;
+    const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB, seg = blockIdx.y;
+    const int seglen = (P + segs - 1) / segs;
+    const int p0 = seg * seglen, p1 = min(P, p0 + seglen);
+    const f16* base = x + ((size_t)(n * cbt + cb0 + cb) * P) * 16 + half * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s[c] = 0.f; q[c] = 0.f; }
+    for (int p = p0 + pl; p < p1; p += 128) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)p * 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s[c] += f; q[c] += f * f; }
+    }
+    // reduce over the 32 lanes of this wave that share `half` (lane bit 0)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int m = 2; m < 64; m <<= 1) { s[c] += __shfl_xor(s[c], m); q[c] += __shfl_xor(q[c], m); }
+    }
+    if (lane < 2) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { red[wave][0][lane * 8 + c] = s[c]; red[wave][1][lane * 8 + c] = q[c]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int which = tid >> 4, c = tid & 15;
+        const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        partial[(((size_t)blockIdx.x * segs + seg) * 2 + which) * 16 + c] = v;
+    }
+}
+
+void launch_gn_stats(const f16* x, int N, int cbt, int cb0, int C, int P, int segs, float* partial, hipStream_t s) {
+    const int CB = C / 16;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * CB, segs), dim3(256), 0, s, x, cbt, cb0, CB, P, segs, partial);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int CB, int P, int cpg,
+                                                        float eps, const float* __restrict__ partial, int segs,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                        f16* __restrict__ y, int y_cbt, int y_cb0) {
+    __shared__ float ab[2][16];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB;
+    if (tid < 16) {
+        const int c = cb * 16 + tid;
+        const int g0 = (c / cpg) * cpg;           // first channel of this channel's group
+        float S = 0.f, Q = 0.f;
+        for (int cc = g0; cc < g0 + cpg; ++cc) {
+            const float* pp = partial + ((size_t)(n * CB + (cc >> 4)) * segs) * 32 + (cc & 15);
+            for (int sg = 0; sg < segs; ++sg) { S += pp[sg * 32]; Q += pp[sg * 32 + 16]; }
+        }
+        const float cnt = (float)cpg * (float)P;
+        const float mean = S / cnt;
+        const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        const float a = gamma[c] * rstd;
+        ab[0][tid] = a;
+        ab[1][tid] = beta[c] - mean * a;
+    }
+    __syncthreads();
+    const int half = tid & 1;
+    float a8[8], b8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { a8[c] = ab[0][half * 8 + c]; b8[c] = ab[1][half * 8 + c]; }
+    const f16* xb = x + ((size_t)(n * x_cbt + x_cb0 + cb) * P) * 16 + half * 8;
+    f16* yb = y + ((size_t)(n * y_cbt + y_cb0 + cb) * P) * 16 + half * 8;
+    const int p0 = blockIdx.y * 1024;
+    const int p1 = min(P, p0 + 1024);
+    for (int p = p0 + (tid >> 1); p < p1; p += 128) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)p * 16);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = (float)v[c] * a8[c] + b8[c];
+            if (silu) t = silu_f(t);
+            o[c] = (f16)t;
+        }
+        *reinterpret_cast<f16x8*>(yb + (size_t)p * 16) = o;
+    }
+}
+
+void launch_gn_apply(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
+                     int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    const int CB = C / 16;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
+                       partial, segs, gamma, beta, silu, y, y_cbt, y_cb0);
+}
+
+// =============================================================================================== LayerNorm
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int cbt, int cb0, int C, int P, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         f16* __restrict__ y, int y_cbt, int y_cb0) {
+    __shared__ float red[2][4][64];
+    const int tid = threadIdx.x;
+    const int tok = tid & 63, part = tid >> 6;
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 64 + tok;
+    const bool ok = p < P;
+    const int items = C >> 3;
+    const f16* xb = x + ((size_t)(n * cbt + cb0) * P) * 16;
+    float s = 0.f, q = 0.f;
+    if (ok) {
+        for (int i = part; i < items; i += 4) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xb + ((size_t)(i >> 1) * P + p) * 16 + (i & 1) * 8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s += f; q += f * f; }
+        }
+    }
+    red[0][part][tok] = s;
+    red[1][part][tok] = q;
+    __syncthreads();
+    const float S = red[0][0][tok] + red[0][1][tok] + red[0][2][tok] + red[0][3][tok];
+    const float Q = red[1][0][tok] + red[1][1][tok] + red[1][2][tok] + red[1][3][tok];
+    const float mean = S / (float)C;
+    const float rstd = rsqrtf(fmaxf(Q / (float)C - mean * mean, 0.f) + eps);
+    if (!ok) return;
+    f16* yb = y + ((size_t)(n * y_cbt + y_cb0) * P) * 16;
+    for (int i = part; i < items; i += 4) {
+        const size_t off = ((size_t)(i >> 1) * P + p) * 16 + (i & 1) * 8;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xb + off);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (f16)(((float)v[c] - mean) * rstd * gamma[i * 8 + c] + beta[i * 8 + c]);
+        *reinterpret_cast<f16x8*>(yb + off) = o;
+    }
+}
+
+void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float eps, const float* gamma, const float* beta,
+                      f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((P + 63) / 64, N), dim3(256), 0, s, x, cbt, cb0, C, P, eps, gamma, beta, y, y_cbt, y_cb0);
+}
+
+// =============================================================================================== attention
+int attn_dv32(int d16) { return (d16 + 31) / 32 * 32; }
+int attn_tkp(int Tk) { return (Tk + 63) / 64 * 64; }
+
+// V [N][cbt][Tk][16] (head h at blocks cb0 + h*d16/16) -> VT [N][heads][dv32][Tkp], channel-major, the 16 keys of
+// every group in MFMA B-operand slot order {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}; padding rows / keys are zero.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const f16* __restrict__ v, int cbt, int cb0, int heads, int d16, int dv32,
+                                                           int Tk, int Tkp, f16* __restrict__ vt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_vt[];
+    f16* tile = reinterpret_cast<f16*>(smem_vt);         // [d16][66]
+    const int tid = threadIdx.x;
+    const int key0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+    const int ncb = d16 >> 4;
+    const f16* vb = v + ((size_t)(n * cbt + cb0 + h * ncb) * Tk) * 16;
+    for (int i = tid; i < ncb * 128; i += 256) {
+        const int j = i >> 7, r = i & 127, key = key0 + (r >> 1), half = r & 1;
+        f16x8 val;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) val[c] = (f16)0.f;
+        if (key < Tk) val = *reinterpret_cast<const f16x8*>(vb + ((size_t)j * Tk + key) * 16 + half * 8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tile[(j * 16 + half * 8 + c) * 66 + (r >> 1)] = val[c];
+    }
+    __syncthreads();
+    f16* out = vt + ((size_t)(n * heads + h) * dv32) * Tkp + key0;
+    for (int i = tid; i < dv32 * 8; i += 256) {          // 8 x 16-byte pieces per channel row
+        const int ch = i >> 3, piece = i & 7;             // piece: positions piece*8 .. +7 of the 64-key tile
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int pos = piece * 8 + c;
+            const int w = pos & 15;
+            const int key = (pos & ~15) + ((w < 4) ? w : (w < 8) ? w + 4 : (w < 12) ? w - 4 : w);
+            o[c] = (ch < d16) ? tile[ch * 66 + key] : (f16)0.f;
+        }
+        *reinterpret_cast<f16x8*>(out + (size_t)ch * Tkp + piece * 8) = o;
+    }
+}
+
+void launch_v_transpose(const f16* v, int N, int cbt, int cb0, int heads, int d16, int Tk, f16* vt, hipStream_t s) {
+    const int dv32 = attn_dv32(d16), Tkp = attn_tkp(Tk);
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(Tkp / 64, heads, N), dim3(256), (size_t)d16 * 66 * sizeof(f16), s, v, cbt, cb0, heads,
+                       d16, dv32, Tk, Tkp, vt);
+}
+
+struct AttnArgs {
+    const f16* q; const f16* k; const f16* vt; f16* o;
+    int q_cbt, q_cb0, k_cbt, k_cb0, o_cbt, o_cb0;
+    int Tq, Tk, Tkp, heads, dv32;
+};
+
+// One wave = 32 queries of one (image, head).  S^T = K Q^T (keys as MFMA rows, queries as columns): a lane then
+// holds 16 keys of ONE query, so the softmax statistics are per lane (+ one exchange with the partner lane), and
+// the probabilities already sit in B-operand order for O^T += V^T P^T.  SHARE: the 4 waves of a block take the
+// same query tile and a quarter of the value channels each (head dim 512 of the VAE mid-block attention).
+template <int DT, int DVT, bool SHARE>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int qtile = SHARE ? blockIdx.x : blockIdx.x * 4 + wave;
+    const int q0 = qtile * 32;
+    if (q0 >= a.Tq) return;
+    const int dvt0 = SHARE ? wave * DVT : 0;
+    const int Tq = a.Tq, Tk = a.Tk, Tkp = a.Tkp;
+    const f16* qb = a.q + ((size_t)(n * a.q_cbt + a.q_cb0 + h * DT) * Tq) * 16 + hh * 8;
+    const f16* kb = a.k + ((size_t)(n * a.k_cbt + a.k_cb0 + h * DT) * Tk) * 16 + hh * 8;
+    const f16* vtb = a.vt + ((size_t)(n * a.heads + h) * a.dv32 + dvt0 * 32 + l31) * Tkp + hh * 8;
+    const int qrow = min(q0 + l31, Tq - 1);
+
+    f16x8 qf[SHARE ? 1 : DT];
+    if constexpr (!SHARE) {
+#pragma unroll
+        for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
+    }
+    f32x16 acc[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    for (int key0 = 0; key0 < Tk; key0 += 32) {
+        const int krow = min(key0 + l31, Tk - 1);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + ((size_t)j * Tk + krow) * 16);
+            f16x8 qj;
+            if constexpr (SHARE) qj = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
+            else qj = qf[j];
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qj, st, 0, 0, 0);
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+            if (key >= Tk) st[r] = -1e30f;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);
+        float ls = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+        l = l * alpha + ls;
+        m = m_new;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pf[r] = (f16)p[8 * s + r]; pf[4 + r] = (f16)p[8 * s + 4 + r]; }
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) {
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(vtb + (size_t)t * 32 * Tkp + key0 + s * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.f / (l + __shfl_xor(l, 32));
+    const bool qok = (q0 + l31) < Tq;
+    f16* ob = a.o + ((size_t)(n * a.o_cbt + a.o_cb0 + h * DT) * Tq + q0 + l31) * 16 + hh * 8;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int cbl = (dvt0 + t) * 2 + pr;       // channel block of the head
+            unsigned pk[2][2];
+#pragma unroll
+            for (int eo = 0; eo < 2; ++eo) {
+                const int g = 2 * pr + eo;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[t][4 * g + r] * inv);
+                const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                pk[eo][0] = u.x; pk[eo][1] = u.y;
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (qok && cbl < DT) *reinterpret_cast<uint4*>(ob + (size_t)cbl * Tq * 16) = out;
+        }
+    }
+}
+
+int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, int k_cbt, int k_cb0, int Tk, const f16* vt,
+                     f16* o, int o_cbt, int o_cb0, int N, int heads, int d16, hipStream_t s) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.vt = vt; a.o = o;
+    a.q_cbt = q_cbt; a.q_cb0 = q_cb0; a.k_cbt = k_cbt; a.k_cb0 = k_cb0; a.o_cbt = o_cbt; a.o_cb0 = o_cb0;
+    a.Tq = Tq; a.Tk = Tk; a.Tkp = attn_tkp(Tk); a.heads = heads; a.dv32 = attn_dv32(d16);
+    const int qtiles = (Tq + 31) / 32;
+    const dim3 grid4((qtiles + 3) / 4, heads, N), grid1(qtiles, heads, N);
+    switch (d16) {
+        case 48: hipLaunchKernelGGL((attn_kernel<3, 2, false>), grid4, dim3(256), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((attn_kernel<4, 2, false>), grid4, dim3(256), 0, s, a); break;
+        case 80: hipLaunchKernelGGL((attn_kernel<5, 3, false>), grid4, dim3(256), 0, s, a); break;
+        case 160: hipLaunchKernelGGL((attn_kernel<10, 5, false>), grid4, dim3(256), 0, s, a); break;
+        case 512: hipLaunchKernelGGL((attn_kernel<32, 4, true>), grid1, dim3(256), 0, s, a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// =============================================================================================== elementwise
+__global__ __launch_bounds__(256) void geglu_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int CB, int P,
+                                                     f16* __restrict__ y, int y_cbt, int y_cb0, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (n, cb, p, half)
+    if (i >= total) return;
+    const int half = (int)(i & 1);
+    const long long r = i >> 1;
+    const int p = (int)(r % P);
+    const long long r2 = r / P;
+    const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+    const f16x8 av = *reinterpret_cast<const f16x8*>(x + ((size_t)(n * x_cbt + x_cb0 + cb) * P + p) * 16 + half * 8);
+    const f16x8 gv = *reinterpret_cast<const f16x8*>(x + ((size_t)(n * x_cbt + x_cb0 + CB + cb) * P + p) * 16 + half * 8);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (f16)((float)av[c] * gelu_f((float)gv[c]));
+    *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_geglu(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    const int CB = C / 16;
+    const long long total = (long long)N * CB * P * 2;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, y, y_cbt, y_cb0, total);
+}
+
+__global__ __launch_bounds__(256) void act_kernel(const f16* __restrict__ x, int cbt, int cb0, int CB, int P, int act,
+                                                   f16* __restrict__ y, int y_cbt, int y_cb0, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int half = (int)(i & 1);
+    const long long r = i >> 1;
+    const int p = (int)(r % P);
+    const long long r2 = r / P;
+    const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+    const f16x8 v = *reinterpret_cast<const f16x8*>(x + ((size_t)(n * cbt + cb0 + cb) * P + p) * 16 + half * 8);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float f = (float)v[c];
+        o[c] = (f16)(act == 2 ? gelu_f(f) : act == 3 ? silu_f(f) : f);
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_act(const f16* x, int N, int cbt, int cb0, int C, int P, int act, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    const int CB = C / 16;
+    const long long total = (long long)N * CB * P * 2;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cbt, cb0, CB, P, act, y, y_cbt, y_cb0, total);
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(f16* __restrict__ x, int cbt, int cb0, int CB, int P, int C,
+                                                       const float* __restrict__ pos, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int half = (int)(i & 1);
+    const long long r = i >> 1;
+    const int p = (int)(r % P);
+    const long long r2 = r / P;
+    const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+    f16* ptr = x + ((size_t)(n * cbt + cb0 + cb) * P + p) * 16 + half * 8;
+    f16x8 v = *reinterpret_cast<const f16x8*>(ptr);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cb * 16 + half * 8 + c;
+        if (ch < C) v[c] = (f16)((float)v[c] + pos[(size_t)p * C + ch]);
+    }
+    *reinterpret_cast<f16x8*>(ptr) = v;
+}
+
+void launch_add_pos(f16* x, int N, int cbt, int cb0, int C, int P, const float* pos, hipStream_t s) {
+    const int CB = (C + 15) / 16;
+    const long long total = (long long)N * CB * P * 2;
+    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cbt, cb0, CB, P, C, pos, total);
+}
+
+// =============================================================================================== layout bridges
+__global__ __launch_bounds__(256) void nchw_to_cb16_kernel(const float* __restrict__ x, int C, int P, f16* __restrict__ y,
+                                                            int y_cbt, int y_cb0, int CB, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (n, cb, p, half)
+    if (i >= total) return;
+    const int half = (int)(i & 1);
+    const long long r = i >> 1;
+    const int p = (int)(r % P);
+    const long long r2 = r / P;
+    const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cb * 16 + half * 8 + c;
+        o[c] = (ch < C) ? (f16)x[((size_t)n * C + ch) * P + p] : (f16)0.f;
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_nchw_to_cb16(const float* x, int N, int C, int P, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    const int CB = (C + 15) / 16;
+    const long long total = (long long)N * CB * P * 2;
+    hipLaunchKernelGGL(nchw_to_cb16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, C, P, y, y_cbt, y_cb0, CB, total);
+}
+
+__global__ __launch_bounds__(256) void tokens_to_cb16_kernel(const float* __restrict__ x, int P, int C, const float* __restrict__ add,
+                                                              f16* __restrict__ y, int y_cbt, int y_cb0, int CB, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int half = (int)(i & 1);
+    const long long r = i >> 1;
+    const int p = (int)(r % P);
+    const long long r2 = r / P;
+    const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cb * 16 + half * 8 + c;
+        float v = 0.f;
+        if (ch < C) {
+            v = x[((size_t)n * P + p) * C + ch];
+            if (add) v += add[(size_t)p * C + ch];
+        }
+        o[c] = (f16)v;
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_tokens_to_cb16(const float* x, int N, int P, int C, const float* add, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
+    const int CB = (C + 15) / 16;
+    const long long total = (long long)N * CB * P * 2;
+    hipLaunchKernelGGL(tokens_to_cb16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, P, C, add, y, y_cbt, y_cb0, CB, total);
+}
+
+__global__ __launch_bounds__(256) void gather_latents_kernel(const PtrList64 src, int C, int P, f16* __restrict__ y, int y_cbt, int CB) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;       // (cb, p, half)
+    if (i >= CB * P * 2) return;
+    const int half = i & 1, p = (i >> 1) % P, cb = (i >> 1) / P;
+    const float* x = reinterpret_cast<const float*>(src.p[f]);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cb * 16 + half * 8 + c;
+        o[c] = (ch < C) ? (f16)x[(size_t)ch * P + p] : (f16)0.f;
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)(f * y_cbt + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_gather_latents(const PtrList64& src, int nframes, int C, int P, f16* y, int y_cbt, hipStream_t s) {
+    const int CB = (C + 15) / 16;
+    hipLaunchKernelGGL(gather_latents_kernel, dim3((CB * P * 2 + 255) / 256, nframes), dim3(256), 0, s, src, C, P, y, y_cbt, CB);
+}
+
+__global__ __launch_bounds__(256) void vae_post_kernel(const f16* __restrict__ x, int x_cbt, int P, const OutList64 out,
+                                                        float* __restrict__ out_f32) {
+    __shared__ unsigned obytes[192];
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if (p < P) {
+        const f16x4 v = *reinterpret_cast<const f16x4*>(x + ((size_t)f * x_cbt * P + p) * 16);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // (image / 2 + 0.5).clamp(0, 1) in the VAE's fp16, then float * 255 and round-half-even (vae.py:104-106)
+            const f16 t = (f16)((float)v[c] * 0.5f + 0.5f);
+            rgb[c] = fminf(fmaxf((float)t, 0.f), 1.f);
+            if (out_f32) out_f32[((size_t)f * 3 + c) * P + p] = (float)v[c];
+        }
+    }
+    unsigned char* ob = reinterpret_cast<unsigned char*>(obytes) + threadIdx.x * 3;
+    ob[0] = (unsigned char)rintf(rgb[2] * 255.f);   // image[..., ::-1]: RGB -> BGR (vae.py:107)
+    ob[1] = (unsigned char)rintf(rgb[1] * 255.f);
+    ob[2] = (unsigned char)rintf(rgb[0] * 255.f);
+    __syncthreads();
+    if (out.p[f] && threadIdx.x < 192 && (blockIdx.x * 256 + 255) < P)
+        reinterpret_cast<unsigned*>(out.p[f] + (size_t)blockIdx.x * 768)[threadIdx.x] = obytes[threadIdx.x];
+}
+
+void launch_vae_post(const f16* x, int x_cbt, int nframes, int P, const OutList64& out, float* out_f32_nchw, hipStream_t s) {
+    hipLaunchKernelGGL(vae_post_kernel, dim3((P + 255) / 256, nframes), dim3(256), 0, s, x, x_cbt, P, out, out_f32_nchw);
+}
+
+}  // namespace ltk

@@ -14,7 +14,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import LtkError, NamedTensor, W2lReq  # noqa: F401
+from ._lib import LtkError, MtReq, NamedTensor, W2lReq  # noqa: F401
 
 
 def _as_f32(a) -> np.ndarray:
@@ -52,9 +52,8 @@ class Engine:
         _lib.check(self._lib.ltk_engine_sync(self._h))
 
     # ------------------------------------------------------------------ model
-    def load_wav2lip(self, state_dict: Dict[str, object], max_frames: int = 16):
-        """wav2lip_avatar.py:59-70: `state_dict` = checkpoint["state_dict"] with any
-        "module." prefix stripped (tensors or arrays)."""
+    @staticmethod
+    def _named_tensors(state_dict: Dict[str, object]):
         keep = []
         arr = (NamedTensor * len(state_dict))()
         n = 0
@@ -70,8 +69,24 @@ class Engine:
             arr[n].ndim = a.ndim
             arr[n].shape = shape
             n += 1
+        return arr, n, keep
+
+    def load_wav2lip(self, state_dict: Dict[str, object], max_frames: int = 16):
+        """wav2lip_avatar.py:59-70: `state_dict` = checkpoint["state_dict"] with any
+        "module." prefix stripped (tensors or arrays)."""
+        arr, n, keep = self._named_tensors(state_dict)
         _lib.check(self._lib.ltk_wav2lip_load(self._h, arr, n, int(max_frames)))
         self.max_frames = int(max_frames)
+        del keep
+
+    def load_musetalk(self, unet_sd: Dict[str, object], vae_sd: Dict[str, object], max_frames: int = 16):
+        """musetalk_avatar.py:57-67: diffusers-named state dicts of the U-Net (models/musetalkV15/unet.pth) and of
+        the sd-vae AutoencoderKL (post_quant_conv.*, decoder.*)."""
+        ua, un, k1 = self._named_tensors(unet_sd)
+        va, vn, k2 = self._named_tensors(vae_sd)
+        _lib.check(self._lib.ltk_musetalk_load(self._h, ua, un, va, vn, int(max_frames)))
+        self.mt_max_frames = int(max_frames)
+        del k1, k2
 
     # ------------------------------------------------------------------ avatars
     def register_avatar(self, face_list: Sequence[np.ndarray], frame_list: Sequence[np.ndarray],
@@ -119,6 +134,61 @@ class Engine:
     def paste_back_device(self, avatar_id: int, idx: int, d_pred_ptr: int, d_out_ptr: int, stream: int = 0):
         _lib.check(self._lib.ltk_paste_back(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr),
                                             C.c_void_p(d_out_ptr), 1, C.c_void_p(stream)))
+
+    # ------------------------------------------------------------------ musetalk
+    def register_musetalk_avatar(self, latents: Sequence[np.ndarray], frame_list: Sequence[np.ndarray], coord_list,
+                                 mask_list: Sequence[np.ndarray], mask_coords_list) -> int:
+        """(frame_list_cycle, mask_list_cycle, coord_list_cycle, mask_coords_list_cycle, input_latent_list_cycle) as
+        musetalk_avatar.load_avatar returns them (musetalk_avatar.py:69-91)."""
+        lat = np.ascontiguousarray(np.concatenate([_as_f32(x).reshape(1, 8, 32, 32) for x in latents]), dtype=np.float32)
+        fulls = np.ascontiguousarray(np.stack(frame_list), dtype=np.uint8)
+        fb = np.ascontiguousarray(np.asarray(coord_list, dtype=np.int32).reshape(-1, 4))
+        cb = np.ascontiguousarray(np.asarray(mask_coords_list, dtype=np.int32).reshape(-1, 4))
+        n = lat.shape[0]
+        flat = [np.ascontiguousarray(m, dtype=np.uint8).reshape(-1) for m in mask_list]
+        offs = np.zeros(n + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([f.size for f in flat])
+        masks = np.ascontiguousarray(np.concatenate(flat))
+        aid = C.c_int()
+        _lib.check(self._lib.ltk_musetalk_avatar_register(self._h, lat.ctypes.data, fulls.ctypes.data, fb.ctypes.data, cb.ctypes.data,
+                                                          masks.ctypes.data, offs.ctypes.data, n, fulls.shape[1], fulls.shape[2],
+                                                          C.byref(aid)))
+        return aid.value
+
+    def musetalk_infer(self, reqs: Sequence[tuple], stream: int = 0):
+        """reqs: (avatar_id, index, batch, d_feat_ptr fp32 [batch][50][384], d_pred_ptr uint8 [batch][256][256][3])."""
+        arr = (MtReq * len(reqs))()
+        for i, (aid, index, batch, feat_ptr, pred_ptr) in enumerate(reqs):
+            arr[i].avatar = int(aid); arr[i].index = int(index); arr[i].batch = int(batch)
+            arr[i].d_feat = C.c_void_p(feat_ptr); arr[i].d_pred = C.c_void_p(pred_ptr)
+        _lib.check(self._lib.ltk_musetalk_infer(self._h, arr, len(reqs), C.c_void_p(stream)))
+
+    def paste_blend(self, avatar_id: int, idx: int, d_pred_ptr: int, out: np.ndarray, stream: int = 0):
+        _lib.check(self._lib.ltk_paste_blend(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr), out.ctypes.data, 0,
+                                             C.c_void_p(stream)))
+
+    def musetalk_forward_host(self, latents: np.ndarray, feat: np.ndarray, want_image=True, want_frames=True):
+        latents = np.ascontiguousarray(latents, dtype=np.float32).reshape(-1, 8, 32, 32)
+        feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(-1, 50, 384)
+        B = latents.shape[0]
+        unet_out = np.empty((B, 4, 32, 32), dtype=np.float32)
+        image = np.empty((B, 3, 256, 256), dtype=np.float32) if want_image else None
+        frames = np.empty((B, 256, 256, 3), dtype=np.uint8) if want_frames else None
+        _lib.check(self._lib.ltk_musetalk_forward_host(self._h, latents.ctypes.data, feat.ctypes.data, B, unet_out.ctypes.data,
+                                                       image.ctypes.data if want_image else None,
+                                                       frames.ctypes.data if want_frames else None))
+        return unet_out, image, frames
+
+    def musetalk_debug_get(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float32)
+        _lib.check(self._lib.ltk_musetalk_debug_get(self._h, name.encode(), int(shape[0]), out.ctypes.data, out.size))
+        return out
+
+    def musetalk_time(self, frames: int, iters: int):
+        ms = C.c_float()
+        macs = C.c_double()
+        _lib.check(self._lib.ltk_musetalk_time(self._h, int(frames), int(iters), C.byref(ms), C.byref(macs)))
+        return ms.value, macs.value
 
     # ------------------------------------------------------------------ test / measurement hooks
     def wav2lip_forward_host(self, mel: np.ndarray, face6: np.ndarray) -> np.ndarray:

@@ -137,3 +137,135 @@ def wav2lip_avatar(n_frames: int = 8, full_hw: Tuple[int, int] = (720, 1280),
         x1 = int(cx - box // 2 + j[2]); x2 = int(cx + box // 2 + j[3])
         coords.append((y1, y2, x1, x2))
     return frames, faces, coords
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MuseTalk: seeded state dicts under diffusers' key names (UNet2DConditionModel with the MuseTalk-1.5 config,
+# AutoencoderKL decoder of sd-vae-ft-mse).  No checkpoint or config exists in the reference tree
+# (avatars/musetalk/utils/utils.py:16-18 loads models/musetalkV15/{unet.pth,musetalk.json} at run time).
+# ---------------------------------------------------------------------------------------------------------
+UNET_CH = (320, 640, 1280, 1280)
+UNET_CTX = 384
+VAE_CH = (128, 256, 512, 512)
+
+
+def _w(rng, shape, fan_in, gain=1.0):
+    return (rng.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))).astype(np.float32)
+
+
+def _norm(rng, sd, p, c):
+    sd[p + ".weight"] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+    sd[p + ".bias"] = (rng.standard_normal(c) * 0.05).astype(np.float32)
+
+
+def _conv(rng, sd, p, cin, cout, k, gain=1.0):
+    sd[p + ".weight"] = _w(rng, (cout, cin, k, k), cin * k * k, gain)
+    sd[p + ".bias"] = (rng.standard_normal(cout) * 0.02).astype(np.float32)
+
+
+def _lin(rng, sd, p, cin, cout, bias=True, gain=1.0):
+    sd[p + ".weight"] = _w(rng, (cout, cin), cin, gain)
+    if bias:
+        sd[p + ".bias"] = (rng.standard_normal(cout) * 0.02).astype(np.float32)
+
+
+def _resnet(rng, sd, p, cin, cout, temb):
+    _norm(rng, sd, p + ".norm1", cin)
+    _conv(rng, sd, p + ".conv1", cin, cout, 3)
+    if temb:
+        _lin(rng, sd, p + ".time_emb_proj", temb, cout, gain=0.3)
+    _norm(rng, sd, p + ".norm2", cout)
+    _conv(rng, sd, p + ".conv2", cout, cout, 3, gain=0.5)
+    if cin != cout:
+        _conv(rng, sd, p + ".conv_shortcut", cin, cout, 1)
+
+
+def _transformer(rng, sd, p, c, ctx):
+    _norm(rng, sd, p + ".norm", c)
+    _conv(rng, sd, p + ".proj_in", c, c, 1)
+    b = p + ".transformer_blocks.0"
+    for i, kv in ((1, c), (2, ctx)):
+        _norm(rng, sd, b + f".norm{i}", c)
+        _lin(rng, sd, b + f".attn{i}.to_q", c, c, bias=False, gain=1.5)
+        _lin(rng, sd, b + f".attn{i}.to_k", kv, c, bias=False, gain=1.5)
+        _lin(rng, sd, b + f".attn{i}.to_v", kv, c, bias=False)
+        _lin(rng, sd, b + f".attn{i}.to_out.0", c, c, gain=0.5)
+    _norm(rng, sd, b + ".norm3", c)
+    _lin(rng, sd, b + ".ff.net.0.proj", c, 8 * c)
+    _lin(rng, sd, b + ".ff.net.2", 4 * c, c, gain=0.5)
+    _conv(rng, sd, p + ".proj_out", c, c, 1, gain=0.5)
+
+
+def musetalk_unet_state_dict(seed: int = 4321) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    ch = UNET_CH
+    _conv(rng, sd, "conv_in", 8, ch[0], 3)
+    _lin(rng, sd, "time_embedding.linear_1", ch[0], 1280)
+    _lin(rng, sd, "time_embedding.linear_2", 1280, 1280)
+    cin = ch[0]
+    skip_ch = [ch[0]]
+    for i in range(4):
+        for j in range(2):
+            _resnet(rng, sd, f"down_blocks.{i}.resnets.{j}", cin, ch[i], 1280)
+            cin = ch[i]
+            if i < 3:
+                _transformer(rng, sd, f"down_blocks.{i}.attentions.{j}", ch[i], UNET_CTX)
+            skip_ch.append(cin)
+        if i < 3:
+            _conv(rng, sd, f"down_blocks.{i}.downsamplers.0.conv", cin, cin, 3)
+            skip_ch.append(cin)
+    _resnet(rng, sd, "mid_block.resnets.0", cin, cin, 1280)
+    _transformer(rng, sd, "mid_block.attentions.0", cin, UNET_CTX)
+    _resnet(rng, sd, "mid_block.resnets.1", cin, cin, 1280)
+    rev = ch[::-1]
+    for i in range(4):
+        for j in range(3):
+            sk = skip_ch.pop()
+            _resnet(rng, sd, f"up_blocks.{i}.resnets.{j}", cin + sk, rev[i], 1280)
+            cin = rev[i]
+            if i > 0:
+                _transformer(rng, sd, f"up_blocks.{i}.attentions.{j}", cin, UNET_CTX)
+        if i < 3:
+            _conv(rng, sd, f"up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
+    _norm(rng, sd, "conv_norm_out", cin)
+    _conv(rng, sd, "conv_out", cin, 4, 3, gain=0.5)
+    return sd
+
+
+def vae_decoder_state_dict(seed: int = 987) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    _conv(rng, sd, "post_quant_conv", 4, 4, 1)
+    top = VAE_CH[-1]
+    _conv(rng, sd, "decoder.conv_in", 4, top, 3)
+    _resnet(rng, sd, "decoder.mid_block.resnets.0", top, top, 0)
+    a = "decoder.mid_block.attentions.0"
+    _norm(rng, sd, a + ".group_norm", top)
+    for nme in ("to_q", "to_k", "to_v"):
+        _lin(rng, sd, a + "." + nme, top, top, gain=1.5 if nme != "to_v" else 1.0)
+    _lin(rng, sd, a + ".to_out.0", top, top, gain=0.5)
+    _resnet(rng, sd, "decoder.mid_block.resnets.1", top, top, 0)
+    cin = top
+    for i, c in enumerate(VAE_CH[::-1]):
+        for j in range(3):
+            _resnet(rng, sd, f"decoder.up_blocks.{i}.resnets.{j}", cin, c, 0)
+            cin = c
+        if i < 3:
+            _conv(rng, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
+    _norm(rng, sd, "decoder.conv_norm_out", cin)
+    _conv(rng, sd, "decoder.conv_out", cin, 3, 3, gain=0.7)
+    return sd
+
+
+def musetalk_latents(n_frames: int = 4, seed: int = 5) -> List[np.ndarray]:
+    """input_latent_list_cycle stand-in: per frame fp32 (1,8,32,32) = cat(masked, reference) VAE latents scaled by
+    0.18215 (avatars/musetalk/models/vae.py:110-122)."""
+    rng = np.random.default_rng(seed)
+    return [(rng.standard_normal((1, 8, 32, 32)) * 0.18215 * 4).astype(np.float32) for _ in range(n_frames)]
+
+
+def musetalk_whisper_feats(batch: int, seed: int = 11) -> np.ndarray:
+    """(B,50,384) audio feature stand-in with the value range of Whisper encoder states."""
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((batch, 50, 384)).astype(np.float32)

@@ -100,20 +100,27 @@ def time_embed(sd: SD, timesteps: Tensor) -> Tensor:
     return _linear(sd, "time_embedding.linear_2", t)
 
 
-def resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float) -> Tensor:
+def _tap(taps, name, t):
+    if taps is not None:
+        taps[name] = t.detach().clone()
+    return t
+
+
+def resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float, taps=None) -> Tensor:
     """diffusers ResnetBlock2D (output_scale_factor 1, no up/down)."""
-    h = F.silu(_gn(sd, p + ".norm1", x, groups, eps))
+    h = _tap(taps, p + ".norm1", F.silu(_gn(sd, p + ".norm1", x, groups, eps)))
     h = _conv(sd, p + ".conv1", h)
     if temb is not None:
         h = h + _linear(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
-    h = F.silu(_gn(sd, p + ".norm2", h, groups, eps))
+    _tap(taps, p + ".conv1", h)
+    h = _tap(taps, p + ".norm2", F.silu(_gn(sd, p + ".norm2", h, groups, eps)))
     h = _conv(sd, p + ".conv2", h)
     if (p + ".conv_shortcut.weight") in sd:
-        x = _conv(sd, p + ".conv_shortcut", x, pad=0)
-    return x + h
+        x = _tap(taps, p + ".conv_shortcut", _conv(sd, p + ".conv_shortcut", x, pad=0))
+    return _tap(taps, p + ".conv2", x + h)
 
 
-def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
+def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, taps=None) -> Tensor:
     """diffusers Attention (AttnProcessor2_0): q/k/v projections, scaled dot-product, to_out.0."""
     B, T, C = x.shape
     q = _linear(sd, p + ".to_q", x)
@@ -125,28 +132,40 @@ def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
     v = v.view(B, -1, heads, d).transpose(1, 2)
     o = F.scaled_dot_product_attention(q, k, v)            # scale = d ** -0.5
     o = o.transpose(1, 2).reshape(B, T, C)
+    _tap(taps, p + ".attn", o)            # (B, T, C) token-major
     return _linear(sd, p + ".to_out.0", o)
 
 
-def transformer2d(sd: SD, p: str, x: Tensor, ctx: Tensor) -> Tensor:
-    """diffusers Transformer2DModel (use_linear_projection False) with one BasicTransformerBlock."""
+def transformer2d(sd: SD, p: str, x: Tensor, ctx: Tensor, taps=None) -> Tensor:
+    """diffusers Transformer2DModel (use_linear_projection False) with one BasicTransformerBlock.
+    Token-major taps (B, T, C) are stored as (B, C, H, W) so they compare directly with the device tensors."""
     B, C, H, W = x.shape
+
+    def tk(name, t):      # (B, T, c) -> (B, c, H, W)
+        if taps is not None:
+            taps[name] = t.detach().reshape(B, H, W, -1).permute(0, 3, 1, 2).clone()
+        return t
+
     res = x
-    h = _gn(sd, p + ".norm", x, UNET_GROUPS, ATTN_GN_EPS)
-    h = _conv(sd, p + ".proj_in", h, pad=0)
+    h = _tap(taps, p + ".norm", _gn(sd, p + ".norm", x, UNET_GROUPS, ATTN_GN_EPS))
+    h = _tap(taps, p + ".proj_in", _conv(sd, p + ".proj_in", h, pad=0))
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = p + ".transformer_blocks.0"
-    n = _ln(sd, b + ".norm1", h)
-    h = attention(sd, b + ".attn1", n, n, UNET_HEADS) + h
-    n = _ln(sd, b + ".norm2", h)
-    h = attention(sd, b + ".attn2", n, ctx, UNET_HEADS) + h
-    n = _ln(sd, b + ".norm3", h)
-    g = _linear(sd, b + ".ff.net.0.proj", n)               # GEGLU
+    n = tk(b + ".norm1", _ln(sd, b + ".norm1", h))
+    at = {} if taps is not None else None
+    h = tk(b + ".attn1.to_out.0", attention(sd, b + ".attn1", n, n, UNET_HEADS, at) + h)
+    n = tk(b + ".norm2", _ln(sd, b + ".norm2", h))
+    h = tk(b + ".attn2.to_out.0", attention(sd, b + ".attn2", n, ctx, UNET_HEADS, at) + h)
+    if at:
+        for k, v in at.items():
+            tk(k, v)
+    n = tk(b + ".norm3", _ln(sd, b + ".norm3", h))
+    g = tk(b + ".ff.net.0.proj", _linear(sd, b + ".ff.net.0.proj", n))               # GEGLU
     a, gate = g.chunk(2, dim=-1)
-    h = _linear(sd, b + ".ff.net.2", a * F.gelu(gate)) + h
+    h = tk(b + ".ff.net.2", _linear(sd, b + ".ff.net.2", tk(b + ".ff.geglu", a * F.gelu(gate))) + h)
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     h = _conv(sd, p + ".proj_out", h, pad=0)
-    return h + res
+    return _tap(taps, p + ".proj_out", h + res)
 
 
 def positional_encoding(x: Tensor) -> Tensor:
@@ -164,21 +183,24 @@ def positional_encoding(x: Tensor) -> Tensor:
 # UNet2DConditionModel.forward
 # ---------------------------------------------------------------------------------------------
 def unet_forward(sd: SD, latent: Tensor, ctx: Tensor, timestep: int = 0,
-                 taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                 taps: Optional[Dict[str, Tensor]] = None, detail: Optional[str] = None) -> Tensor:
     """latent (B,8,32,32), ctx (B,50,384) (already position-encoded) -> (B,4,32,32)."""
     def tap(name, t):
         if taps is not None:
             taps[name] = t.detach().clone()
         return t
 
+    def dt(prefix):       # op-level taps only for blocks whose name starts with `detail`
+        return taps if (taps is not None and detail is not None and prefix.startswith(detail)) else None
+
     temb = time_embed(sd, torch.tensor([timestep])).expand(latent.shape[0], -1)
     h = tap("conv_in", _conv(sd, "conv_in", latent))
     skips: List[Tensor] = [h]
     for i in range(4):
         for j in range(2):
-            h = resnet(sd, f"down_blocks.{i}.resnets.{j}", h, temb, UNET_GROUPS, UNET_EPS)
+            h = resnet(sd, f"down_blocks.{i}.resnets.{j}", h, temb, UNET_GROUPS, UNET_EPS, dt(f"down_blocks.{i}.resnets.{j}"))
             if DOWN_HAS_ATTN[i]:
-                h = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", h, ctx)
+                h = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", h, ctx, dt(f"down_blocks.{i}.attentions.{j}"))
             skips.append(tap(f"down_blocks.{i}.{j}", h))
         if i < 3:
             h = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, pad=1)
@@ -189,9 +211,9 @@ def unet_forward(sd: SD, latent: Tensor, ctx: Tensor, timestep: int = 0,
     for i in range(4):
         for j in range(3):
             h = torch.cat([h, skips.pop()], dim=1)
-            h = resnet(sd, f"up_blocks.{i}.resnets.{j}", h, temb, UNET_GROUPS, UNET_EPS)
+            h = resnet(sd, f"up_blocks.{i}.resnets.{j}", h, temb, UNET_GROUPS, UNET_EPS, dt(f"up_blocks.{i}.resnets.{j}"))
             if UP_HAS_ATTN[i]:
-                h = transformer2d(sd, f"up_blocks.{i}.attentions.{j}", h, ctx)
+                h = transformer2d(sd, f"up_blocks.{i}.attentions.{j}", h, ctx, dt(f"up_blocks.{i}.attentions.{j}"))
             tap(f"up_blocks.{i}.{j}", h)
         if i < 3:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")

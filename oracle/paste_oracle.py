@@ -99,3 +99,31 @@ def paste_back_frame(pred_frame: np.ndarray, full_frame: np.ndarray, bbox) -> np
     res = resize_linear_u8(pred_frame.astype(np.uint8), (x2 - x1, y2 - y1))
     combine[y1:y2, x1:x2] = res
     return combine
+
+
+# ---------------------------------------------------------------------------------------------
+# MuseTalk paste-back: avatars/musetalk_avatar.py:154-164 + avatars/musetalk/myutil.py:4-25
+# ---------------------------------------------------------------------------------------------
+def blend_linear_u8(src1: np.ndarray, src2: np.ndarray, w1: np.ndarray, w2: np.ndarray) -> np.ndarray:
+    """cv2.blendLinear for 8UC3 restated from OpenCV's published algorithm (modules/imgproc/src/blend.cpp):
+    dst = saturate_cast<uchar>((src1*w1 + src2*w2) / (w1 + w2 + 1e-5f)), float32 arithmetic, cvRound
+    (round half to even).  PARITY UNPINNED (no OpenCV here)."""
+    f = np.float32
+    den = (w1.astype(f) + w2.astype(f)) + f(1e-5)
+    num = src1.astype(f) * w1.astype(f)[..., None] + src2.astype(f) * w2.astype(f)[..., None]
+    q = num / den[..., None]
+    return np.clip(np.rint(q), 0, 255).astype(np.uint8)
+
+
+def paste_blend_frame(pred_frame: np.ndarray, ori_frame: np.ndarray, bbox, mask_bgr: np.ndarray, crop_box) -> np.ndarray:
+    """MuseReal.paste_back_frame on explicit inputs (musetalk_avatar.py:154-164, myutil.py:4-25)."""
+    x1, y1, x2, y2 = [int(v) for v in bbox]
+    body = ori_frame.copy()
+    res = resize_linear_u8(np.ascontiguousarray(pred_frame).astype(np.uint8), (x2 - x1, y2 - y1))
+    x_s, y_s, x_e, y_e = [int(v) for v in crop_box]
+    face_large = body[y_s:y_e, x_s:x_e].copy()
+    face_large[y1 - y_s:y2 - y_s, x1 - x_s:x2 - x_s] = res
+    gray = mask_bgr[:, :, 0]            # cvtColor(BGR2GRAY) of a B=G=R image is the channel itself
+    mask_image = (gray / 255).astype(np.float32)
+    body[y_s:y_e, x_s:x_e] = blend_linear_u8(face_large, body[y_s:y_e, x_s:x_e], mask_image, 1 - mask_image)
+    return body

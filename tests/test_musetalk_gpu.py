@@ -1,0 +1,145 @@
+"""Parity of the HIP MuseTalk path (U-Net + VAE decoder, csrc/musetalk.hip + nn_kernels.hip) against the oracle
+(oracle/musetalk_oracle.py: a restatement of the diffusers graph - PARITY UNPINNED against diffusers itself, see
+its header) on seeded weights and inputs.
+
+Tolerances (fp16 activations / fp32 accumulate on the device vs the fp32 oracle; the reference itself runs this
+path in fp16, avatars/musetalk_avatar.py:62-64):
+  per tensor : relative L2 <= 1e-2 (measured ~1.5e-3)
+  latents    : relative L2 <= 1e-2 on the U-Net output
+  frames     : PSNR >= 45 dB and >= 99.9 % of the bytes within +-2 LSB of the oracle decode_latents (measured 60.5 dB, max 1 LSB)
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from livetalking_amd import synth  # noqa: E402
+from oracle import musetalk_oracle as M  # noqa: E402
+
+B = 2
+
+
+@pytest.fixture(scope="module")
+def mt():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    unet_sd = synth.musetalk_unet_state_dict()
+    vae_sd = synth.vae_decoder_state_dict()
+    eng = Engine(0)
+    eng.load_musetalk(unet_sd, vae_sd, max_frames=B)
+    yield eng, {k: torch.from_numpy(v) for k, v in unet_sd.items()}, {k: torch.from_numpy(v) for k, v in vae_sd.items()}
+    eng.close()
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-9))
+
+
+@pytest.mark.gpu
+def test_unet_and_vae_vs_oracle(mt):
+    eng, usd, vsd = mt
+    lat = np.concatenate(synth.musetalk_latents(B))
+    feat = synth.musetalk_whisper_feats(B)
+    taps = {}
+    with torch.no_grad():
+        pe = M.positional_encoding(torch.from_numpy(feat))
+        ref_lat = M.unet_forward(usd, torch.from_numpy(lat), pe, taps=taps, detail="down_blocks.0")
+        vtaps = {}
+        ref_img = M.vae_decode(vsd, ref_lat / M.VAE_SCALING, vtaps)
+    got_lat, got_img, got_frames = eng.musetalk_forward_host(lat, feat)
+
+    report = []
+
+    def check(name, ref, tol=1e-2, heads=None):
+        ref = ref.numpy()
+        shape = list(ref.shape)
+        if heads:      # padded heads on the device
+            d = shape[1] // heads
+            d16 = (d + 15) // 16 * 16
+            dev = eng.musetalk_debug_get(name, (shape[0], heads * d16, shape[2], shape[3]))
+            dev = dev.reshape(shape[0], heads, d16, shape[2], shape[3])[:, :, :d].reshape(shape)
+        else:
+            c16 = (shape[1] + 15) // 16 * 16
+            dev = eng.musetalk_debug_get(name, (shape[0], c16, shape[2], shape[3]))[:, :shape[1]]
+        r = rel_l2(dev, ref)
+        print(f"[mt] {name:70s} rel_l2={r:.3e} refmax={np.abs(ref).max():.3g}")
+        if not (r <= tol):
+            report.append(f"{name}: rel L2 {r:.3e}")
+
+    # op-level taps of the first down block (every kernel type appears there), then block-level taps
+    for name, t in taps.items():
+        if name.count(".") >= 3:
+            check(name, t, heads=8 if name.endswith(".attn") else None)
+    for name, t in taps.items():
+        if name.count(".") < 3:
+            check(name, t)
+    r = rel_l2(got_lat, ref_lat.numpy())
+    print(f"[mt] U-Net output rel_l2={r:.3e}")
+    assert r <= 1e-2, report
+    assert not report, "\n".join(report)
+
+    # VAE decoder, fed with the DEVICE's latents so that its error is measured on its own
+    with torch.no_grad():
+        vt2 = {}
+        ref_img2 = M.vae_decode(vsd, torch.from_numpy(got_lat) / M.VAE_SCALING, vt2)
+    # the device decoded its own fp16 latents; got_lat is their fp32 copy
+    for name, t in vt2.items():
+        shape = list(t.shape)
+        c16 = (shape[1] + 15) // 16 * 16
+        dev = eng.musetalk_debug_get(name, (shape[0], c16, shape[2], shape[3]))[:, :shape[1]]
+        rr = rel_l2(dev, t.numpy())
+        print(f"[mt] {name:70s} rel_l2={rr:.3e}")
+        if not (rr <= 1e-2):
+            report.append(f"{name}: rel L2 {rr:.3e}")
+    assert not report, "\n".join(report)
+    ri = rel_l2(got_img, ref_img2.numpy())
+    print(f"[mt] VAE image rel_l2={ri:.3e} (vs oracle on the same latents); end-to-end vs oracle {rel_l2(got_img, ref_img.numpy()):.3e}")
+    ref_frames = ((ref_img2 / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).round().astype(np.uint8)[..., ::-1]
+    d = np.abs(got_frames.astype(np.int32) - ref_frames.astype(np.int32))
+    mse = float((d.astype(np.float64) ** 2).mean())
+    psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    print(f"[mt] frames PSNR {psnr:.2f} dB, max {d.max()} LSB, within+-2: {float((d <= 2).mean()):.5f}")
+    assert psnr >= 45.0 and float((d <= 2).mean()) >= 0.999
+
+
+@pytest.mark.gpu
+def test_musetalk_infer_and_blend(mt):
+    """ltk_musetalk_infer (latent gather by mirror_index + PE + U-Net + VAE + uint8 BGR) equals the host-input hook on
+    the same frames, and ltk_paste_blend matches the oracle's paste_back_frame bit for bit."""
+    from oracle import paste_oracle
+    eng, usd, vsd = mt
+    n = 3
+    lats = synth.musetalk_latents(n)
+    frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(360, 640), box=160, seed=2)
+    face_boxes, crop_boxes, masks = [], [], []
+    rng = np.random.default_rng(3)
+    for i in range(n):
+        x1, y1 = 240 + int(rng.integers(-3, 4)), 100 + int(rng.integers(-3, 4))
+        x2, y2 = x1 + 150 + int(rng.integers(0, 9)), y1 + 170 + int(rng.integers(0, 9))
+        xs, ys, xe, ye = x1 - 30, y1 - 40, x2 + 30, y2 + 35
+        face_boxes.append((x1, y1, x2, y2)); crop_boxes.append((xs, ys, xe, ye))
+        m = np.zeros((ye - ys, xe - xs), np.float64)
+        m[(ye - ys) // 2:, 20:-20] = 255.0
+        # soft edge, like the Gaussian-blurred masks of avatars/musetalk/utils/blending.py:129-135
+        k = np.ones(15) / 15
+        m = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, m)
+        m = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, m)
+        m8 = np.clip(np.rint(m), 0, 255).astype(np.uint8)
+        masks.append(np.repeat(m8[:, :, None], 3, axis=2))
+    aid = eng.register_musetalk_avatar(lats, frames, face_boxes, masks, crop_boxes)
+    feat = synth.musetalk_whisper_feats(B, seed=21)
+    d_feat = torch.from_numpy(feat).cuda()
+    d_pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    index = 2          # frames mirror_index(3, 2) = 2, mirror_index(3, 3) = 2
+    eng.musetalk_infer([(aid, index, B, d_feat.data_ptr(), d_pred.data_ptr())])
+    idxs = [paste_oracle.mirror_index(n, index + i) for i in range(B)]
+    _, _, want = eng.musetalk_forward_host(np.concatenate([lats[i] for i in idxs]), feat)
+    got = d_pred.cpu().numpy()
+    assert np.array_equal(got, want), f"infer vs host hook: max diff {np.abs(got.astype(int) - want.astype(int)).max()}"
+    out = np.empty((360, 640, 3), np.uint8)
+    eng.paste_blend(aid, idxs[0], d_pred[0].data_ptr(), out)
+    ref = paste_oracle.paste_blend_frame(got[0], frames[idxs[0]], face_boxes[idxs[0]], masks[idxs[0]], crop_boxes[idxs[0]])
+    dd = np.abs(out.astype(int) - ref.astype(int))
+    print(f"[mt] paste_blend max diff {dd.max()}, differing bytes {(dd != 0).sum()}")
+    assert np.array_equal(out, ref)
