@@ -136,7 +136,26 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
  * cached frame under the avatar's mask.  out: uint8 [H][W][3] (device or host, as ltk_paste_back). */
 int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream);
 
+/* avatars/musetalk/whisper/audio2feature.py:15-23 Audio2Feature.__init__: the Whisper-tiny ENCODER
+ * (transformers WhisperModel(...).encoder.state_dict(): conv1, conv2, embed_positions, layers.{0..3}.*, layer_norm),
+ * fp32 host tensors.  The WhisperFeatureExtractor constants (n_fft 400, hop 160, 80 slaney mels, 30-s padding) are
+ * built in. */
+int ltk_whisper_load(ltk_engine* e, const ltk_named_tensor* encoder_sd, int n);
+
+/* avatars/audio_features/whisper.py:58-76 WhisperASR.run_step feature part: audio2feat
+ * (audio2feature.py:106-117: log-mel of the zero-padded 30-s window -> encoder with all 5 hidden states) and
+ * _feature2chunks (whisper.py:35-56, base_asr.py:91-133): frame i takes encoder rows
+ * [first_row + i*row_step, first_row + i*row_step + rows), index-clamped, each row = its 5 hidden states.
+ * pcm: host float32 [n_samples] (the concatenated l + 2B + r chunks).  d_out: device float32
+ * [batch][rows*5][384] (= the (50,384) whisper chunks at rows 10, first_row 2*(l/2), row_step 2). */
+int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, int first_row, int row_step, int rows,
+                     void* d_out, void* stream);
+
 /* ---- test / measurement hooks (not on the production call path) ---- */
+
+/* named tensor of the last Whisper step as [C][T] float32: "input_features", "hidden_states.0".."hidden_states.4",
+ * or an op name ("conv1", "layers.0.self_attn.out_proj", ...) */
+int ltk_whisper_debug_get(ltk_engine* e, const char* name, float* out, size_t n_floats);
 
 /* U-Net + VAE decoder on explicit inputs: latents host fp32 [B][8][32][32], feat host fp32 [B][50][384] (before
  * the positional encoding).  Outputs (any may be NULL): unet_out fp32 [B][4][32][32], image fp32 [B][3][256][256]

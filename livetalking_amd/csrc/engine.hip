@@ -185,6 +185,11 @@ struct ltk_engine {
     // musetalk
     MtGraph* mt = nullptr;
     int mt_max_frames = 0;
+    MtGraph* whisper = nullptr;           // Whisper-tiny encoder graph (Audio2Feature)
+    float* d_wbasis = nullptr;            // slaney mel basis [80][201] (n_fft 400, 0..8000 Hz)
+    float* d_wlogspec = nullptr;          // [80][3000]
+    float* d_wpcm = nullptr;              // staging, 30 s
+    int* d_wgmax = nullptr;
     float* d_pe = nullptr;                // PositionalEncoding table [50][384]
     float* d_mt_feat = nullptr;           // staging: fp32 [max_frames][50][384]
     float* d_mt_lat = nullptr;            // staging for the host-input hook: fp32 [max_frames][8][32][32]
@@ -506,9 +511,10 @@ double mel_to_hz(double m) {
     const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
     return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
-void build_mel_basis(std::vector<float>* basis, std::vector<int32_t>* lohi) {
-    const int n_mels = 80, n_bins = 401;
-    const double sr = 16000.0, f_lo = 55.0, f_hi = 7600.0;
+void build_mel_basis(std::vector<float>* basis, std::vector<int32_t>* lohi, int n_bins = 401, double f_lo = 55.0,
+                     double f_hi = 7600.0) {
+    const int n_mels = 80;
+    const double sr = 16000.0;
     std::vector<double> mel_f(n_mels + 2);
     const double m0 = hz_to_mel(f_lo), m1 = hz_to_mel(f_hi);
     for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (n_mels + 1));
@@ -583,6 +589,11 @@ void ltk_engine_destroy(ltk_engine* e) {
     for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
     for (auto& kv : e->mt_avatars) { (void)hipFree(kv.second.d_latents); (void)hipFree(kv.second.d_full); (void)hipFree(kv.second.d_masks); }
     if (e->mt) mt_graph_delete(e->mt);
+    if (e->whisper) mt_graph_delete(e->whisper);
+    if (e->d_wbasis) (void)hipFree(e->d_wbasis);
+    if (e->d_wlogspec) (void)hipFree(e->d_wlogspec);
+    if (e->d_wpcm) (void)hipFree(e->d_wpcm);
+    if (e->d_wgmax) (void)hipFree(e->d_wgmax);
     if (e->d_pe) (void)hipFree(e->d_pe);
     if (e->d_mt_feat) (void)hipFree(e->d_mt_feat);
     if (e->d_mt_lat) (void)hipFree(e->d_mt_lat);
@@ -1160,6 +1171,83 @@ int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, 
     *ms_per_pass = ms / iters;
     if (macs_per_pass) *macs_per_pass = mt_macs_per_frame(e->mt) * frames;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return LTK_OK;
+}
+
+// ================================================================================ Whisper audio features
+int ltk_whisper_load(ltk_engine* e, const ltk_named_tensor* encoder_sd, int n) {
+    if (!e || !encoder_sd || n <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->whisper) return fail(LTK_E_STATE, "a Whisper encoder is already loaded in this engine");
+    CHK(hipSetDevice(e->device));
+    MtGraph* wg = mt_graph_new();
+    if (mt_build_whisper_graph(wg, encoder_sd, n)) {
+        const std::string msg = mt_graph_error(wg);
+        mt_graph_delete(wg);
+        return fail(LTK_E_INVALID, "whisper: " + msg);
+    }
+    std::vector<float> basis;
+    std::vector<int32_t> lohi;
+    build_mel_basis(&basis, &lohi, 201, 0.0, 8000.0);     // WhisperFeatureExtractor.mel_filters (slaney, 80 x 201)
+    CHK(hipMalloc((void**)&e->d_wbasis, basis.size() * sizeof(float)));
+    CHK(hipMemcpy(e->d_wbasis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
+    CHK(hipMalloc((void**)&e->d_wlogspec, (size_t)80 * 3000 * sizeof(float)));
+    CHK(hipMalloc((void**)&e->d_wpcm, (size_t)480000 * sizeof(float)));
+    CHK(hipMalloc((void**)&e->d_wgmax, 16));
+    e->whisper = wg;
+    return LTK_OK;
+}
+
+int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, int first_row, int row_step, int rows, void* d_out,
+                     void* stream) {
+    if (!e || !pcm || !d_out || n_samples <= 0 || n_samples > 479000 || batch <= 0 || rows <= 0 || rows > 64)
+        return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->whisper) return fail(LTK_E_STATE, "ltk_whisper_load has not been called");
+    CHK(hipSetDevice(e->device));
+    hipEvent_t done;
+    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        hipStream_t s = e->compute;
+        CHK(hipMemcpyAsync(e->d_wpcm, pcm, (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, s));
+        int cbt, cb0;
+        f16* mel = mt_latent_in(e->whisper, &cbt);
+        launch_whisper_logmel(e->d_wpcm, n_samples, e->d_wbasis, e->d_wlogspec, e->d_wgmax, mel, s);
+        rc = mt_run(e->whisper, 1, e->d_partial, e->partial_cap, s);
+        if (rc) rc = fail(LTK_E_INVALID, std::string("whisper: ") + mt_graph_error(e->whisper));
+        if (!rc) {
+            WhisperStates st;
+            for (int i = 0; i < 5; ++i) { st.p[i] = mt_whisper_state(e->whisper, i, &cbt, &cb0); st.cb0[i] = cb0; }
+            launch_whisper_chunks(st, 1500, batch, first_row, row_step, rows, (float*)d_out, s);
+            if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "whisper kernels failed to launch");
+        }
+        if (!rc && hipEventRecord(done, s) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
+    }
+    if (!rc) {
+        if (stream && hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed");
+        if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+    }
+    (void)hipEventDestroy(done);
+    return rc;
+}
+
+int ltk_whisper_debug_get(ltk_engine* e, const char* name, float* out, size_t n_floats) {
+    if (!e || !name || !out) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->whisper) return fail(LTK_E_STATE, "ltk_whisper_load has not been called");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    int C, ld, coff, H, W;
+    f16* t = (std::string(name) == "input_features") ? mt_named(e->whisper, "input_features", &C, &ld, &coff, &H, &W) : mt_named(e->whisper, name, &C, &ld, &coff, &H, &W);
+    if (!t) return fail(LTK_E_STATE, std::string("no Whisper tensor named ") + name);
+    const size_t cnt = (size_t)C * H * W;
+    if (cnt != n_floats) return fail(LTK_E_INVALID, "size mismatch: tensor has " + std::to_string(cnt) + " floats");
+    float* d_tmp = nullptr;
+    CHK(hipMalloc((void**)&d_tmp, cnt * sizeof(float)));
+    launch_nhwc_to_nchw_f32(t, 1, H, W, ld, coff, C, d_tmp, e->compute);
+    CHK(hipStreamSynchronize(e->compute));
+    CHK(hipMemcpy(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_tmp);
     return LTK_OK;
 }
 

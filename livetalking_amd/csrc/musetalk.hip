@@ -66,7 +66,7 @@ struct MtTensor {
     int P() const { return H * W; }
 };
 
-enum MtOpType { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU };
+enum MtOpType { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_ADDPOS };
 
 struct MtOp {
     MtOpType type;
@@ -96,6 +96,7 @@ struct MtGraph {
     double macs = 0;                          // conv / linear MACs per frame (attention excluded)
     std::string err;
     MtTensor *t_latent = nullptr, *t_ctx = nullptr, *t_unet_out = nullptr, *t_vae_out = nullptr;
+    MtTensor* whisper_states = nullptr;
 
     MtTensor alloc(int C, int H, int W) {
         MtTensor t;
@@ -122,24 +123,32 @@ struct MtGraph {
     // conv / linear: weight [Cout][Cin][k][k] fp32 host, bias [Cout] or null
     int add_conv(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int k, int stride, int pad,
                  const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
+        return add_conv2(name, w, bias, Cin, Cout, k, k, stride, stride, pad, pad, x, y, res, act, ups);
+    }
+    // rectangular kernel / stride (Conv1d over a [T][1] token map: kh x 1)
+    int add_conv2(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                  int ph, int pw, const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
+        const int k = kh, stride = sh;
+        const int kk = kh * kw;
+        (void)k;
         const int CoutP = up16(Cout);
         const int CinR = Cin;
         Cin = up16(Cin);                    // whole channel blocks on both sides (zero weights for the padding)
         std::vector<float> wp;
         const float* wuse = w;
         if (CoutP != Cout || Cin != CinR) {
-            wp.assign((size_t)CoutP * Cin * k * k, 0.f);
+            wp.assign((size_t)CoutP * Cin * kk, 0.f);
             for (int co = 0; co < Cout; ++co)
                 for (int ci = 0; ci < CinR; ++ci)
-                    memcpy(&wp[((size_t)co * Cin + ci) * k * k], &w[((size_t)co * CinR + ci) * k * k], (size_t)k * k * sizeof(float));
+                    memcpy(&wp[((size_t)co * Cin + ci) * kk], &w[((size_t)co * CinR + ci) * kk], (size_t)kk * sizeof(float));
             wuse = wp.data();
         }
-        macs += (double)CinR * Cout * k * k * (stride == 2 ? y.P() : (ups ? x.P() : y.P()));
+        macs += (double)CinR * Cout * kk * (stride == 2 ? y.P() : (ups ? x.P() : y.P()));
         std::vector<float> sc(CoutP, 1.f), sf(CoutP, 0.f);
         if (bias) memcpy(sf.data(), bias, Cout * sizeof(float));
         ConvPlan p;
         std::string e;
-        int rc = conv_plan_create(&p, wuse, Cin, CoutP, k, k, stride, stride, pad, pad, false, 0, sc.data(), sf.data(), &e, x.P());
+        int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, 0, sc.data(), sf.data(), &e, x.P());
         if (rc) { err = name + ": " + e; return -1; }
         plans.push_back(p);
         MtOp op;
@@ -532,6 +541,76 @@ int mt_build_vae(MtGraph& g, const ltk_named_tensor* t, int n, const MtTensor& z
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ Whisper encoder
+// transformers WhisperEncoder (whisper-tiny: d 384, 4 layers, 6 heads, ffn 1536), the Audio2Feature model
+// (avatars/musetalk/whisper/audio2feature.py:15-23,106-117).  In-tree statement of the same encoder:
+// avatars/musetalk/whisper/whisper/model.py (AudioEncoder, ResidualAttentionBlock).  state_dict = model.encoder's.
+// x: log-mel [80][3000] as a [3000][1] token map.  states[5] = hidden_states (embeddings, layers 0-2, final LN).
+int mt_build_whisper(MtGraph& g, const ltk_named_tensor* t, int n, MtTensor* mel_in, MtTensor states[5], int* pos_vec) {
+    SD sd{t, n, ""};
+    const int D = 384, L = 4, HEADS = 6, FF = 1536, T0 = 3000, T = 1500;
+    *mel_in = g.alloc(80, T0, 1);
+    g.named["input_features"] = *mel_in;
+    const float* w1 = sd.get("conv1.weight", (size_t)D * 80 * 3);
+    const float* b1 = sd.get("conv1.bias", D);
+    const float* w2 = sd.get("conv2.weight", (size_t)D * D * 3);
+    const float* b2 = sd.get("conv2.bias", D);
+    const float* pos = sd.get("embed_positions.weight", (size_t)T * D);
+    if (!w1 || !b1 || !w2 || !b2 || !pos) { g.err = sd.err; return -1; }
+    MtTensor c1 = g.alloc(D, T0, 1), h = g.alloc(D, T, 1);
+    if (g.add_conv2("conv1", w1, b1, 80, D, 3, 1, 1, 1, 1, 0, *mel_in, c1, nullptr, 2, 0)) return -1;     // GELU
+    if (g.add_conv2("conv2", w2, b2, D, D, 3, 1, 2, 1, 1, 0, c1, h, nullptr, 2, 0)) return -1;            // stride 2, GELU
+    *pos_vec = g.add_vec(pos, T * D);
+    {
+        MtOp op;
+        op.type = OP_ADDPOS; op.name = "embed_positions"; op.x = h; op.y = h; op.gamma = *pos_vec;
+        g.ops.push_back(op);
+        g.named["embed_positions"] = h;
+    }
+    states[0] = h;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "layers." + std::to_string(l);
+        MtTensor n1 = g.alloc(D, T, 1), h1 = g.alloc(D, T, 1);
+        if (g.add_ln(p + ".self_attn_layer_norm", sd, p + ".self_attn_layer_norm", h, n1, 1e-5f)) return -1;
+        // WhisperAttention: q (bias, scaled by d^-0.5), k (no bias), v (bias), out (bias)
+        const int d = D / HEADS;
+        const float scale = 1.0f / sqrtf((float)d);
+        const float* wq = sd.get(p + ".self_attn.q_proj.weight", (size_t)D * D);
+        const float* bq = sd.get(p + ".self_attn.q_proj.bias", D);
+        const float* wk = sd.get(p + ".self_attn.k_proj.weight", (size_t)D * D);
+        const float* wv = sd.get(p + ".self_attn.v_proj.weight", (size_t)D * D);
+        const float* bv = sd.get(p + ".self_attn.v_proj.bias", D);
+        const float* wo = sd.get(p + ".self_attn.out_proj.weight", (size_t)D * D);
+        const float* bo = sd.get(p + ".self_attn.out_proj.bias", D);
+        if (!wq || !bq || !wk || !wv || !bv || !wo || !bo) { g.err = sd.err; return -1; }
+        std::vector<float> wqs((size_t)D * D), bqs(D);
+        for (size_t i = 0; i < wqs.size(); ++i) wqs[i] = wq[i] * scale;
+        for (int i = 0; i < D; ++i) bqs[i] = bq[i] * scale;
+        MtTensor q = g.alloc(D, T, 1), k = g.alloc(D, T, 1), v = g.alloc(D, T, 1), o = g.alloc(D, T, 1);
+        if (g.add_conv(p + ".self_attn.q_proj", wqs.data(), bqs.data(), D, D, 1, 1, 0, n1, q, nullptr, 0, 0)) return -1;
+        if (g.add_conv(p + ".self_attn.k_proj", wk, nullptr, D, D, 1, 1, 0, n1, k, nullptr, 0, 0)) return -1;
+        if (g.add_conv(p + ".self_attn.v_proj", wv, bv, D, D, 1, 1, 0, n1, v, nullptr, 0, 0)) return -1;
+        g.add_attn(p + ".self_attn", q, k, v, o, HEADS, d);
+        if (g.add_conv(p + ".self_attn.out_proj", wo, bo, D, D, 1, 1, 0, o, h1, &h, 0, 0)) return -1;
+        MtTensor n2 = g.alloc(D, T, 1), f1 = g.alloc(FF, T, 1), h2 = g.alloc(D, T, 1);
+        if (g.add_ln(p + ".final_layer_norm", sd, p + ".final_layer_norm", h1, n2, 1e-5f)) return -1;
+        const float* wf1 = sd.get(p + ".fc1.weight", (size_t)FF * D);
+        const float* bf1 = sd.get(p + ".fc1.bias", FF);
+        const float* wf2 = sd.get(p + ".fc2.weight", (size_t)D * FF);
+        const float* bf2 = sd.get(p + ".fc2.bias", D);
+        if (!wf1 || !bf1 || !wf2 || !bf2) { g.err = sd.err; return -1; }
+        if (g.add_conv(p + ".fc1", wf1, bf1, D, FF, 1, 1, 0, n2, f1, nullptr, 2, 0)) return -1;               // GELU
+        if (g.add_conv(p + ".fc2", wf2, bf2, FF, D, 1, 1, 0, f1, h2, &h1, 0, 0)) return -1;
+        h = h2;
+        if (l + 1 < L) states[l + 1] = h;
+    }
+    MtTensor fin = g.alloc(D, T, 1);
+    if (g.add_ln("layer_norm", sd, "layer_norm", h, fin, 1e-5f)) return -1;
+    states[4] = fin;
+    for (int i = 0; i < 5; ++i) g.named["hidden_states." + std::to_string(i)] = states[i];
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ allocate / run / free
 int mt_graph_alloc(MtGraph& g, int frames) {
     g.frames = frames;
@@ -605,6 +684,9 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                 if (rc) { g.err = op.name + ": attention launch failed (head dim " + std::to_string(op.d16) + ")"; return rc; }
                 break;
             }
+            case OP_ADDPOS:
+                launch_add_pos(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), g.vecs[op.gamma], s);
+                break;
             case OP_GEGLU:
                 launch_geglu(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), g.bufs[op.y.buf], op.y.ld / 16,
                              op.y.coff / 16, s);
@@ -621,6 +703,7 @@ void mt_graph_delete(MtGraph* g) {
     if (!g) return;
     mt_graph_free(*g);
     delete g->t_latent; delete g->t_ctx; delete g->t_unet_out; delete g->t_vae_out;
+    delete[] g->whisper_states;
     delete g;
 }
 const char* mt_graph_error(const MtGraph* g) { return g->err.c_str(); }
@@ -642,6 +725,18 @@ f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, 
     if (it == g->named.end()) return nullptr;
     const MtTensor& t = it->second;
     *C = t.C; *ld = t.ld; *coff = t.coff; *H = t.H; *W = t.W;
+    return g->bufs[t.buf];
+}
+int mt_build_whisper_graph(MtGraph* g, const ltk_named_tensor* sd, int n) {
+    g->t_latent = new MtTensor();                       // reused as the log-mel input tensor
+    g->whisper_states = new MtTensor[5];
+    int pos_vec = -1;
+    if (mt_build_whisper(*g, sd, n, g->t_latent, g->whisper_states, &pos_vec)) return -1;
+    return mt_graph_alloc(*g, 1);
+}
+f16* mt_whisper_state(MtGraph* g, int i, int* cbt, int* cb0) {
+    const MtTensor& t = g->whisper_states[i];
+    *cbt = t.ld / 16; *cb0 = t.coff / 16;
     return g->bufs[t.buf];
 }
 double mt_macs_per_frame(const MtGraph* g) { return g->macs; }

@@ -49,4 +49,11 @@ struct OutList64 { uint8_t* p[64]; };
 // vae.py:104-107: (x/2+0.5).clamp(0,1) -> *255 -> round-half-even -> uint8, RGB -> BGR, NHWC [256][256][3]
 void launch_vae_post(const f16* x, int x_cbt, int nframes, int P, const OutList64& out, float* out_f32_nchw, hipStream_t s);
 
+// ---- Whisper front end / feature slicing (MuseTalk audio features)
+// pcm device fp32 [n_samples] (<= 30 s); basis fp32 [80][201]; logspec scratch fp32 [80][3000]; gmax scratch int;
+// y: CB16 [5][3000][16] log-mel features
+void launch_whisper_logmel(const float* d_pcm, int n_samples, const float* d_basis, float* d_logspec, int* d_gmax, f16* y, hipStream_t s);
+struct WhisperStates { const f16* p[5]; int cb0[5]; };     // each state: CB16 [cbt >= 24][T][16], first block cb0 (buffers are 24 blocks wide)
+void launch_whisper_chunks(const WhisperStates& st, int T, int batch, int first_row, int row_step, int rows, float* out, hipStream_t s);
+
 }  // namespace ltk

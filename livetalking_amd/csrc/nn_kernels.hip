@@ -514,4 +514,102 @@ void launch_vae_post(const f16* x, int x_cbt, int nframes, int P, const OutList6
     hipLaunchKernelGGL(vae_post_kernel, dim3((P + 255) / 256, nframes), dim3(256), 0, s, x, x_cbt, P, out, out_f32_nchw);
 }
 
+// =============================================================================================== Whisper front end
+// transformers WhisperFeatureExtractor (the Audio2Feature.feature_extractor of avatars/musetalk/whisper/
+// audio2feature.py:20,107-111; same arithmetic as the vendored avatars/musetalk/whisper/whisper/audio.py:92-127):
+// zero-pad to 30 s, STFT n_fft 400 / hop 160 / periodic Hann / centre reflect padding, power spectrum, 80 slaney
+// mel bins, log10(max(1e-10,.)), drop the last frame, max(x, global_max - 8), (x + 4) / 4  ->  (80, 3000).
+// Frames whose window lies entirely in the zero padding are the constant -10 before the global step.
+constexpr int kWNfft = 400, kWHop = 160, kWBins = 201, kWMels = 80, kWFrames = 3000;
+
+__global__ __launch_bounds__(256) void whisper_logmel_kernel(const float* __restrict__ pcm, int n_samples,
+                                                              const float* __restrict__ basis, float* __restrict__ logspec,
+                                                              int* __restrict__ gmax_bits) {
+    __shared__ double frame[kWNfft];
+    __shared__ double tw_c[kWNfft];
+    __shared__ double tw_s[kWNfft];
+    __shared__ double power[kWBins + 7];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    for (int n = tid; n < kWNfft; n += 256) {
+        int i = t * kWHop - kWNfft / 2 + n;
+        if (i < 0) i = -i;                                   // reflect (np.pad / torch.stft pad_mode="reflect")
+        const double x = (i < n_samples) ? (double)pcm[i] : 0.0;
+        double sn, cs;
+        sincospi(2.0 * (double)n / (double)kWNfft, &sn, &cs);
+        frame[n] = x * (0.5 - 0.5 * cs);
+        tw_c[n] = cs;
+        tw_s[n] = sn;
+    }
+    __syncthreads();
+    if (tid < kWBins) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int n = 0; n < kWNfft; ++n) {
+            const double v = frame[n];
+            re += v * tw_c[idx];
+            im -= v * tw_s[idx];
+            idx += tid;
+            if (idx >= kWNfft) idx -= kWNfft;
+        }
+        power[tid] = re * re + im * im;
+    }
+    __syncthreads();
+    if (tid < kWMels) {
+        double acc = 0.0;
+        for (int k = 0; k < kWBins; ++k) acc += (double)basis[tid * kWBins + k] * power[k];
+        const float v = (float)log10(fmax(acc, 1e-10));
+        logspec[(size_t)tid * kWFrames + t] = v;
+        // float max through an int atomic: v >= -10, so v + 16 is positive and its bit pattern is monotonic
+        atomicMax(gmax_bits, __float_as_int(v + 16.0f));
+    }
+}
+
+__global__ __launch_bounds__(256) void whisper_logmel_finish_kernel(const float* __restrict__ logspec, int n_active,
+                                                                     const int* __restrict__ gmax_bits, f16* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // (cb, frame, half)
+    if (i >= 5 * kWFrames * 2) return;
+    const int half = i & 1, t = (i >> 1) % kWFrames, cb = (i >> 1) / kWFrames;
+    const float gmax = fmaxf(__int_as_float(*gmax_bits) - 16.0f, -10.0f);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int m = cb * 16 + half * 8 + c;
+        float v = (t < n_active) ? logspec[(size_t)m * kWFrames + t] : -10.0f;
+        v = fmaxf(v, gmax - 8.0f);
+        o[c] = (f16)((v + 4.0f) / 4.0f);
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)cb * kWFrames + t) * 16 + half * 8) = o;
+}
+
+void launch_whisper_logmel(const float* d_pcm, int n_samples, const float* d_basis, float* d_logspec, int* d_gmax, f16* y,
+                           hipStream_t s) {
+    int n_active = (n_samples + kWNfft / 2 + kWHop - 1) / kWHop + 1;
+    if (n_active > kWFrames) n_active = kWFrames;
+    (void)hipMemsetAsync(d_gmax, 0, sizeof(int), s);      // bits of +0.0f == "-16" in the shifted domain
+    hipLaunchKernelGGL(whisper_logmel_kernel, dim3(n_active), dim3(256), 0, s, d_pcm, n_samples, d_basis, d_logspec, d_gmax);
+    hipLaunchKernelGGL(whisper_logmel_finish_kernel, dim3((5 * kWFrames * 2 + 255) / 256), dim3(256), 0, s, d_logspec, n_active, d_gmax, y);
+}
+
+// avatars/audio_features/whisper.py:35-56 + base_asr.py:91-133: frame i takes encoder rows
+// [first_row + i*row_step, +rows) (clamped), each row = the 5 hidden states -> out fp32 [batch][rows*5][384]
+__global__ __launch_bounds__(256) void whisper_chunks_kernel(const WhisperStates st, int T, int batch, int first_row, int row_step,
+                                                              int rows, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (frame, row, state, c8)
+    const int total = batch * rows * 5 * 48;
+    if (i >= total) return;
+    const int c8 = i % 48, s5 = (i / 48) % 5, r = (i / 240) % rows, f = i / (240 * rows);
+    int row = first_row + f * row_step + r;
+    row = min(max(row, 0), T - 1);
+    const f16x8 v = *reinterpret_cast<const f16x8*>(st.p[s5] + ((size_t)(st.cb0[s5] + (c8 >> 1)) * T + row) * 16 + (c8 & 1) * 8);
+    float* o = out + (((size_t)f * rows + r) * 5 + s5) * 384 + c8 * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (float)v[c];
+}
+
+void launch_whisper_chunks(const WhisperStates& st, int T, int batch, int first_row, int row_step, int rows, float* out, hipStream_t s) {
+    const int total = batch * rows * 5 * 48;
+    hipLaunchKernelGGL(whisper_chunks_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, T, batch, first_row, row_step, rows, out);
+}
+
 }  // namespace ltk

@@ -190,6 +190,24 @@ class Engine:
         _lib.check(self._lib.ltk_musetalk_time(self._h, int(frames), int(iters), C.byref(ms), C.byref(macs)))
         return ms.value, macs.value
 
+    # ------------------------------------------------------------------ whisper audio features
+    def load_whisper(self, encoder_sd: Dict[str, object]):
+        """audio2feature.py:15-23: `encoder_sd` = WhisperModel.from_pretrained(...).encoder.state_dict()."""
+        arr, n, keep = self._named_tensors(encoder_sd)
+        _lib.check(self._lib.ltk_whisper_load(self._h, arr, n))
+        del keep
+
+    def whisper_step(self, pcm: np.ndarray, batch: int, first_row: int, d_out_ptr: int, row_step: int = 2, rows: int = 10,
+                     stream: int = 0):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        _lib.check(self._lib.ltk_whisper_step(self._h, pcm.ctypes.data, pcm.shape[0], int(batch), int(first_row), int(row_step),
+                                              int(rows), C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def whisper_debug_get(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float32)
+        _lib.check(self._lib.ltk_whisper_debug_get(self._h, name.encode(), out.ctypes.data, out.size))
+        return out
+
     # ------------------------------------------------------------------ test / measurement hooks
     def wav2lip_forward_host(self, mel: np.ndarray, face6: np.ndarray) -> np.ndarray:
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, 80, 16)
