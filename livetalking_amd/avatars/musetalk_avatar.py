@@ -1,0 +1,141 @@
+"""HIP-backed drop-in for avatars/musetalk_avatar.py.
+
+Module contract the reference's app.py relies on (app.py:128-143,99):
+  load_model() -> model handle                    (musetalk_avatar.py:57-67)
+  load_avatar(avatar_id) -> avatar tuple          (musetalk_avatar.py:69-91)
+  warm_up(batch_size, model)                      (musetalk_avatar.py:93-108)
+  @register("avatar", "musetalk") class MuseReal(BaseAvatar) with
+  inference_batch(index, audiofeat_batch) and paste_back_frame(pred_frame, idx)   (musetalk_avatar.py:110-164)
+
+Underneath: the model handle owns a per-GPU Engine with the U-Net + VAE decoder program and the Whisper encoder;
+the avatar's latents, frames and masks are uploaded to HBM once; `inference_batch` returns device handles (uint8
+256x256x3 BGR crops, already rounded the way vae.decode_latents does); `paste_back_frame` blends on the GPU and
+returns the writable C-contiguous uint8 (H,W,3) array the reference returns.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import pickle
+import threading
+
+import numpy as np
+
+from ..engine import Engine
+from ..hostshim import BaseAvatar, register
+from .audio_features.whisper import Audio2Feature, WhisperASR
+
+
+class MuseTalkModel:
+    """Opaque `model` object (the reference's tuple vae, unet, pe, timesteps, audio_processor)."""
+
+    def __init__(self, engine: Engine, audio_processor: Audio2Feature):
+        self.engine = engine
+        self.audio_processor = audio_processor
+        self._avatars = {}
+        self._lock = threading.Lock()
+
+    def avatar_id(self, avatar) -> int:
+        frame_list, mask_list, coord_list, mask_coords_list, latent_list = avatar
+        key = id(latent_list)
+        with self._lock:
+            aid = self._avatars.get(key)
+            if aid is None:
+                aid = self.engine.register_musetalk_avatar(latent_list, frame_list, coord_list, mask_list, mask_coords_list)
+                self._avatars[key] = aid
+            return aid
+
+
+def _device_index() -> int:
+    return int(os.environ.get("LTK_DEVICE", "0"))
+
+
+def load_model(unet_state_dict=None, vae_state_dict=None, whisper_encoder_state_dict=None, max_frames=None, device=None):
+    """The reference reads models/musetalkV15/unet.pth, models/sd-vae and models/whisper
+    (avatars/musetalk/utils/utils.py:16-37, audio2feature.py:15-23); state dicts may be passed directly (tests and
+    the bench use seeded synthetic weights: none of those checkpoints exists in the reference tree)."""
+    import torch
+    if unet_state_dict is None:
+        unet_state_dict = torch.load(os.path.join("models", "musetalkV15", "unet.pth"), map_location="cpu")
+    if vae_state_dict is None:
+        from safetensors.torch import load_file   # sd-vae ships diffusion_pytorch_model.safetensors / .bin
+        p = os.path.join("models", "sd-vae", "diffusion_pytorch_model.safetensors")
+        vae_state_dict = load_file(p) if os.path.exists(p) else torch.load(p.replace(".safetensors", ".bin"), map_location="cpu")
+    vae_state_dict = {k: v for k, v in vae_state_dict.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    dev = _device_index() if device is None else int(device)
+    if max_frames is None:
+        max_frames = int(os.environ.get("LTK_MT_MAX_FRAMES", "16"))
+    eng = Engine(dev)
+    eng.load_musetalk(unet_state_dict, vae_state_dict, max_frames=max_frames)
+    ap = Audio2Feature(eng, whisper_encoder_state_dict)
+    return MuseTalkModel(eng, ap)
+
+
+def read_imgs(img_list):
+    import cv2  # same third-party reader the reference uses (utils/image.py:14-24)
+    return [cv2.imread(p) for p in img_list]
+
+
+def load_avatar(avatar_id):
+    import torch
+    avatar_path = f"./data/avatars/{avatar_id}"
+
+    def numbered(d):
+        files = glob.glob(os.path.join(d, "*.[jpJP][pnPN]*[gG]"))
+        return sorted(files, key=lambda x: int(os.path.splitext(os.path.basename(x))[0]))
+
+    input_latent_list_cycle = torch.load(f"{avatar_path}/latents.pt")
+    with open(f"{avatar_path}/coords.pkl", "rb") as f:
+        coord_list_cycle = pickle.load(f)
+    frame_list_cycle = read_imgs(numbered(f"{avatar_path}/full_imgs"))
+    with open(f"{avatar_path}/mask_coords.pkl", "rb") as f:
+        mask_coords_list_cycle = pickle.load(f)
+    mask_list_cycle = read_imgs(numbered(f"{avatar_path}/mask"))
+    return frame_list_cycle, mask_list_cycle, coord_list_cycle, mask_coords_list_cycle, input_latent_list_cycle
+
+
+def warm_up(batch_size, model):
+    """One forward on ones, as the reference does (musetalk_avatar.py:93-108)."""
+    n = min(batch_size, model.engine.mt_max_frames)
+    model.engine.musetalk_forward_host(np.ones((n, 8, 32, 32), np.float32), np.ones((n, 50, 384), np.float32),
+                                       want_image=False, want_frames=False)
+
+
+@register("avatar", "musetalk")
+class MuseReal(BaseAvatar):
+    def __init__(self, opt, model, avatar):
+        super().__init__(opt)
+        self.model = model
+        (self.frame_list_cycle, self.mask_list_cycle, self.coord_list_cycle, self.mask_coords_list_cycle,
+         self.input_latent_list_cycle) = avatar
+        self._aid = model.avatar_id(avatar)
+        h, w = self.frame_list_cycle[0].shape[:2]
+        self._frame_hw = (int(h), int(w))
+        self.asr = WhisperASR(opt, self, model.audio_processor)
+        self.asr.warm_up()
+
+    def inference_batch(self, index, audiofeat_batch):
+        """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for bank index
+        mirror_index(len, index+i)."""
+        import torch
+        dev = torch.device("cuda", self.model.engine.device)
+        if isinstance(audiofeat_batch, torch.Tensor):
+            feat = audiofeat_batch.to(device=dev, dtype=torch.float32).contiguous()
+        else:                                               # list of (50,384) arrays from a foreign ASR
+            feat = torch.from_numpy(np.ascontiguousarray(np.stack(audiofeat_batch), dtype=np.float32)).to(dev)
+        B = self.batch_size
+        if feat.shape[0] != B:
+            raise ValueError(f"expected {B} whisper chunks, got {feat.shape[0]}")
+        pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=dev)
+        self.model.engine.musetalk_infer([(self._aid, int(index), B, feat.data_ptr(), pred.data_ptr())])
+        return [pred[i] for i in range(B)]
+
+    def paste_back_frame(self, pred_frame, idx: int):
+        import torch
+        if not isinstance(pred_frame, torch.Tensor):
+            pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
+                torch.device("cuda", self.model.engine.device))
+        h, w = self._frame_hw
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        self.model.engine.paste_blend(self._aid, int(idx), pred_frame.data_ptr(), out)
+        return out
