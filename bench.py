@@ -56,6 +56,82 @@ def cpu_baseline(batch: int, budget_s: float = 20.0):
             "kind": "port", "sample": f"{n} x inference_batch(B={batch}) fp32 torch-CPU oracle, seeded synthetic weights/bank/audio"}
 
 
+def main_musetalk(args):
+    """BASELINE.json configs[2]: MuseTalk (Whisper audio feat + U-Net + VAE decoder), 1 session, 1 GPU.  A step =
+    one MuseReal.inference_batch-equivalent pass (latent gather + PE + U-Net + VAE decode + uint8 BGR) over
+    sessions x batch frames with latents, weights and whisper chunks resident in HBM; the Whisper step
+    (run_step's work, outside inferfps in the reference too) is timed separately."""
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    from livetalking_amd import synth
+    from livetalking_amd.engine import Engine
+
+    S, B = args.sessions, args.batch
+    fps_step = S * B
+    eng = Engine(local_rank)
+    eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=min(fps_step, 64))
+    n = 8
+    lats = synth.musetalk_latents(n)
+    frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(720, 1280), box=320, seed=0)
+    coords = [(480, 200, 800, 520)] * n
+    crops = [(400, 120, 880, 600)] * n
+    masks = [np.full((480, 480, 3), 128, np.uint8)] * n
+    aid = eng.register_musetalk_avatar(lats, frames, coords, masks, crops)
+    d_feat = torch.from_numpy(synth.musetalk_whisper_feats(fps_step)).cuda().reshape(S, B, 50, 384)
+    d_pred = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+
+    def step(i):
+        eng.musetalk_infer([(aid, i * B + 3 * s, B, d_feat[s].data_ptr(), d_pred[s].data_ptr()) for s in range(S)])
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.steps * fps_step / elapsed
+    nt = min(fps_step, 64)
+    ms, macs = eng.musetalk_time(nt, 3)
+    achieved = 2.0 * macs / (ms * 1e-3) / 1e12
+    if rank == 0:
+        out = {"metric": "inferfps", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": f"musetalk (U-Net + VAE decoder), {S} session(s)/GPU, {B}-frame batch, fp16 activations / fp32 accumulate",
+                          "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": fps_step,
+                          "parallelism": f"session-sharded x{world} (no collective)"},
+               "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
+                            "kernel": "conv3_kernel / conv_mfma_kernel (U-Net + VAE conv and linear layers; attention excluded from the flop count)",
+                            "pass_ms": round(ms, 4), "flops_per_frame": 2.0 * macs / nt}}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +140,11 @@ def main():
     ap.add_argument("--sessions", type=int, default=1, help="sessions coalesced per launch on each GPU")
     ap.add_argument("--batch", type=int, default=16, help="frames per session per step (opt.batch_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=("wav2lip", "musetalk"), default="wav2lip",
+                    help="wav2lip = BASELINE.json configs[1] (default, the driver's line); musetalk = configs[2]")
     args = ap.parse_args()
+    if args.model == "musetalk":
+        return main_musetalk(args)
 
     import numpy as np
     import torch
