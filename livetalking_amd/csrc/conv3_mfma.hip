@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace ltk {
@@ -45,6 +46,7 @@ struct K3Args {
     const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
     float* partial;                  // split-K slabs [ksplit][Mtot][CoutP] or nullptr
     int N, H, W, x_cbt, x_cb0;       // input: channel blocks in the buffer, first block of this tensor
+    int Ho, Wo;                      // output grid the tiles cover (= H, W except for stride 2)
     int y_cbt, y_cb0, HoA, WoA;      // output pixel (n,oy,ox) of block cb -> ((n*y_cbt + y_cb0+cb)*HoA + oy)*WoA + ox
     int res_cbt, res_cb0;
     int Cout, CoutP;                 // logical output channels; CoutP = padded (scale/shift/partial pitch)
@@ -65,9 +67,9 @@ struct K3Args {
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
 };
 
-__host__ __device__ constexpr int k3_maxa(int PXW, int NC8) {
-    // 16-byte A items per thread per chunk: NC8 * NPIX64 / 256
-    return PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
+__host__ __device__ constexpr int k3_maxa(int PXW, int NC8, int S = 1) {
+    // 16-byte A items per thread per chunk: (NC8/2) * SLOTS / 256; a stride-2 patch is ~4x the tile
+    return S == 2 ? (NC8 == 2 ? 10 : 20) : PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
 }
 __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT * T * NC8 * 32 + 255) / 256; }
 
@@ -80,11 +82,11 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 //   t : 0 1 2 3 | 4 5 | 6 7 | 8
 //   o : 0 0 0 0 | 1 1 | 2 2 | 3
 //   g : 0 1 2 3 | 1 3 | 2 3 | 3
-template <int G, int NBT, int PXW, int NC8, int T>
+template <int G, int NBT, int PXW, int NC8, int T, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BN = NBT * 32;
-    constexpr int MAXA = k3_maxa(PXW, NC8);
+    constexpr int MAXA = k3_maxa(PXW, NC8, S);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
     static_assert(G == 1 || (G == 4 && T == 9 && NBT == 1), "merged convT: 9 taps, 32 couts per block");
 
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 
     const int TWm = (1 << a.log2TW) - 1, THm = (1 << a.log2TH) - 1;
     const int tx0 = tx_t << a.log2TW, ty0 = ty_t << a.log2TH, n0 = tn_t * a.NB;
-    const int iy0 = ty0 - a.pad, ix0 = tx0 - a.pad;
+    const int iy0 = ty0 * S - a.pad, ix0 = tx0 * S - a.pad;
     const int PHW = a.PH * a.PW;
 
     // ---- zero both A stages once: halo slots outside the image are never written by the DMA
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         const int tx = m & TWm;
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
-        pixb[j] = (b < a.NB) ? ((b * a.PH + ty) * a.PW + tx) : 0;     // patch pixel slot
+        pixb[j] = (b < a.NB) ? ((b * a.PH + ty * S) * a.PW + tx * S) : 0;     // patch pixel slot
     }
 
     f32x16 acc[G][NBT][PXW];
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
         const int n = n0 + b, y = ty0 + ty, x = tx0 + tx;
-        *ok = (b < a.NB) && (n < a.N) && (y < a.H) && (x < a.W);
+        *ok = (b < a.NB) && (n < a.N) && (y < a.Ho) && (x < a.Wo);
         *n_out = n;
         const int oy = (G == 4) ? 2 * y + (g >> 1) : y;
         const int ox = (G == 4) ? 2 * x + (g & 1) : x;
@@ -382,6 +384,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int HWo16 = HWo * 16;
     const float* const sbase = reinterpret_cast<const float*>(smem + a.lds_scale_off);   // [2][BN] staged in the prologue
 
+    // the activation is a compile-time parameter of the epilogue body (one wave-uniform branch selects the copy):
+    // as a per-value runtime test hipcc if-converted it and every value paid for erff and exp
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -414,9 +420,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float t = v[r];
-                            if (a.relu == 1) t = fmaxf(t, 0.f);
-                            else if (a.relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
-                            else if (a.relu == 3) t = t / (1.f + __expf(-t));
+                            if constexpr (ACT == 1) t = fmaxf(t, 0.f);
+                            else if constexpr (ACT == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                            else if constexpr (ACT == 3) t = t / (1.f + __expf(-t));
                             t = fminf(fmaxf(t, -65504.f), 65504.f);
                             o[r] = (f16)t;
                         }
@@ -434,6 +440,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
             }
         }
     }
+    };
+    if (a.relu == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (a.relu == 2) epilogue(std::integral_constant<int, 2>{});
+    else if (a.relu == 3) epilogue(std::integral_constant<int, 3>{});
+    else epilogue(std::integral_constant<int, 0>{});
 }
 
 // split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts;
@@ -469,8 +480,7 @@ __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restri
         float t = v[r] * scale[c0 + r] + shift[c0 + r];
         if (res) t += (float)rr[r];
         if (relu == 1) t = fmaxf(t, 0.f);
-        else if (relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
-        else if (relu == 3) t = t / (1.f + __expf(-t));
+        else if (relu >= 2) t = (relu == 2) ? 0.5f * t * (1.f + erff(t * 0.70710678118654752f)) : t / (1.f + __expf(-t));
         t = fminf(fmaxf(t, -65504.f), 65504.f);
         o[r] = (f16)t;
     }
@@ -490,6 +500,11 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
     K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
     K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
 #undef K3CASE
+    return nullptr;
+}
+
+static k3_kernel_t k3_pick_s2(int NBT, int NC8) {     // 3x3 stride 2 pad 1 (face-encoder / U-Net downsamples): PXW = 2
+    if (NC8 == 2) return NBT == 2 ? (k3_kernel_t)conv3_kernel<1, 2, 2, 2, 9, 2> : (k3_kernel_t)conv3_kernel<1, 1, 2, 2, 9, 2>;
     return nullptr;
 }
 
@@ -538,7 +553,10 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     if (io.ups && ((io.H | io.W) & 1)) { if (err) *err = "conv3: upsampled input needs even H, W"; return -1; }
     a.Cout = p.lCout; a.CoutP = p.CoutPad;
     int ext;
+    const int S = p.v3_S;
+    a.Ho = io.H; a.Wo = io.W;
     if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = 0; ext = 1; }
+    else if (S == 2) { a.Ho = (io.H + 2 - 3) / 2 + 1; a.Wo = (io.W + 2 - 3) / 2 + 1; a.HoA = a.Ho; a.WoA = a.Wo; a.pad = 1; ext = 2; }
     else { a.HoA = io.H; a.WoA = io.W; a.pad = (T == 9) ? 1 : 0; ext = (T == 9) ? 2 : 0; }
     if (p.gemm_1x1_expand) {
         if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }
@@ -556,26 +574,30 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
 
     // tile selection (does not change any output element's summation order)
     int NBT = (G == 4) ? 1 : ((p.lCout >= 64) ? 2 : 1);
-    int PXW = (G == 1 && T == 9 && NC8 == 2) ? 4 : 2;
+    int PXW = (G == 1 && T == 9 && NC8 == 2 && S == 1) ? 4 : 2;
+    const char* ev_pxw = getenv("LTK_CONV_PXW");      // tuning sweeps only
+    const char* ev_nbt = getenv("LTK_CONV3_NBT");
+    if (ev_pxw && atoi(ev_pxw) == 2) PXW = 2;
+    if (ev_nbt && atoi(ev_nbt) == 1) NBT = 1;
     int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0;
     long long blocks = 0;
     auto geom = [&](int pxw) -> bool {
         const int M = 128 * pxw;
         const int lm = ceil_log2_(M);
-        l2w = std::min(5, ceil_log2_(io.W));
-        l2h = std::min(lm - l2w, ceil_log2_(io.H));
+        l2w = std::min(5, ceil_log2_(a.Wo));
+        l2h = std::min(lm - l2w, ceil_log2_(a.Ho));
         NB = M >> (l2w + l2h);
         NB = std::max(1, std::min(NB, io.N));
-        PH = (1 << l2h) + ext; PW = (1 << l2w) + ext;
+        PH = ((1 << l2h) - 1) * S + 1 + ext; PW = ((1 << l2w) - 1) * S + 1 + ext;
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
-        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8) * 256) --NB;
+        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S) * 256) --NB;
         npix = NB * PH * PW;
         SLOTS = (2 * npix + 63) / 64 * 64;
-        const int tiles_x = (io.W + (1 << l2w) - 1) >> l2w, tiles_y = (io.H + (1 << l2h) - 1) >> l2h;
+        const int tiles_x = (a.Wo + (1 << l2w) - 1) >> l2w, tiles_y = (a.Ho + (1 << l2h) - 1) >> l2h;
         const int tiles_n = (io.N + NB - 1) / NB;
         blocks = (long long)tiles_x * tiles_y * tiles_n;
         a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
-        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8) * 256 && npix < 32768;
+        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S) * 256 && npix < 32768;
     };
     bool fit = geom(PXW);
     if (PXW == 4) {
@@ -613,7 +635,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     a.lds_scale_off = (int)lds;
     lds += 2 * BN * sizeof(float);
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
-    k3_kernel_t k = k3_pick(G, NBT, PXW, NC8, T);
+    k3_kernel_t k = (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }

@@ -69,6 +69,7 @@ struct ConvPlan {
     bool v3 = false;
     int v3_G = 1;                         // 1 = conv, 4 = merged transposed conv (4 sub-pixel phases per block)
     int v3_T = 9;                         // taps: 9 (3x3 / merged convT) or 1 (1x1)
+    int v3_S = 1;                         // stride (3x3 pad 1 only): 1 or 2
     ConvPhase phase[kMaxPhases];
     // device data
     f16* d_w = nullptr;

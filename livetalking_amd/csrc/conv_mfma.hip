@@ -347,8 +347,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     float t = v[r];
                     if (a.relu == 1) t = fmaxf(t, 0.f);
-                    else if (a.relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
-                    else if (a.relu == 3) t = t / (1.f + __expf(-t));
+                    else if (a.relu >= 2) {      // rare (Whisper convs): keep the transcendental code out of the common path
+                        if (a.relu == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                        else t = t / (1.f + __expf(-t));
+                    }
                     t = fminf(fmaxf(t, -65504.f), 65504.f);
                     o[r] = (f16)t;
                 }
@@ -493,6 +495,10 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         return -1;
     }
 
+    if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+        env_int("LTK_CONV_V3_S2", 1)) {
+        p->v3 = true; p->v3_G = 1; p->v3_T = 9; p->v3_S = 2;
+    }
     if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {
         if (!transposed && kh == 3 && kw == 3 && ph == 1 && pw == 1) { p->v3 = true; p->v3_G = 1; p->v3_T = 9; }
         if ((!transposed && kh == 1 && kw == 1 && ph == 0 && pw == 0) || p->gemm_1x1_expand) { p->v3 = true; p->v3_G = 1; p->v3_T = 1; }
@@ -523,6 +529,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         if (p->v3_T == 1) NC8 = (Cin % 64 == 0) ? 8 : 2;
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
         else NC8 = (Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4;
+        if (p->v3_S == 2) NC8 = 2;
         NBT = 2;
     }
     p->NC8 = NC8; p->NBT = NBT;      // NBT here = the widest block the staging registers allow

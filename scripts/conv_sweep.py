@@ -28,6 +28,12 @@ LAYERS = [
     ("c7x7 6>16@256", 256, 256, 6, 16, 7, 1, 3, False, 0, False),
     ("s2 16>32@256", 256, 256, 16, 32, 3, 2, 1, False, 0, False),
     ("c32@128", 128, 128, 32, 32, 3, 1, 1, False, 0, True),
+    ("s2 32>64@128", 128, 128, 32, 64, 3, 2, 1, False, 0, False),
+    ("s2 64>128@64", 64, 64, 64, 128, 3, 2, 1, False, 0, False),
+    ("s2 128>256@32", 32, 32, 128, 256, 3, 2, 1, False, 0, False),
+    ("s2 256>512@16", 16, 16, 256, 512, 3, 2, 1, False, 0, False),
+    ("s2 512>512@8", 8, 8, 512, 512, 3, 2, 1, False, 0, False),
+    ("s2 320>320@32", 32, 32, 320, 320, 3, 2, 1, False, 0, False),
     ("c256@16", 16, 16, 256, 256, 3, 1, 1, False, 0, True),
     ("c512@4", 4, 4, 512, 512, 3, 1, 1, False, 0, True),
     ("T1024>512@8", 8, 8, 1024, 512, 3, 2, 1, True, 1, False),
@@ -50,11 +56,13 @@ def main():
     eng = Engine(0)
     # (LTK_CONV_V3, LTK_CONV_MODE, LTK_CONV_NBT, LTK_CONV_NC8)
     variants = [(0, 1, 0, 0), (1, 1, 0, 0)]
+    if os.environ.get("SWEEP_V3TILES"):
+        variants = [(1, 1, 0, 0), ("pxw2", 1, 0, 0), ("nbt1", 1, 0, 0), ("pxw2nbt1", 1, 0, 0)]
     if os.environ.get("SWEEP_FULL"):
         variants = [(0, m, n, c) for m, n, c in itertools.product((1, 0), (0, 2, 1), (0, 2))] + [(1, 1, 0, 0)]
     only = os.environ.get("SWEEP_ONLY")
     print(f"frames={N}   cell = us / TFLOP/s")
-    hdr = "layer".ljust(16) + "".join((("v3" if v else f"old m{m}n{n}c{c}")).rjust(14) for v, m, n, c in variants)
+    hdr = "layer".ljust(16) + "".join(((str(v) if isinstance(v, str) else "v3" if v else f"old m{m}n{n}c{c}")).rjust(14) for v, m, n, c in variants)
     print(hdr)
     for l in LAYERS:
         name, H, W, Cin, Cout, k, s, p, tr, op, res = l
@@ -75,6 +83,11 @@ def main():
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
         for v3, mode, nbt, nc8 in variants:
+            os.environ.pop("LTK_CONV_PXW", None); os.environ.pop("LTK_CONV3_NBT", None)
+            if isinstance(v3, str):
+                if "pxw2" in v3: os.environ["LTK_CONV_PXW"] = "2"
+                if "nbt1" in v3: os.environ["LTK_CONV3_NBT"] = "1"
+                v3 = 1
             os.environ["LTK_CONV_V3"] = str(v3)
             os.environ["LTK_CONV_MODE"] = str(mode)
             os.environ["LTK_CONV_NBT"] = str(nbt)
