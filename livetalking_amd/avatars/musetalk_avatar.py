@@ -79,6 +79,10 @@ def read_imgs(img_list):
 def load_avatar(avatar_id):
     import torch
     avatar_path = f"./data/avatars/{avatar_id}"
+    bank_path = os.path.join(avatar_path, "bank.ltkbank")       # packed by livetalking_amd.bank.pack_avatar_dir
+    if os.path.exists(bank_path):
+        from ..bank import load_bank
+        return load_bank(bank_path).as_avatar()
 
     def numbered(d):
         files = glob.glob(os.path.join(d, "*.[jpJP][pnPN]*[gG]"))

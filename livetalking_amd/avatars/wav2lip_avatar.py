@@ -87,6 +87,10 @@ def read_imgs(img_list):
 
 def load_avatar(avatar_id):
     avatar_path = f"./data/avatars/{avatar_id}"
+    bank_path = os.path.join(avatar_path, "bank.ltkbank")       # packed by livetalking_amd.bank.pack_avatar_dir
+    if os.path.exists(bank_path):
+        from ..bank import load_bank
+        return load_bank(bank_path).as_avatar()
     with open(f"{avatar_path}/coords.pkl", "rb") as f:
         coord_list_cycle = pickle.load(f)
 

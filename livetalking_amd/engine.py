@@ -93,8 +93,11 @@ class Engine:
                         coord_list: Sequence[Sequence[int]]) -> int:
         """Upload (frame_list_cycle, face_list_cycle, coord_list_cycle) as
         load_avatar returns them (wav2lip_avatar.py:72-88)."""
-        faces = np.ascontiguousarray(np.stack(face_list), dtype=np.uint8)
-        fulls = np.ascontiguousarray(np.stack(frame_list), dtype=np.uint8)
+        # a packed bank (livetalking_amd/bank.py) hands over its contiguous mmap sections: no re-stacking, one H2D copy each
+        faces = getattr(face_list, "packed", None)
+        fulls = getattr(frame_list, "packed", None)
+        faces = np.ascontiguousarray(np.stack(face_list) if faces is None else faces, dtype=np.uint8)
+        fulls = np.ascontiguousarray(np.stack(frame_list) if fulls is None else fulls, dtype=np.uint8)
         coords = np.ascontiguousarray(np.asarray(coord_list, dtype=np.int32).reshape(-1, 4))
         n = faces.shape[0]
         if faces.shape[1:] != (256, 256, 3) or fulls.shape[0] != n or coords.shape[0] != n or fulls.shape[3] != 3:
@@ -141,7 +144,8 @@ class Engine:
         """(frame_list_cycle, mask_list_cycle, coord_list_cycle, mask_coords_list_cycle, input_latent_list_cycle) as
         musetalk_avatar.load_avatar returns them (musetalk_avatar.py:69-91)."""
         lat = np.ascontiguousarray(np.concatenate([_as_f32(x).reshape(1, 8, 32, 32) for x in latents]), dtype=np.float32)
-        fulls = np.ascontiguousarray(np.stack(frame_list), dtype=np.uint8)
+        fulls = getattr(frame_list, "packed", None)
+        fulls = np.ascontiguousarray(np.stack(frame_list) if fulls is None else fulls, dtype=np.uint8)
         fb = np.ascontiguousarray(np.asarray(coord_list, dtype=np.int32).reshape(-1, 4))
         cb = np.ascontiguousarray(np.asarray(mask_coords_list, dtype=np.int32).reshape(-1, 4))
         n = lat.shape[0]
