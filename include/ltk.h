@@ -151,6 +151,15 @@ int ltk_whisper_load(ltk_engine* e, const ltk_named_tensor* encoder_sd, int n);
 int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, int first_row, int row_step, int rows,
                      void* d_out, void* stream);
 
+/* Avatar preparation: avatars/musetalk/models/vae.py:84-94,110-122 get_latents_for_unet, as
+ * avatars/musetalk/genavatar.py:116-128 calls it.  vae_sd: the AutoencoderKL state_dict keys "encoder.*" and
+ * "quant_conv.*" (fp32 host).  faces_bgr: host uint8 [nfaces][256][256][3] (the LANCZOS-resized crops);
+ * latents_out: host fp32 [nfaces][8][32][32] = cat(masked, reference) latents * scaling_factor.
+ * noise: host fp32 [nfaces][2][4][32][32] standard-normal draws for latent_dist.sample() (the reference draws them
+ * from torch's global RNG), or NULL for the distribution mean. */
+int ltk_vae_encoder_load(ltk_engine* e, const ltk_named_tensor* vae_sd, int n, int max_faces);
+int ltk_vae_encode_faces(ltk_engine* e, const uint8_t* faces_bgr, int nfaces, const float* noise, float* latents_out);
+
 /* ---- test / measurement hooks (not on the production call path) ---- */
 
 /* named tensor of the last Whisper step as [C][T] float32: "input_features", "hidden_states.0".."hidden_states.4",

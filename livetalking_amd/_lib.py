@@ -57,6 +57,8 @@ SYMBOLS = {
     "ltk_whisper_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int]),
     "ltk_whisper_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_whisper_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "ltk_vae_encoder_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int, C.c_int]),
+    "ltk_vae_encode_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "ltk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

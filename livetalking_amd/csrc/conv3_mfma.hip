@@ -556,7 +556,10 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     const int S = p.v3_S;
     a.Ho = io.H; a.Wo = io.W;
     if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = 0; ext = 1; }
-    else if (S == 2) { a.Ho = (io.H + 2 - 3) / 2 + 1; a.Wo = (io.W + 2 - 3) / 2 + 1; a.HoA = a.Ho; a.WoA = a.Wo; a.pad = 1; ext = 2; }
+    else if (S == 2) {   // pad 1, or pad 0 + one zero row/column at the bottom/right (p.out_pad)
+        a.Ho = (io.H + 2 * p.ph + p.out_pad - 3) / 2 + 1; a.Wo = (io.W + 2 * p.pw + p.out_pad - 3) / 2 + 1;
+        a.HoA = a.Ho; a.WoA = a.Wo; a.pad = p.ph; ext = 2;
+    }
     else { a.HoA = io.H; a.WoA = io.W; a.pad = (T == 9) ? 1 : 0; ext = (T == 9) ? 2 : 0; }
     if (p.gemm_1x1_expand) {
         if (io.H != 1 || io.W != 1) { if (err) *err = "k x k transposed conv only supported on 1x1 maps"; return -1; }

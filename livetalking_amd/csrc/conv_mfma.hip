@@ -414,9 +414,10 @@ static int ceil_log2(int v) {
 }
 
 void ConvPlan::out_dims(int H, int W, int* Ho, int* Wo) const {
-    if (!transposed) {
-        *Ho = (H + 2 * ph - kh) / sh + 1;
-        *Wo = (W + 2 * pw - kw) / sw + 1;
+    if (!transposed) {   // out_pad on a plain conv = extra zero rows/columns at the bottom/right (diffusers Downsample2D
+                         // with padding=0: F.pad(x, (0,1,0,1)) then a stride-2 "valid" conv)
+        *Ho = (H + 2 * ph + out_pad - kh) / sh + 1;
+        *Wo = (W + 2 * pw + out_pad - kw) / sw + 1;
     } else {
         *Ho = (H - 1) * sh - 2 * ph + kh + out_pad;
         *Wo = (W - 1) * sw - 2 * pw + kw + out_pad;
@@ -495,8 +496,8 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         return -1;
     }
 
-    if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
-        env_int("LTK_CONV_V3_S2", 1)) {
+    if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 &&
+        ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && env_int("LTK_CONV_V3_S2", 1)) {
         p->v3 = true; p->v3_G = 1; p->v3_T = 9; p->v3_S = 2;
     }
     if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {

@@ -185,6 +185,8 @@ struct ltk_engine {
     // musetalk
     MtGraph* mt = nullptr;
     int mt_max_frames = 0;
+    MtGraph* vae_enc = nullptr;           // AutoencoderKL encoder graph (avatar preparation), 2 images per face
+    int vae_enc_faces = 0;
     MtGraph* whisper = nullptr;           // Whisper-tiny encoder graph (Audio2Feature)
     float* d_wbasis = nullptr;            // slaney mel basis [80][201] (n_fft 400, 0..8000 Hz)
     float* d_wlogspec = nullptr;          // [80][3000]
@@ -590,6 +592,7 @@ void ltk_engine_destroy(ltk_engine* e) {
     for (auto& kv : e->mt_avatars) { (void)hipFree(kv.second.d_latents); (void)hipFree(kv.second.d_full); (void)hipFree(kv.second.d_masks); }
     if (e->mt) mt_graph_delete(e->mt);
     if (e->whisper) mt_graph_delete(e->whisper);
+    if (e->vae_enc) mt_graph_delete(e->vae_enc);
     if (e->d_wbasis) (void)hipFree(e->d_wbasis);
     if (e->d_wlogspec) (void)hipFree(e->d_wlogspec);
     if (e->d_wpcm) (void)hipFree(e->d_wpcm);
@@ -1249,6 +1252,53 @@ int ltk_whisper_debug_get(ltk_engine* e, const char* name, float* out, size_t n_
     CHK(hipMemcpy(out, d_tmp, cnt * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(d_tmp);
     return LTK_OK;
+}
+
+// ================================================================================ VAE encoder (avatar preparation)
+int ltk_vae_encoder_load(ltk_engine* e, const ltk_named_tensor* vae_sd, int n, int max_faces) {
+    if (!e || !vae_sd || n <= 0 || max_faces < 1 || max_faces > 32) return fail(LTK_E_INVALID, "bad arguments (max_faces in [1,32])");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->vae_enc) return fail(LTK_E_STATE, "a VAE encoder is already loaded in this engine");
+    CHK(hipSetDevice(e->device));
+    MtGraph* vg = mt_graph_new();
+    if (mt_build_vae_encoder_graph(vg, vae_sd, n, 2 * max_faces)) {
+        const std::string msg = mt_graph_error(vg);
+        mt_graph_delete(vg);
+        return fail(LTK_E_INVALID, "vae encoder: " + msg);
+    }
+    e->vae_enc = vg;
+    e->vae_enc_faces = max_faces;
+    return LTK_OK;
+}
+
+int ltk_vae_encode_faces(ltk_engine* e, const uint8_t* faces_bgr, int nfaces, const float* noise, float* latents_out) {
+    if (!e || !faces_bgr || !latents_out || nfaces <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->vae_enc) return fail(LTK_E_STATE, "ltk_vae_encoder_load has not been called");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = e->compute;
+    uint8_t* d_faces = nullptr;
+    float *d_noise = nullptr, *d_out = nullptr;
+    const int cap = e->vae_enc_faces;
+    CHK(hipMalloc((void**)&d_faces, (size_t)cap * 65536 * 3));
+    CHK(hipMalloc((void**)&d_out, (size_t)cap * 8 * 1024 * sizeof(float)));
+    if (noise) CHK(hipMalloc((void**)&d_noise, (size_t)cap * 2 * 4 * 1024 * sizeof(float)));
+    int rc = 0;
+    for (int f0 = 0; f0 < nfaces && !rc; f0 += cap) {
+        const int nf = std::min(cap, nfaces - f0);
+        CHK(hipMemcpyAsync(d_faces, faces_bgr + (size_t)f0 * 65536 * 3, (size_t)nf * 65536 * 3, hipMemcpyHostToDevice, s));
+        if (noise) CHK(hipMemcpyAsync(d_noise, noise + (size_t)f0 * 2 * 4 * 1024, (size_t)nf * 2 * 4 * 1024 * sizeof(float), hipMemcpyHostToDevice, s));
+        int cbt;
+        launch_vae_pre(d_faces, nf, mt_latent_in(e->vae_enc, &cbt), s);
+        rc = mt_run(e->vae_enc, 2 * nf, e->d_partial, e->partial_cap, s);
+        if (rc) { rc = fail(LTK_E_INVALID, std::string("vae encoder: ") + mt_graph_error(e->vae_enc)); break; }
+        launch_vae_latents(mt_unet_out(e->vae_enc, &cbt), nf, noise ? d_noise : nullptr, 0.18215f, d_out, s);
+        CHK(hipMemcpyAsync(latents_out + (size_t)f0 * 8 * 1024, d_out, (size_t)nf * 8 * 1024 * sizeof(float), hipMemcpyDeviceToHost, s));
+        CHK(hipStreamSynchronize(s));
+    }
+    (void)hipFree(d_faces); (void)hipFree(d_out);
+    if (d_noise) (void)hipFree(d_noise);
+    return rc;
 }
 
 }  // extern "C"

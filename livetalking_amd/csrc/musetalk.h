@@ -26,6 +26,9 @@ int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s
 // named intermediate (debug / parity): returns device pointer + geometry, or null
 f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, int* W);
 double mt_macs_per_frame(const MtGraph* g);
+// VAE encoder graph (avatar preparation): image input = mt_latent_in() ([N][1][65536][16], RGB in [-1,1]),
+// moments (mean | logvar, 8 channels at 32x32) = mt_unet_out()
+int mt_build_vae_encoder_graph(MtGraph* g, const ltk_named_tensor* vae_sd, int n, int frames);
 // Whisper encoder graph (one 30-s window per run): input log-mel tensor = mt_latent_in(), 5 hidden states
 int mt_build_whisper_graph(MtGraph* g, const ltk_named_tensor* encoder_sd, int n);
 f16* mt_whisper_state(MtGraph* g, int i, int* cbt, int* cb0);

@@ -125,9 +125,13 @@ struct MtGraph {
                  const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
         return add_conv2(name, w, bias, Cin, Cout, k, k, stride, stride, pad, pad, x, y, res, act, ups);
     }
+    // diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + Conv2d(k3, s2, p0)  (AutoencoderKL encoder)
+    int add_conv_down_asym(const std::string& name, const float* w, const float* bias, int C, const MtTensor& x, const MtTensor& y) {
+        return add_conv2(name, w, bias, C, C, 3, 3, 2, 2, 0, 0, x, y, nullptr, 0, 0, 1);
+    }
     // rectangular kernel / stride (Conv1d over a [T][1] token map: kh x 1)
     int add_conv2(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int kh, int kw, int sh, int sw,
-                  int ph, int pw, const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
+                  int ph, int pw, const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups, int pad_br = 0) {
         const int k = kh, stride = sh;
         const int kk = kh * kw;
         (void)k;
@@ -148,7 +152,7 @@ struct MtGraph {
         if (bias) memcpy(sf.data(), bias, Cout * sizeof(float));
         ConvPlan p;
         std::string e;
-        int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, 0, sc.data(), sf.data(), &e, x.P());
+        int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, pad_br, sc.data(), sf.data(), &e, x.P());
         if (rc) { err = name + ": " + e; return -1; }
         plans.push_back(p);
         MtOp op;
@@ -541,6 +545,62 @@ int mt_build_vae(MtGraph& g, const ltk_named_tensor* t, int n, const MtTensor& z
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ VAE encoder
+// AutoencoderKL.encode of sd-vae (avatars/musetalk/models/vae.py:84-94 encode_latents; avatar preparation,
+// avatars/musetalk/genavatar.py:116-128): conv_in, 4 down blocks x 2 resnets with asymmetric-pad stride-2 convs,
+// mid (resnet, attention, resnet), GN-SiLU-conv_out (8 = mean | logvar), quant_conv.
+int mt_build_vae_encoder(MtGraph& g, const ltk_named_tensor* t, int n, MtTensor* img_in, MtTensor* moments) {
+    SD sd{t, n, ""};
+    *img_in = g.alloc(3, 256, 256);
+    const float* wi = sd.get("encoder.conv_in.weight", (size_t)128 * 3 * 9);
+    const float* bi = sd.get("encoder.conv_in.bias", 128);
+    if (!wi || !bi) { g.err = sd.err; return -1; }
+    MtTensor h = g.alloc(128, 256, 256);
+    if (g.add_conv("encoder.conv_in", wi, bi, 3, 128, 3, 1, 1, *img_in, h, nullptr, 0, 0)) return -1;
+    const int chs[4] = {128, 256, 512, 512};
+    int C = 128;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            MtTensor r = g.alloc(chs[i], h.H, h.W);
+            if (build_resnet(g, sd, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h, r, C, chs[i], nullptr, 1e-6f)) return -1;
+            C = chs[i];
+            h = r;
+        }
+        if (i < 3) {
+            const std::string dp = "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
+            const float* w = sd.get(dp + ".weight", (size_t)C * C * 9);
+            const float* b = sd.get(dp + ".bias", C);
+            if (!w || !b) { g.err = sd.err; return -1; }
+            MtTensor d = g.alloc(C, h.H / 2, h.W / 2);
+            if (g.add_conv_down_asym(dp, w, b, C, h, d)) return -1;
+            h = d;
+        }
+        g.named["encoder.down_blocks." + std::to_string(i)] = h;
+    }
+    {
+        MtTensor r0 = g.alloc(512, 32, 32);
+        if (build_resnet(g, sd, "encoder.mid_block.resnets.0", h, r0, 512, 512, nullptr, 1e-6f)) return -1;
+        const std::string a = "encoder.mid_block.attentions.0";
+        MtTensor gn = g.alloc(512, 32, 32), ao = g.alloc(512, 32, 32), r1 = g.alloc(512, 32, 32);
+        if (g.add_gn(a + ".group_norm", sd, a + ".group_norm", r0, gn, 1e-6f, 0)) return -1;
+        if (build_attention(g, sd, a, gn, gn, 512, 512, 1, true, r0, ao)) return -1;
+        if (build_resnet(g, sd, "encoder.mid_block.resnets.1", ao, r1, 512, 512, nullptr, 1e-6f)) return -1;
+        h = r1;
+        g.named["encoder.mid_block"] = h;
+    }
+    MtTensor tn = g.alloc(512, 32, 32), co = g.alloc(8, 32, 32);
+    if (g.add_gn("encoder.conv_norm_out", sd, "encoder.conv_norm_out", h, tn, 1e-6f, 1)) return -1;
+    const float* wo = sd.get("encoder.conv_out.weight", (size_t)8 * 512 * 9);
+    const float* bo = sd.get("encoder.conv_out.bias", 8);
+    const float* wq = sd.get("quant_conv.weight", 64);
+    const float* bq = sd.get("quant_conv.bias", 8);
+    if (!wo || !bo || !wq || !bq) { g.err = sd.err; return -1; }
+    if (g.add_conv("encoder.conv_out", wo, bo, 512, 8, 3, 1, 1, tn, co, nullptr, 0, 0)) return -1;
+    *moments = g.alloc(8, 32, 32);
+    if (g.add_conv("quant_conv", wq, bq, 8, 8, 1, 1, 0, co, *moments, nullptr, 0, 0)) return -1;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ Whisper encoder
 // transformers WhisperEncoder (whisper-tiny: d 384, 4 layers, 6 heads, ffn 1536), the Audio2Feature model
 // (avatars/musetalk/whisper/audio2feature.py:15-23,106-117).  In-tree statement of the same encoder:
@@ -738,6 +798,12 @@ f16* mt_whisper_state(MtGraph* g, int i, int* cbt, int* cb0) {
     const MtTensor& t = g->whisper_states[i];
     *cbt = t.ld / 16; *cb0 = t.coff / 16;
     return g->bufs[t.buf];
+}
+int mt_build_vae_encoder_graph(MtGraph* g, const ltk_named_tensor* sd, int n, int frames) {
+    g->t_latent = new MtTensor();          // image input
+    g->t_unet_out = new MtTensor();        // moments output
+    if (mt_build_vae_encoder(*g, sd, n, g->t_latent, g->t_unet_out)) return -1;
+    return mt_graph_alloc(*g, frames);
 }
 double mt_macs_per_frame(const MtGraph* g) { return g->macs; }
 

@@ -49,6 +49,11 @@ struct OutList64 { uint8_t* p[64]; };
 // vae.py:104-107: (x/2+0.5).clamp(0,1) -> *255 -> round-half-even -> uint8, RGB -> BGR, NHWC [256][256][3]
 void launch_vae_post(const f16* x, int x_cbt, int nframes, int P, const OutList64& out, float* out_f32_nchw, hipStream_t s);
 
+// ---- VAE encode bridges (avatar preparation): uint8 BGR faces [n][256][256][3] -> normalised RGB CB16 images
+// (2 per face: lower-half masked, full); moments -> fp32 latents [n][8][32][32]
+void launch_vae_pre(const uint8_t* d_bgr, int nfaces, f16* y, hipStream_t s);
+void launch_vae_latents(const f16* moments, int nfaces, const float* d_noise, float scaling, float* out, hipStream_t s);
+
 // ---- Whisper front end / feature slicing (MuseTalk audio features)
 // pcm device fp32 [n_samples] (<= 30 s); basis fp32 [80][201]; logspec scratch fp32 [80][3000]; gmax scratch int;
 // y: CB16 [5][3000][16] log-mel features

@@ -612,4 +612,53 @@ void launch_whisper_chunks(const WhisperStates& st, int T, int batch, int first_
     hipLaunchKernelGGL(whisper_chunks_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, T, batch, first_row, row_step, rows, out);
 }
 
+// =============================================================================================== VAE encode bridges
+// avatars/musetalk/models/vae.py:55-82 preprocess_img on an array input: BGR->RGB, /255., lower-half mask
+// (x * (mask > 0.5), mask = 1 on rows < 128), Normalize(0.5, 0.5) -> [-1, 1]; image 2i = masked, 2i+1 = full.
+__global__ __launch_bounds__(256) void vae_pre_kernel(const uint8_t* __restrict__ bgr, int nfaces, f16* __restrict__ y) {
+    const int img = blockIdx.y;                     // 0 .. 2*nfaces-1
+    const int p = blockIdx.x * 256 + threadIdx.x;   // pixel
+    const uint8_t* src = bgr + ((size_t)(img >> 1) * 65536 + p) * 3;
+    const bool masked = !(img & 1) && (p >> 8) >= 128;
+    f16x8 o0, o1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { o0[c] = (f16)0.f; o1[c] = (f16)0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (float)((double)src[2 - c] / 255.0);      // RGB order
+        if (masked) v = 0.f;
+        o0[c] = (f16)((v - 0.5f) / 0.5f);
+    }
+    f16* dst = y + ((size_t)img * 65536 + p) * 16;
+    *reinterpret_cast<f16x8*>(dst) = o0;
+    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+}
+
+void launch_vae_pre(const uint8_t* d_bgr, int nfaces, f16* y, hipStream_t s) {
+    hipLaunchKernelGGL(vae_pre_kernel, dim3(256, 2 * nfaces), dim3(256), 0, s, d_bgr, nfaces, y);
+}
+
+// vae.py:84-94,110-122: latents = scaling_factor * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) per image,
+// then cat([masked, reference], dim=1) -> fp32 [nfaces][8][32][32].  noise fp32 [2*nfaces][4][1024] or null (= mean).
+__global__ __launch_bounds__(256) void vae_latents_kernel(const f16* __restrict__ moments, int nfaces, const float* __restrict__ noise,
+                                                           float scaling, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;       // (image, pixel)
+    if (i >= 2 * nfaces * 1024) return;
+    const int img = i >> 10, p = i & 1023;
+    const f16x8 m = *reinterpret_cast<const f16x8*>(moments + ((size_t)img * 1024 + p) * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = (float)m[c];
+        if (noise) {
+            const float lv = fminf(fmaxf((float)m[4 + c], -30.f), 20.f);
+            v += __expf(0.5f * lv) * noise[((size_t)img * 4 + c) * 1024 + p];
+        }
+        out[(((size_t)(img >> 1) * 8) + (img & 1) * 4 + c) * 1024 + p] = scaling * v;
+    }
+}
+
+void launch_vae_latents(const f16* moments, int nfaces, const float* d_noise, float scaling, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(vae_latents_kernel, dim3((2 * nfaces * 1024 + 255) / 256), dim3(256), 0, s, moments, nfaces, d_noise, scaling, out);
+}
+
 }  // namespace ltk

@@ -194,6 +194,23 @@ class Engine:
         _lib.check(self._lib.ltk_musetalk_time(self._h, int(frames), int(iters), C.byref(ms), C.byref(macs)))
         return ms.value, macs.value
 
+    # ------------------------------------------------------------------ avatar preparation (VAE encoder)
+    def load_vae_encoder(self, vae_sd: Dict[str, object], max_faces: int = 8):
+        sd = {k: v for k, v in vae_sd.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        arr, n, keep = self._named_tensors(sd)
+        _lib.check(self._lib.ltk_vae_encoder_load(self._h, arr, n, int(max_faces)))
+        del keep
+
+    def vae_encode_faces(self, faces_bgr: np.ndarray, noise: Optional[np.ndarray] = None) -> np.ndarray:
+        """vae.get_latents_for_unet for each 256x256 BGR crop -> fp32 (n, 8, 32, 32)."""
+        faces = np.ascontiguousarray(faces_bgr, dtype=np.uint8).reshape(-1, 256, 256, 3)
+        n = faces.shape[0]
+        out = np.empty((n, 8, 32, 32), dtype=np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).reshape(n, 2, 4, 32, 32)
+        _lib.check(self._lib.ltk_vae_encode_faces(self._h, faces.ctypes.data, n, nz.ctypes.data if nz is not None else None,
+                                                  out.ctypes.data))
+        return out
+
     # ------------------------------------------------------------------ whisper audio features
     def load_whisper(self, encoder_sd: Dict[str, object]):
         """audio2feature.py:15-23: `encoder_sd` = WhisperModel.from_pretrained(...).encoder.state_dict()."""

@@ -258,6 +258,31 @@ def vae_decoder_state_dict(seed: int = 987) -> Dict[str, np.ndarray]:
     return sd
 
 
+def vae_encoder_state_dict(seed: int = 654) -> Dict[str, np.ndarray]:
+    """AutoencoderKL (sd-vae) encoder + quant_conv under diffusers' key names."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    _conv(rng, sd, "encoder.conv_in", 3, VAE_CH[0], 3)
+    cin = VAE_CH[0]
+    for i, c in enumerate(VAE_CH):
+        for j in range(2):
+            _resnet(rng, sd, f"encoder.down_blocks.{i}.resnets.{j}", cin, c, 0)
+            cin = c
+        if i < 3:
+            _conv(rng, sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", cin, cin, 3)
+    _resnet(rng, sd, "encoder.mid_block.resnets.0", cin, cin, 0)
+    a = "encoder.mid_block.attentions.0"
+    _norm(rng, sd, a + ".group_norm", cin)
+    for nme in ("to_q", "to_k", "to_v"):
+        _lin(rng, sd, a + "." + nme, cin, cin, gain=1.5 if nme != "to_v" else 1.0)
+    _lin(rng, sd, a + ".to_out.0", cin, cin, gain=0.5)
+    _resnet(rng, sd, "encoder.mid_block.resnets.1", cin, cin, 0)
+    _norm(rng, sd, "encoder.conv_norm_out", cin)
+    _conv(rng, sd, "encoder.conv_out", cin, 8, 3, gain=0.7)
+    _conv(rng, sd, "quant_conv", 8, 8, 1)
+    return sd
+
+
 def musetalk_latents(n_frames: int = 4, seed: int = 5) -> List[np.ndarray]:
     """input_latent_list_cycle stand-in: per frame fp32 (1,8,32,32) = cat(masked, reference) VAE latents scaled by
     0.18215 (avatars/musetalk/models/vae.py:110-122)."""

@@ -257,6 +257,49 @@ def vae_decode(sd: SD, z: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> T
     return tap("decoder.conv_out", _conv(sd, "decoder.conv_out", h))
 
 
+def vae_encode_moments(sd: SD, x: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """AutoencoderKL.encode(x) up to the moments (mean | logvar): x (B,3,256,256) in [-1,1] -> (B,8,32,32).
+    diffusers Encoder: conv_in, DownEncoderBlock2D x4 (2 resnets; Downsample2D(padding=0) = F.pad(0,1,0,1) + conv s2),
+    UNetMidBlock2D, GN-SiLU-conv_out, then quant_conv."""
+    h = _conv(sd, "encoder.conv_in", x)
+    for i in range(4):
+        for j in range(2):
+            h = resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, None, VAE_GROUPS, VAE_EPS)
+        if i < 3:
+            h = F.pad(h, (0, 1, 0, 1))
+            h = _conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride=2, pad=0)
+        if taps is not None:
+            taps[f"encoder.down_blocks.{i}"] = h.detach().clone()
+    h = resnet(sd, "encoder.mid_block.resnets.0", h, None, VAE_GROUPS, VAE_EPS)
+    h = vae_attention(sd, "encoder.mid_block.attentions.0", h)
+    h = resnet(sd, "encoder.mid_block.resnets.1", h, None, VAE_GROUPS, VAE_EPS)
+    if taps is not None:
+        taps["encoder.mid_block"] = h.detach().clone()
+    h = F.silu(_gn(sd, "encoder.conv_norm_out", h, VAE_GROUPS, VAE_EPS))
+    h = _conv(sd, "encoder.conv_out", h)
+    return _conv(sd, "quant_conv", h, pad=0)
+
+
+def get_latents_for_unet(vae_sd: SD, face_bgr, noise: Optional[Tensor] = None) -> Tensor:
+    """avatars/musetalk/models/vae.py:55-94,110-122 for one 256x256 BGR array -> (1,8,32,32).
+    noise (2,4,32,32): the standard-normal draws of latent_dist.sample() for (masked, reference); None -> the mean."""
+    import numpy as np
+    img = np.asarray(face_bgr)[..., ::-1]                             # cv2.cvtColor(BGR2RGB)
+    x = np.asarray([img]) / 255.
+    x = torch.squeeze(torch.FloatTensor(np.transpose(x, (3, 0, 1, 2))))
+    mask = torch.zeros((256, 256))
+    mask[:128, :] = 1
+    outs = []
+    for k, half_mask in enumerate((True, False)):
+        xi = x * (mask > 0.5) if half_mask else x
+        xi = ((xi - 0.5) / 0.5).unsqueeze(0)
+        mom = vae_encode_moments(vae_sd, xi)
+        mean, logvar = mom[:, :4], torch.clamp(mom[:, 4:], -30.0, 20.0)
+        z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise[k][None]
+        outs.append(VAE_SCALING * z)
+    return torch.cat(outs, dim=1)
+
+
 def decode_latents(vae_sd: SD, latents: Tensor):
     """avatars/musetalk/models/vae.py:96-108 -> uint8 (B,256,256,3) BGR."""
     image = vae_decode(vae_sd, latents / VAE_SCALING)

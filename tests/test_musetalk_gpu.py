@@ -143,3 +143,28 @@ def test_musetalk_infer_and_blend(mt):
     dd = np.abs(out.astype(int) - ref.astype(int))
     print(f"[mt] paste_blend max diff {dd.max()}, differing bytes {(dd != 0).sum()}")
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_vae_encoder_avatar_prep():
+    """ltk_vae_encode_faces (avatar preparation, vae.get_latents_for_unet) vs the oracle: the distribution mean and a
+    sample with explicit noise, rel. L2 <= 1e-2 (fp16 activations; the reference runs this in fp16 too,
+    avatars/musetalk/genavatar.py:108)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    sd_np = synth.vae_encoder_state_dict()
+    eng = Engine(0)
+    eng.load_vae_encoder(sd_np, max_faces=2)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    _, faces, _ = synth.wav2lip_avatar(n_frames=2, full_hw=(64, 64), box=16, seed=9)
+    noise = np.random.default_rng(1).standard_normal((2, 2, 4, 32, 32)).astype(np.float32)
+    got_mean = eng.vae_encode_faces(np.stack(faces))
+    got_samp = eng.vae_encode_faces(np.stack(faces), noise)
+    with torch.no_grad():
+        ref_mean = torch.cat([M.get_latents_for_unet(sd, f) for f in faces]).numpy()
+        ref_samp = torch.cat([M.get_latents_for_unet(sd, f, torch.from_numpy(noise[i])) for i, f in enumerate(faces)]).numpy()
+    r1, r2 = rel_l2(got_mean, ref_mean), rel_l2(got_samp, ref_samp)
+    print(f"[mt] vae encoder: mean rel_l2={r1:.3e}, sample rel_l2={r2:.3e}, |latent| max {np.abs(ref_mean).max():.3g}")
+    assert got_mean.shape == (2, 8, 32, 32) and r1 <= 1e-2 and r2 <= 1e-2
+    eng.close()
