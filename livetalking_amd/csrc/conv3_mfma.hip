@@ -58,6 +58,7 @@ struct K3Args {
     int nchunks, ksplit, chunks_per_split;
     int relu;                        // activation: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU
     int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
+    int nitems;                      // work items (ksplit x pixel tiles x cout tiles); gridDim.x <= nitems
     int stagger;                     // cycles the second resident block of each CU idles before it starts, so the
                                      // two blocks of a CU run out of phase (one in its MFMA loop while the other
                                      // is in its prologue / epilogue)
@@ -82,9 +83,9 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 //   t : 0 1 2 3 | 4 5 | 6 7 | 8
 //   o : 0 0 0 0 | 1 1 | 2 2 | 3
 //   g : 0 1 2 3 | 1 3 | 2 3 | 3
-template <int G, int NBT, int PXW, int NC8, int T, int S = 1>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// one work item = one (k split, pixel tile, cout tile); `bid` is its logical id
+template <int G, int NBT, int PXW, int NC8, int T, int S>
+__device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem) {
     constexpr int BN = NBT * 32;
     constexpr int MAXA = k3_maxa(PXW, NC8, S);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
@@ -96,19 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)a.stagger) __builtin_amdgcn_s_sleep(16);
-    }
-
-    // ---- block -> (k split, image tile, y tile, x tile, cout tile); XCD-contiguous logical ids
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
+    // ---- item -> (k split, image tile, y tile, x tile, cout tile)
     const int ntile = bid % a.n_ntiles;
     int t0 = bid / a.n_ntiles;
     const int tx_t = t0 % a.tiles_x; t0 /= a.tiles_x;
@@ -158,12 +147,6 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
                         ((unsigned)ix < (unsigned)a.W);
         a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) : -1;
         a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
-    }
-
-    // ---- folded-BN scale/shift of this block's BN output channels -> LDS (read by the epilogue)
-    if (tid < 2 * BN) {
-        const int which = tid / BN, c = tid - which * BN;
-        reinterpret_cast<float*>(smem + a.lds_scale_off)[tid] = (which ? a.shift : a.scale)[ntile * BN + c];
     }
 
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
@@ -310,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
 
     __syncthreads();                       // zero fill done before any DMA lands
     stage(c_begin, 0);
+    // folded-BN scale/shift of this block's BN output channels -> LDS by DMA, behind the first chunk (a register
+    // round trip here would put one global-load latency in front of every block's first DMA)
+    if (wave < 2 && lane < BN / 4)
+        GLDS16((wave ? a.shift : a.scale) + ntile * BN + lane * 4, smem + a.lds_scale_off + wave * (BN * 4));
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
         __syncthreads();                   // vmcnt(0): chunk c landed; every wave left stage cur^1
@@ -445,6 +432,24 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     else if (a.relu == 2) epilogue(std::integral_constant<int, 2>{});
     else if (a.relu == 3) epilogue(std::integral_constant<int, 3>{});
     else epilogue(std::integral_constant<int, 0>{});
+}
+
+// Persistent launch: the grid is at most `2 x CUs` blocks (what is resident at once) and every block walks the item
+// list with stride gridDim.x.  With thousands of items per layer (64/128-channel layers on 128^2..256^2 maps) the
+// per-block dispatch, kernarg fetch and descriptor set-up were a fixed ~16 us per launch; a non-persistent launch
+// (gridDim.x == nitems) is the same code with one trip.  Logical ids are XCD-contiguous: consecutive ids (same
+// pixel tile, different cout tiles) run on one XCD and share its L2.
+template <int G, int NBT, int PXW, int NC8, int T, int S = 1>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    for (int item = first; item < a.nitems; item += nblk) {
+        if (item != first) __syncthreads();      // every wave is out of the previous item's LDS stages
+        conv3_item<G, NBT, PXW, NC8, T, S>(a, item, smem);
+    }
 }
 
 // split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts;
@@ -614,7 +619,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     const char* ev_split = getenv("LTK_SPLITK");      // 0: never split (batch-size independent summation order)
     const char* ev_abl = getenv("LTK_ABLATE");
     const int allow_split = ev_split ? atoi(ev_split) : 1;
-    const char* ev_stag = getenv("LTK_STAGGER");
+
     const int ablate = ev_abl ? atoi(ev_abl) : 0;
     a.ablate = ablate;
     int ksplit = allow_split ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
@@ -647,10 +652,12 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         HIPCHK3(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured.push_back((const void*)k);
     }
-    a.stagger = ev_stag ? atoi(ev_stag) : 0;
-    if (a.stagger < 0) a.stagger = (a.chunks_per_split * (G == 4 ? 1400 : 2300) * (PXW == 4 ? 2 : 1) / 2 + 3000) / 2 * (-a.stagger) / 100;
-    if (nblk < 512) a.stagger = 0;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    a.stagger = 0;
+    a.nitems = (int)nblk;
+    const char* ev_pers = getenv("LTK_CONV_PERSIST");      // 0: one block per item
+    const int persist_blocks = ev_pers ? atoi(ev_pers) : 512;
+    const long long grid = (persist_blocks > 0 && nblk > persist_blocks) ? persist_blocks : nblk;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, stream, a);
     HIPCHK3(hipGetLastError());
     if (ksplit > 1) {
         const long long items = a.Mtot * (p.lCout >> 3);
