@@ -295,7 +295,9 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     stage(c_begin, 0);
     // folded-BN scale/shift of this block's BN output channels -> LDS by DMA, behind the first chunk (a register
     // round trip here would put one global-load latency in front of every block's first DMA)
-    if (wave < 2 && lane < BN / 4)
+    // (1x1 layers read them from global in the epilogue instead: their two 40-KiB stage pairs are exactly half of
+    // the CU's LDS and 512 more bytes would cost the second resident block)
+    if (T != 1 && wave < 2 && lane < BN / 4)
         GLDS16((wave ? a.shift : a.scale) + ntile * BN + lane * 4, smem + a.lds_scale_off + wave * (BN * 4));
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
@@ -393,8 +395,14 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                     for (int eo = 0; eo < 2; ++eo) {    // q4 = 2pr+eo: channels 8*q4 + 4*hh .. +3 of the 32-cout tile i
                         const int q4 = 2 * pr + eo;
                         const int cl = i * 32 + 8 * q4 + 4 * hh;
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(sbase + cl);
-                        const f32x4 sf = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
+                        f32x4 sc, sf;
+                        if constexpr (T == 1) {
+                            sc = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);
+                            sf = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
+                        } else {
+                            sc = *reinterpret_cast<const f32x4*>(sbase + cl);
+                            sf = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
+                        }
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[r] + sf[r];
@@ -641,7 +649,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     size_t lds = 2 * (a_bytes + b_bytes);
     lds = (lds + 255) / 256 * 256;
     a.lds_scale_off = (int)lds;
-    lds += 2 * BN * sizeof(float);
+    if (T != 1) lds += 2 * BN * sizeof(float);
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
     k3_kernel_t k = (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }

@@ -983,11 +983,13 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
 }
 
 // latents already gathered into the graph's latent tensor; d_feat = fp32 [nf][50][384] on the device
-static int mt_run_locked(ltk_engine* e, const float* d_feat, int nf, const OutList64* outs, float* d_image_f32) {
+static int mt_run_locked(ltk_engine* e, const float* d_feat, const PtrList64* feat_ptrs, int nf, const OutList64* outs,
+                         float* d_image_f32) {
     hipStream_t s = e->compute;
     int cbt;
     f16* ctx = mt_ctx_in(e->mt, &cbt);
-    launch_tokens_to_cb16(d_feat, nf, 50, 384, e->d_pe, ctx, cbt, 0, s);
+    if (feat_ptrs) launch_tokens_gather_to_cb16(*feat_ptrs, nf, 50, 384, e->d_pe, ctx, cbt, s);
+    else launch_tokens_to_cb16(d_feat, nf, 50, 384, e->d_pe, ctx, cbt, 0, s);
     const int rc = mt_run(e->mt, nf, e->d_partial, e->partial_cap, s);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     if (outs || d_image_f32) {
@@ -1036,21 +1038,14 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
         }
         for (int f0 = 0; f0 < total && !rc; f0 += e->mt_max_frames) {
             const int nf = std::min(e->mt_max_frames, total - f0);
-            PtrList64 lp;
+            PtrList64 lp, fp;
             OutList64 op;
-            for (int i = 0; i < 64; ++i) { lp.p[i] = nullptr; op.p[i] = nullptr; }
-            for (int i = 0; i < nf; ++i) {
-                lp.p[i] = lptr[f0 + i];
-                op.p[i] = optr[f0 + i];
-                // the feature rows of one request are contiguous, but requests are not: gather into the staging buffer
-                if (hipMemcpyAsync(e->d_mt_feat + (size_t)i * 50 * 384, fptr[f0 + i], 50 * 384 * sizeof(float), hipMemcpyDeviceToDevice,
-                                   e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "feature gather failed");
-            }
-            if (rc) break;
+            for (int i = 0; i < 64; ++i) { lp.p[i] = nullptr; fp.p[i] = nullptr; op.p[i] = nullptr; }
+            for (int i = 0; i < nf; ++i) { lp.p[i] = lptr[f0 + i]; fp.p[i] = fptr[f0 + i]; op.p[i] = optr[f0 + i]; }
             int cbt;
             f16* lat = mt_latent_in(e->mt, &cbt);
             launch_gather_latents(lp, nf, 8, 1024, lat, cbt, e->compute);
-            rc = mt_run_locked(e, e->d_mt_feat, nf, &op, nullptr);
+            rc = mt_run_locked(e, nullptr, &fp, nf, &op, nullptr);
         }
         if (!rc && hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
     }
@@ -1115,7 +1110,7 @@ int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* 
     if (frames) CHK(hipMalloc((void**)&d_frames, (size_t)B * 65536 * 3));
     OutList64 op;
     for (int i = 0; i < 64; ++i) op.p[i] = (frames && i < B) ? d_frames + (size_t)i * 65536 * 3 : nullptr;
-    int rc = mt_run_locked(e, e->d_mt_feat, B, &op, d_img);
+    int rc = mt_run_locked(e, e->d_mt_feat, nullptr, B, &op, d_img);
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(LTK_E_HIP, "stream sync failed");
     if (!rc && unet_out) {
         int C, ld, coff, H, W;

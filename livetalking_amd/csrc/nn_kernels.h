@@ -43,6 +43,8 @@ void launch_nchw_to_cb16(const float* x, int N, int C, int P, f16* y, int y_cbt,
 // tokens fp32 [N][P][C] (+ optional additive table [P][C], e.g. the MuseTalk positional encoding) -> CB16
 void launch_tokens_to_cb16(const float* x, int N, int P, int C, const float* add, f16* y, int y_cbt, int y_cb0, hipStream_t s);
 struct PtrList64 { const void* p[64]; };
+// same, with one fp32 [P][C] block per image given by pointer
+void launch_tokens_gather_to_cb16(const PtrList64& src, int N, int P, int C, const float* add, f16* y, int y_cbt, hipStream_t s);
 // latents: per-frame fp32 [C][P] planes gathered by pointer -> CB16 (musetalk_avatar.py:134-141)
 void launch_gather_latents(const PtrList64& src, int nframes, int C, int P, f16* y, int y_cbt, hipStream_t s);
 struct OutList64 { uint8_t* p[64]; };

@@ -459,6 +459,33 @@ __global__ __launch_bounds__(256) void tokens_to_cb16_kernel(const float* __rest
     *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
 }
 
+// per-frame token blocks gathered by pointer (cross-session batches: every request has its own feature tensor)
+__global__ __launch_bounds__(256) void tokens_gather_to_cb16_kernel(const PtrList64 src, int P, int C, const float* __restrict__ add,
+                                                                     f16* __restrict__ y, int y_cbt, int CB) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;       // (cb, p, half)
+    if (i >= CB * P * 2) return;
+    const int half = i & 1, p = (i >> 1) % P, cb = (i >> 1) / P;
+    const float* x = reinterpret_cast<const float*>(src.p[n]);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cb * 16 + half * 8 + c;
+        float v = 0.f;
+        if (ch < C) {
+            v = x[(size_t)p * C + ch];
+            if (add) v += add[(size_t)p * C + ch];
+        }
+        o[c] = (f16)v;
+    }
+    *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + cb) * P + p) * 16 + half * 8) = o;
+}
+
+void launch_tokens_gather_to_cb16(const PtrList64& src, int N, int P, int C, const float* add, f16* y, int y_cbt, hipStream_t s) {
+    const int CB = (C + 15) / 16;
+    hipLaunchKernelGGL(tokens_gather_to_cb16_kernel, dim3((CB * P * 2 + 255) / 256, N), dim3(256), 0, s, src, P, C, add, y, y_cbt, CB);
+}
+
 void launch_tokens_to_cb16(const float* x, int N, int P, int C, const float* add, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
     const int CB = (C + 15) / 16;
     const long long total = (long long)N * CB * P * 2;

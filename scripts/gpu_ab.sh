@@ -1,4 +1,3 @@
-for t in 0 512 0 512 768; do LTK_CONV_PERSIST=$t python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('PERSIST=$t', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'])"; done
-for t in 0 512; do LTK_CONV_PERSIST=$t python bench.py --steps 10 --warmup 3 --sessions 16 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('s16 PERSIST=$t', d['value'], d['ms_per_step'])"; done
-for t in 0 512; do LTK_CONV_PERSIST=$t python bench.py --model musetalk --steps 4 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mt PERSIST=$t', d['value'], d['ms_per_step'])"; done
-python -m pytest tests/test_conv_gpu.py tests/test_wav2lip_gpu.py -m gpu -q 2>&1 | tail -2
+python -m pytest tests/test_conv_gpu.py tests/test_musetalk_gpu.py -m gpu -q 2>&1 | tail -2
+for i in 1 2; do python bench.py --model musetalk --steps 4 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mt', d['value'], d['ms_per_step'])"; done
+python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-60
