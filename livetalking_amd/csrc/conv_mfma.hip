@@ -497,7 +497,12 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
     }
 
     if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 &&
-        ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && env_int("LTK_CONV_V3_S2", 1)) {
+        ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && env_int("LTK_CONV_V3_S2", 1) &&
+        // measured (scripts/conv_sweep.py, 16 frames): the 2x-strided LDS operand reads make conv3 slower than the
+        // register-staged kernel on the wide, shallow downsamples (16->32 @256^2: 29 vs 18 us); it wins where the
+        // K loop is deep and split-K fills the chip (256->512 @16^2: 18 vs 27 us, 512->512 @8^2: 19 vs 46 us).
+        // The asymmetric-pad form exists only in conv3.
+        (Cin >= 256 || out_pad == 1 || env_int("LTK_CONV_V3_S2", 1) == 2)) {
         p->v3 = true; p->v3_G = 1; p->v3_T = 9; p->v3_S = 2;
     }
     if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {
