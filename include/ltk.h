@@ -136,6 +136,42 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
  * cached frame under the avatar's mask.  out: uint8 [H][W][3] (device or host, as ltk_paste_back). */
 int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream);
 
+/* ---- frame egress: the steps between paste_back_frame and the encoder ------------
+ * Reference: avatars/base_avatar.py:384-453 process_frames (silent path :407-428, transition blend :419-426 and
+ * :436-445, watermark :449), server/webrtc.py:190-193 (VideoFrame.from_ndarray(bgr24), converted to yuv420p by the
+ * encoder's swscale), streamout/rtmp.py:81-83.
+ *
+ * One egress session per render session: it owns the two cached frames of the transition effect
+ * (_last_silent_frame / _last_speaking_frame) and the watermark. */
+typedef struct ltk_egress ltk_egress;
+int ltk_egress_open(ltk_engine* e, int H, int W, ltk_egress** out);
+int ltk_egress_close(ltk_engine* e, ltk_egress* s);
+/* Watermark as a coverage bitmap: cv2.putText(..., thickness 1, LINE_8) sets every covered pixel to the colour, so
+ * the host rasterises the text once (cv2.putText on a zero image) and hands the non-zero rectangle over.
+ * mask host uint8 [h][w] (non-zero = covered) placed at (x, y); NULL removes the watermark. */
+int ltk_egress_watermark(ltk_engine* e, ltk_egress* s, const uint8_t* mask, int x, int y, int w, int h, int b, int g, int r);
+
+#define LTK_FMT_BGR24 0
+#define LTK_FMT_I420 1      /* Y [H][W], U [H/2][W/2], V [H/2][W/2]; H and W even; BT.601 limited range, swscale's integer matrix */
+#define LTK_SRC_WAV2LIP 0   /* composite = ltk_paste_back(avatar, idx, d_pred); d_pred NULL = the cached full frame (silent) */
+#define LTK_SRC_MUSETALK 1  /* composite = ltk_paste_blend(avatar, idx, d_pred); d_pred NULL = the cached full frame */
+#define LTK_SRC_HOST 2      /* frame = h_frame, host uint8 [H][W][3] (custom action video, base_avatar.py:411-414) */
+typedef struct ltk_egress_req {
+    int source;             /* LTK_SRC_* */
+    int avatar, idx;        /* bank frame (ignored for LTK_SRC_HOST) */
+    const void* d_pred;     /* device uint8 [256][256][3] or NULL */
+    const uint8_t* h_frame; /* LTK_SRC_HOST only */
+    int speaking;           /* which cache this frame refreshes: 1 = _last_speaking_frame, 0 = _last_silent_frame */
+    double alpha;           /* transition weight of THIS frame: out = addWeighted(other-state cache, 1-alpha, frame, alpha);
+                             * < 0 or >= 1 (or no cached frame of the other state yet): no blend */
+    int keep;               /* non-zero: store the (blended, un-watermarked) frame as this state's cache, as the reference
+                             * does while enable_transition is on */
+    int format;             /* LTK_FMT_* */
+    int chroma;             /* I420 chroma: 1 = 2x2 mean, 0 = top-left pixel of each quad */
+} ltk_egress_req;
+/* h_out: host uint8, H*W*3 bytes (BGR24) or H*W*3/2 bytes (I420); returns after the copy completed. */
+int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* req, uint8_t* h_out, void* stream);
+
 /* avatars/musetalk/whisper/audio2feature.py:15-23 Audio2Feature.__init__: the Whisper-tiny ENCODER
  * (transformers WhisperModel(...).encoder.state_dict(): conv1, conv2, embed_positions, layers.{0..3}.*, layer_norm),
  * fp32 host tensors.  The WhisperFeatureExtractor constants (n_fft 400, hop 160, 80 slaney mels, 30-s padding) are

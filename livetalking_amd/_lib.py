@@ -32,6 +32,11 @@ class MtReq(C.Structure):
     _fields_ = [("avatar", C.c_int), ("index", C.c_int), ("batch", C.c_int), ("d_feat", C.c_void_p), ("d_pred", C.c_void_p)]
 
 
+class EgressReq(C.Structure):
+    _fields_ = [("source", C.c_int), ("avatar", C.c_int), ("idx", C.c_int), ("d_pred", C.c_void_p), ("h_frame", C.c_void_p),
+                ("speaking", C.c_int), ("alpha", C.c_double), ("keep", C.c_int), ("format", C.c_int), ("chroma", C.c_int)]
+
+
 # every symbol include/ltk.h declares: (restype, argtypes)
 SYMBOLS = {
     "ltk_last_error": (C.c_char_p, []),
@@ -51,6 +56,10 @@ SYMBOLS = {
                                                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ltk_musetalk_infer": (C.c_int, [C.c_void_p, C.POINTER(MtReq), C.c_int, C.c_void_p]),
     "ltk_paste_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_egress_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ltk_egress_close": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ltk_egress_watermark": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ltk_egress_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(EgressReq), C.c_void_p, C.c_void_p]),
     "ltk_musetalk_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ltk_musetalk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "ltk_musetalk_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),

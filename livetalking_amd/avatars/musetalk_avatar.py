@@ -21,6 +21,7 @@ import threading
 
 import numpy as np
 
+from ..egress import SRC_MUSETALK, DeviceEgressMixin
 from ..engine import Engine
 from ..hostshim import BaseAvatar, register
 from .audio_features.whisper import Audio2Feature, WhisperASR
@@ -106,7 +107,9 @@ def warm_up(batch_size, model):
 
 
 @register("avatar", "musetalk")
-class MuseReal(BaseAvatar):
+class MuseReal(DeviceEgressMixin, BaseAvatar):
+    _egress_source = SRC_MUSETALK     # opt.egress = "bgr24" | "i420": device-side process_frames (egress.py)
+
     def __init__(self, opt, model, avatar):
         super().__init__(opt)
         self.model = model

@@ -24,6 +24,7 @@ import threading
 
 import numpy as np
 
+from ..egress import SRC_WAV2LIP, DeviceEgressMixin
 from ..engine import Engine
 from ..hostshim import BaseAvatar, mirror_index, register
 from ..scheduler import get_scheduler
@@ -112,7 +113,9 @@ def warm_up(batch_size, model, modelres=256):
 
 
 @register("avatar", "wav2lip")
-class LipReal(BaseAvatar):
+class LipReal(DeviceEgressMixin, BaseAvatar):
+    _egress_source = SRC_WAV2LIP      # opt.egress = "bgr24" | "i420": device-side process_frames (egress.py)
+
     def __init__(self, opt, model, avatar):
         super().__init__(opt)
         self.model = model

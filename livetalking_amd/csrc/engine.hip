@@ -1091,6 +1091,131 @@ int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, v
     return LTK_OK;
 }
 
+// ------------------------------------------------------------------ frame egress (base_avatar.py:384-453)
+struct ltk_egress {
+    int H = 0, W = 0;
+    std::mutex mu;                     // one frame at a time per session (the reference's process thread is serial)
+    uint8_t* d_cache[2] = {nullptr, nullptr};   // [0] _last_silent_frame, [1] _last_speaking_frame
+    bool have[2] = {false, false};
+    uint8_t* d_frame = nullptr;        // composite / uploaded frame
+    uint8_t* d_out = nullptr;          // converted frame before the D2H copy
+    uint8_t* d_wm = nullptr;
+    int wm_x = 0, wm_y = 0, wm_w = 0, wm_h = 0, wm_b = 0, wm_g = 0, wm_r = 0;
+};
+
+int ltk_egress_open(ltk_engine* e, int H, int W, ltk_egress** out) {
+    if (!e || !out || H <= 0 || W <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(hipSetDevice(e->device));
+    ltk_egress* s = new ltk_egress();
+    s->H = H; s->W = W;
+    const size_t bytes = (size_t)H * W * 3;
+    if (hipMalloc((void**)&s->d_cache[0], bytes) != hipSuccess || hipMalloc((void**)&s->d_cache[1], bytes) != hipSuccess ||
+        hipMalloc((void**)&s->d_frame, bytes) != hipSuccess || hipMalloc((void**)&s->d_out, bytes) != hipSuccess) {
+        (void)hipFree(s->d_cache[0]); (void)hipFree(s->d_cache[1]); (void)hipFree(s->d_frame); (void)hipFree(s->d_out);
+        delete s;
+        return fail(LTK_E_NOMEM, "egress session buffers");
+    }
+    *out = s;
+    return LTK_OK;
+}
+
+int ltk_egress_close(ltk_engine* e, ltk_egress* s) {
+    if (!e || !s) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(hipSetDevice(e->device));
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        (void)hipFree(s->d_cache[0]); (void)hipFree(s->d_cache[1]); (void)hipFree(s->d_frame); (void)hipFree(s->d_out); (void)hipFree(s->d_wm);
+    }
+    delete s;
+    return LTK_OK;
+}
+
+int ltk_egress_watermark(ltk_engine* e, ltk_egress* s, const uint8_t* mask, int x, int y, int w, int h, int b, int g, int r) {
+    if (!e || !s) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> gd(s->mu);
+    (void)hipFree(s->d_wm);
+    s->d_wm = nullptr;
+    s->wm_w = s->wm_h = 0;
+    if (!mask) return LTK_OK;
+    if (w <= 0 || h <= 0) return fail(LTK_E_INVALID, "empty watermark rectangle");
+    CHK(hipMalloc((void**)&s->d_wm, (size_t)w * h));
+    CHK(hipMemcpy(s->d_wm, mask, (size_t)w * h, hipMemcpyHostToDevice));
+    s->wm_x = x; s->wm_y = y; s->wm_w = w; s->wm_h = h; s->wm_b = b; s->wm_g = g; s->wm_r = r;
+    return LTK_OK;
+}
+
+int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* q, uint8_t* h_out, void* stream) {
+    if (!e || !s || !q || !h_out) return fail(LTK_E_INVALID, "bad arguments");
+    const int H = s->H, W = s->W;
+    const size_t bytes = (size_t)H * W * 3;
+    if (q->format != LTK_FMT_BGR24 && q->format != LTK_FMT_I420) return fail(LTK_E_INVALID, "unknown output format");
+    if (q->format == LTK_FMT_I420 && ((H | W) & 1)) return fail(LTK_E_INVALID, "I420 needs even frame dimensions");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> gs(s->mu);
+    StreamLease sl(e, stream);
+    const uint8_t* src = nullptr;
+    if (q->source == LTK_SRC_HOST) {
+        if (!q->h_frame) return fail(LTK_E_INVALID, "LTK_SRC_HOST without h_frame");
+        CHK(hipMemcpyAsync(s->d_frame, q->h_frame, bytes, hipMemcpyHostToDevice, sl.s));
+        src = s->d_frame;
+    } else if (q->source == LTK_SRC_WAV2LIP) {
+        Avatar a;
+        {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            auto it = e->avatars.find(q->avatar);
+            if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+            a = it->second;
+        }
+        if (q->idx < 0 || q->idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
+        if (a.H != H || a.W != W) return fail(LTK_E_INVALID, "avatar frame size differs from the egress session");
+        const uint8_t* full = a.d_full + (size_t)q->idx * bytes;
+        if (q->d_pred) {
+            const int32_t* c = a.coords.data() + 4 * (size_t)q->idx;
+            launch_paste(full, H, W, (const uint8_t*)q->d_pred, c[0], c[1], c[2], c[3], s->d_frame, sl.s);
+            src = s->d_frame;
+        } else {
+            src = full;                               // base_avatar.py:417: the cached frame itself
+        }
+    } else if (q->source == LTK_SRC_MUSETALK) {
+        const uint8_t *full, *mask;
+        int32_t fb[4], cb[4];
+        {
+            std::lock_guard<std::mutex> g(e->pool_mu);
+            auto it = e->mt_avatars.find(q->avatar);
+            if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
+            const MtAvatar& a = it->second;
+            if (q->idx < 0 || q->idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
+            if (a.H != H || a.W != W) return fail(LTK_E_INVALID, "avatar frame size differs from the egress session");
+            full = a.d_full + (size_t)q->idx * bytes;
+            mask = a.d_masks + a.mask_off[q->idx];
+            for (int k = 0; k < 4; ++k) { fb[k] = a.face_box[4 * q->idx + k]; cb[k] = a.crop_box[4 * q->idx + k]; }
+        }
+        if (q->d_pred) {
+            launch_paste_blend(full, H, W, (const uint8_t*)q->d_pred, fb[0], fb[1], fb[2], fb[3], cb[0], cb[1], cb[2], cb[3], mask,
+                               s->d_frame, sl.s);
+            src = s->d_frame;
+        } else {
+            src = full;
+        }
+    } else {
+        return fail(LTK_E_INVALID, "unknown frame source");
+    }
+    const int me = q->speaking ? 1 : 0, other = me ^ 1;
+    const bool blend = q->alpha >= 0.0 && q->alpha < 1.0 && s->have[other];
+    // cv2.addWeighted(other, 1 - alpha, frame, alpha, 0): the weights are Python doubles there, OpenCV's 8-bit kernel
+    // computes in float32
+    const float w_src = (float)q->alpha, w_prev = (float)(1.0 - q->alpha);
+    launch_egress(src, blend ? s->d_cache[other] : nullptr, w_prev, w_src, q->keep ? s->d_cache[me] : nullptr, s->d_wm, s->wm_x,
+                  s->wm_y, s->wm_w, s->wm_h, s->wm_b, s->wm_g, s->wm_r, s->d_out, H, W, q->format == LTK_FMT_I420, q->chroma, sl.s);
+    CHK(hipGetLastError());
+    if (q->keep) s->have[me] = true;
+    const size_t out_bytes = q->format == LTK_FMT_I420 ? bytes / 2 : bytes;
+    CHK(hipMemcpyAsync(h_out, s->d_out, out_bytes, hipMemcpyDeviceToHost, sl.s));
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
 int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* feat, int B, float* unet_out, float* image,
                               uint8_t* frames) {
     if (!e || !latents || !feat || B <= 0) return fail(LTK_E_INVALID, "bad arguments");

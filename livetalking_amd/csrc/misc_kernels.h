@@ -56,4 +56,9 @@ void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int
 void launch_paste_blend(const uint8_t* full, int H, int W, const uint8_t* pred256, int x1, int y1, int x2, int y2, int xs, int ys,
                         int xe, int ye, const uint8_t* mask, uint8_t* out, hipStream_t s);
 
+// Frame egress (base_avatar.py:419-449 transition blend + watermark, BGR24 -> I420): see egress_kernels.hip
+void launch_egress(const uint8_t* src, const uint8_t* prev, float w_prev, float w_src, uint8_t* cache, const uint8_t* wm, int wm_x,
+                   int wm_y, int wm_w, int wm_h, int wm_b, int wm_g, int wm_r, uint8_t* out, int H, int W, int i420, int chroma,
+                   hipStream_t s);
+
 }  // namespace ltk

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void paste_blend_kernel(const uint8_t* __restr
                                                            const uint8_t* __restrict__ pred, int x1, int y1, int x2, int y2,
                                                            int xs, int ys, int xe, int ye, const uint8_t* __restrict__ mask,
                                                            uint8_t* __restrict__ out) {
+#pragma clang fp contract(off)      // blendLinear is products-then-sum; no fused multiply-add
     const size_t total = (size_t)H * W * 3;
     const size_t b0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (b0 >= total) return;

@@ -1,0 +1,180 @@
+"""Device-side frame egress: the reference's `BaseAvatar.process_frames`
+(avatars/base_avatar.py:384-460) with everything between `res_frame_queue.get` and `output.push_video_frame` done on
+the GPU in one call per frame: paste-back composite (or the silent / custom frame), the speaking<->silent transition
+`cv2.addWeighted`, the "LiveTalking" watermark, and optionally BGR24 -> I420 so that the host copies 1.5 instead of
+3 bytes per pixel and the encoder skips its swscale pass (server/webrtc.py:190-193).
+
+Opt-in: `opt.egress` in {"bgr24", "i420"} makes the plugin classes use `process_frames` below instead of the base
+class's loop; unset, the reference's own loop runs unchanged and calls `paste_back_frame`.
+"""
+from __future__ import annotations
+
+import queue
+import time
+
+import numpy as np
+
+FMT_BGR24, FMT_I420 = 0, 1
+SRC_WAV2LIP, SRC_MUSETALK, SRC_HOST = 0, 1, 2
+
+WATERMARK_TEXT = "LiveTalking"          # base_avatar.py:449
+WATERMARK_ORG = (10, 20)
+WATERMARK_COLOR = (128, 128, 128)
+
+
+def watermark_mask(H: int, W: int):
+    """Coverage bitmap of the reference's cv2.putText call, rasterised by OpenCV itself so the glyphs are its own.
+    Returns (mask uint8 [h][w], x, y) or None when OpenCV is not installed (tests / the GPU box)."""
+    try:
+        import cv2  # type: ignore
+    except Exception:  # noqa: BLE001
+        return None
+    canvas = np.zeros((H, W), dtype=np.uint8)
+    cv2.putText(canvas, WATERMARK_TEXT, WATERMARK_ORG, cv2.FONT_HERSHEY_SIMPLEX, 0.3, 255, 1)
+    ys, xs = np.nonzero(canvas)
+    if ys.size == 0:
+        return None
+    y0, y1, x0, x1 = int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1
+    return np.ascontiguousarray(canvas[y0:y1, x0:x1]), x0, y0
+
+
+class I420Frame(np.ndarray):
+    """uint8 [H*3/2][W] planar YUV 4:2:0 as `av.VideoFrame.from_ndarray(..., format="yuv420p")` takes it."""
+    width: int
+    height: int
+
+    def planes(self):
+        H, W = self.height, self.width
+        flat = np.asarray(self).reshape(-1)
+        y = flat[: H * W].reshape(H, W)
+        u = flat[H * W: H * W + (H // 2) * (W // 2)].reshape(H // 2, W // 2)
+        v = flat[H * W + (H // 2) * (W // 2):].reshape(H // 2, W // 2)
+        return y, u, v
+
+
+class DeviceEgress:
+    """One per render session: the engine-side egress session plus the transition clock of process_frames."""
+
+    def __init__(self, engine, H: int, W: int, source: int, avatar_id: int, fmt: str = "bgr24", enable_transition: bool = False,
+                 transition_duration: float = 0.1, watermark="auto", chroma: int = 1, clock=time.time):
+        if fmt not in ("bgr24", "i420"):
+            raise ValueError("egress format must be 'bgr24' or 'i420'")
+        if fmt == "i420" and (H % 2 or W % 2):
+            raise ValueError("I420 needs even frame dimensions")
+        self.engine, self.H, self.W = engine, int(H), int(W)
+        self.source, self.avatar_id = int(source), int(avatar_id)
+        self.fmt = FMT_I420 if fmt == "i420" else FMT_BGR24
+        self.chroma = int(chroma)
+        self.enable_transition = bool(enable_transition)          # base_avatar.py:384
+        self.transition_duration = float(transition_duration)     # :389
+        self._clock = clock
+        self._last_speaking = False                               # :386
+        self._transition_start = clock()                          # :387
+        self._h = engine.egress_open(self.H, self.W)
+        if watermark == "auto":
+            watermark = watermark_mask(self.H, self.W)
+        if watermark is not None:
+            mask, x, y = watermark
+            engine.egress_watermark(self._h, mask, x, y, WATERMARK_COLOR)
+
+    def close(self):
+        if self._h:
+            self.engine.egress_close(self._h)
+            self._h = 0
+
+    def _alpha(self, speaking: bool) -> float:
+        # base_avatar.py:402-406: a state change restarts the transition clock
+        if speaking != self._last_speaking:
+            self._transition_start = self._clock()
+        self._last_speaking = speaking
+        if not self.enable_transition:
+            return -1.0
+        dt = self._clock() - self._transition_start
+        if dt < self.transition_duration:                         # :421 / :438
+            return min(1.0, dt / self.transition_duration)
+        return -1.0
+
+    def _out(self):
+        if self.fmt == FMT_I420:
+            out = np.empty((self.H * 3 // 2, self.W), dtype=np.uint8).view(I420Frame)
+            out.width, out.height = self.W, self.H
+            return out
+        return np.empty((self.H, self.W, 3), dtype=np.uint8)
+
+    def speaking_frame(self, d_pred_ptr: int, idx: int) -> np.ndarray:
+        """base_avatar.py:429-447: paste_back_frame + silent->speaking blend (+ watermark, format)."""
+        alpha = self._alpha(True)
+        return self.engine.egress_frame(self._h, self._out(), self.source, self.avatar_id, idx, d_pred_ptr, None, True, alpha,
+                                        self.enable_transition, self.fmt, self.chroma)
+
+    def silent_frame(self, idx: int, custom_frame: np.ndarray = None) -> np.ndarray:
+        """base_avatar.py:408-428: the cached full frame (or a custom-action frame) + speaking->silent blend."""
+        alpha = self._alpha(False)
+        if custom_frame is not None:
+            custom_frame = np.ascontiguousarray(custom_frame, dtype=np.uint8)
+            if custom_frame.shape != (self.H, self.W, 3):
+                raise ValueError("custom frame size differs from the avatar's")
+            return self.engine.egress_frame(self._h, self._out(), SRC_HOST, 0, 0, 0, custom_frame, False, alpha,
+                                            self.enable_transition, self.fmt, self.chroma)
+        return self.engine.egress_frame(self._h, self._out(), self.source, self.avatar_id, idx, 0, None, False, alpha,
+                                        self.enable_transition, self.fmt, self.chroma)
+
+
+class DeviceEgressMixin:
+    """`process_frames` for LipReal / MuseReal when `opt.egress` is set: the control flow of
+    avatars/base_avatar.py:384-460 (queue protocol, speaking flag, custom-action index, audio push, recording), with the
+    per-frame pixel work delegated to DeviceEgress.  `_egress_source` is set by the plugin class."""
+
+    _egress_source = SRC_WAV2LIP
+
+    def _make_egress(self):
+        h, w = self.frame_list_cycle[0].shape[:2]
+        return DeviceEgress(self.model.engine, h, w, self._egress_source, self._aid, fmt=getattr(self.opt, "egress", "bgr24"),
+                            enable_transition=bool(getattr(self.opt, "enable_transition", False)))
+
+    def process_frames(self, quit_event, *args, **kwargs):
+        if not getattr(self.opt, "egress", None):
+            return super().process_frames(quit_event, *args, **kwargs)
+        from .hostshim import mirror_index
+        eg = self._make_egress()
+        output = getattr(self, "output", None)
+        if output is not None:
+            output.start()
+        try:
+            while not quit_event.is_set():
+                try:
+                    res_frame, audio_frames, idx = self.res_frame_queue.get(block=True, timeout=1)
+                except queue.Empty:
+                    continue
+                if audio_frames[0].type != 0 and audio_frames[1].type != 0:      # :407 all silence
+                    self.speaking = False
+                    audiotype = audio_frames[0].type
+                    custom = None
+                    cidx = getattr(self, "custom_index", {})
+                    if cidx.get(audiotype) is not None:                          # :410-414
+                        cyc = self.custom_img_cycle[audiotype]
+                        custom = cyc[mirror_index(len(cyc), cidx[audiotype])]
+                        cidx[audiotype] += 1
+                    frame = eg.silent_frame(idx, custom)
+                else:
+                    self.speaking = True
+                    try:
+                        frame = eg.speaking_frame(res_frame.data_ptr(), idx)
+                    except Exception as e:  # noqa: BLE001 - base_avatar.py:432-436 logs and drops the frame
+                        import logging
+                        logging.getLogger(__name__).warning("paste_back_frame error: %s", e)
+                        continue
+                if output is not None:
+                    output.push_video_frame(frame)
+                if hasattr(self, "record_video_data"):
+                    self.record_video_data(frame)
+                for af in audio_frames:                                          # :455-460
+                    pcm = (af.data * 32767).astype(np.int16)
+                    if output is not None:
+                        output.push_audio_frame(pcm, af.userdata)
+                    if hasattr(self, "record_audio_data"):
+                        self.record_audio_data(pcm)
+        finally:
+            eg.close()
+            if output is not None and hasattr(output, "stop"):
+                output.stop()

@@ -171,6 +171,33 @@ class Engine:
         _lib.check(self._lib.ltk_paste_blend(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr), out.ctypes.data, 0,
                                              C.c_void_p(stream)))
 
+    # ---- frame egress (include/ltk.h: ltk_egress_*)
+    def egress_open(self, H: int, W: int) -> int:
+        h = C.c_void_p()
+        _lib.check(self._lib.ltk_egress_open(self._h, int(H), int(W), C.byref(h)))
+        return h.value
+
+    def egress_close(self, session: int) -> None:
+        if self._h:
+            _lib.check(self._lib.ltk_egress_close(self._h, C.c_void_p(session)))
+
+    def egress_watermark(self, session: int, mask, x: int = 0, y: int = 0, color=(128, 128, 128)) -> None:
+        if mask is None:
+            _lib.check(self._lib.ltk_egress_watermark(self._h, C.c_void_p(session), None, 0, 0, 0, 0, 0, 0, 0))
+            return
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        _lib.check(self._lib.ltk_egress_watermark(self._h, C.c_void_p(session), mask.ctypes.data, int(x), int(y), mask.shape[1],
+                                                  mask.shape[0], int(color[0]), int(color[1]), int(color[2])))
+
+    def egress_frame(self, session: int, out: np.ndarray, source: int, avatar_id: int = 0, idx: int = 0, d_pred_ptr: int = 0,
+                     h_frame: np.ndarray = None, speaking: bool = True, alpha: float = -1.0, keep: bool = False, fmt: int = 0,
+                     chroma: int = 1, stream: int = 0) -> np.ndarray:
+        req = _lib.EgressReq(int(source), int(avatar_id), int(idx), C.c_void_p(d_pred_ptr or None),
+                             C.c_void_p(h_frame.ctypes.data if h_frame is not None else None), int(bool(speaking)), float(alpha),
+                             int(bool(keep)), int(fmt), int(chroma))
+        _lib.check(self._lib.ltk_egress_frame(self._h, C.c_void_p(session), C.byref(req), out.ctypes.data, C.c_void_p(stream)))
+        return out
+
     def musetalk_forward_host(self, latents: np.ndarray, feat: np.ndarray, want_image=True, want_frames=True):
         latents = np.ascontiguousarray(latents, dtype=np.float32).reshape(-1, 8, 32, 32)
         feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(-1, 50, 384)
