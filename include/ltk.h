@@ -119,6 +119,15 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
                                  const int32_t* crop_boxes, const uint8_t* masks, const int64_t* mask_offsets, int n,
                                  int H, int W, int* avatar_id);
 
+/* BASELINE configs[4] "fp8 conv path": before ltk_musetalk_load, ask for the ResnetBlock2D 3x3 convolutions of the U-Net
+ * and the VAE decoder (the GroupNorm -> SiLU -> conv pairs) to run on OCP e4m3 operands: the GroupNorm kernel writes
+ * saturate(y * act_scale) as fp8, weights are quantised per output channel (224 / max|w|), accumulation stays fp32 and
+ * the residual stream fp16.  act_scale <= 0 selects the default 8 (e4m3 then covers |y| <= 56 with 2^-12 resolution
+ * near zero).  Everything else (attention, linears, up/down-samplers, conv_in/out) stays fp16. */
+int ltk_musetalk_set_fp8(ltk_engine* e, int enable, float act_scale);
+/* conv / linear MACs per frame of the loaded U-Net + VAE decoder, and the part of them on fp8 operands */
+int ltk_musetalk_info(ltk_engine* e, double* macs_per_frame, double* macs_fp8_per_frame);
+
 typedef struct ltk_mt_req {
     int avatar;            /* id returned by ltk_musetalk_avatar_register */
     int index;             /* running frame index (mirror_index over the latent bank) */
@@ -237,6 +246,17 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
                    const float* weight, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                    int transposed, int out_pad, const float* scale, const float* shift,
                    const void* d_res, int relu, void* d_y, int iters, float* ms_avg);
+
+/* host-side fp32 -> OCP e4m3fn conversion of the weight packer (round to nearest even, saturating at +-448); no GPU needed */
+int ltk_f32_to_e4m3(const float* in, size_t n, uint8_t* out);
+
+/* fp8-operand 3x3 stride-1 pad-1 conv used by kernel unit tests and per-layer timing: x device e4m3 bytes
+ * [N][Cin/32][H][W][32] holding round(x * act_scale), weight host fp32 [Cout][Cin][3][3] (quantised per output channel
+ * by the engine), y = act((conv(x, w)) * scale + shift + res) as fp16 [N][Cout/16][H][W][16]; act: 0 none, 1 ReLU,
+ * 2 GELU, 3 SiLU. */
+int ltk_conv2d_fp8(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin, const float* weight, int Cout,
+                   const float* scale, const float* shift, float act_scale, const void* d_res, int act, void* d_y, int iters,
+                   float* ms_avg);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,8 @@ SYMBOLS = {
     "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p]),
     "ltk_paste_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_musetalk_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int, C.POINTER(NamedTensor), C.c_int, C.c_int]),
+    "ltk_musetalk_set_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "ltk_musetalk_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ltk_musetalk_avatar_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ltk_musetalk_infer": (C.c_int, [C.c_void_p, C.POINTER(MtReq), C.c_int, C.c_void_p]),
@@ -76,6 +78,9 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.POINTER(C.c_float)]),
+    "ltk_f32_to_e4m3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ltk_conv2d_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None

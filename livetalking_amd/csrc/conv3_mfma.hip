@@ -40,6 +40,7 @@ namespace ltk {
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef long i64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct K3Args {
@@ -84,12 +85,19 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 //   o : 0 0 0 0 | 1 1 | 2 2 | 3
 //   g : 0 1 2 3 | 1 3 | 2 3 | 3
 // one work item = one (k split, pixel tile, cout tile); `bid` is its logical id
-template <int G, int NBT, int PXW, int NC8, int T, int S>
+// Q = 1: fp8 (OCP e4m3) operands.  A "channel block" is then 32 fp8 channels = the same 32 bytes per pixel, the LDS images,
+// the DMA descriptors and the swizzle are byte-identical to the fp16 case, and a lane's 16-byte fragment feeds TWO
+// v_mfma_f32_32x32x16_fp8_fp8 (bytes 0-7, then 8-15): half the LDS / DMA / HBM bytes per MAC at the same MFMA rate.
+// The host packs the fp8 weights as pairs in 16-bit units (conv_plan_create, quant = 1) so that byte i of an A
+// fragment and byte i of a B fragment are the same input channel.
+template <int G, int NBT, int PXW, int NC8, int T, int S, int Q>
 __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem) {
     constexpr int BN = NBT * 32;
     constexpr int MAXA = k3_maxa(PXW, NC8, S);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
     static_assert(G == 1 || (G == 4 && T == 9 && NBT == 1), "merged convT: 9 taps, 32 couts per block");
+    static_assert(Q == 0 || G == 1, "fp8 operands: plain convolutions only");
+    constexpr int MPP = Q ? 2 : 1;         // MFMAs per (cout subtile, pixel subtile) pair and k16 plane pair
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,11 +242,19 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
 #pragma unroll
                     for (int i = 0; i < NBT; ++i)
 #pragma unroll
-                        for (int j = 0; j < PXW; ++j)
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[sl][i], xa[sl][j], acc[0][i][j], 0, 0, 0);
+                        for (int j = 0; j < PXW; ++j) {
+                            if constexpr (Q == 0) {
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[sl][i], xa[sl][j], acc[0][i][j], 0, 0, 0);
+                            } else {
+                                const i64x2 wq = __builtin_bit_cast(i64x2, wf[sl][i]);
+                                const i64x2 xq = __builtin_bit_cast(i64x2, xa[sl][j]);
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wq[0], xq[0], acc[0][i][j], 0, 0, 0);
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wq[1], xq[1], acc[0][i][j], 0, 0, 0);
+                            }
+                        }
                     if (t + 1 < T) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);   // DS reads of tap t+1 first
-                        __builtin_amdgcn_sched_group_barrier(0x008, NBT * PXW, 0);   // then the MFMAs of tap t
+                        __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);         // DS reads of tap t+1 first
+                        __builtin_amdgcn_sched_group_barrier(0x008, NBT * PXW * MPP, 0);   // then the MFMAs of tap t
                     }
                 }
             } else {
@@ -447,7 +463,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
 // per-block dispatch, kernarg fetch and descriptor set-up were a fixed ~16 us per launch; a non-persistent launch
 // (gridDim.x == nitems) is the same code with one trip.  Logical ids are XCD-contiguous: consecutive ids (same
 // pixel tile, different cout tiles) run on one XCD and share its L2.
-template <int G, int NBT, int PXW, int NC8, int T, int S = 1>
+template <int G, int NBT, int PXW, int NC8, int T, int S = 1, int Q = 0>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nblk = gridDim.x;
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     for (int item = first; item < a.nitems; item += nblk) {
         if (item != first) __syncthreads();      // every wave is out of the previous item's LDS stages
-        conv3_item<G, NBT, PXW, NC8, T, S>(a, item, smem);
+        conv3_item<G, NBT, PXW, NC8, T, S, Q>(a, item, smem);
     }
 }
 
@@ -513,6 +529,13 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
     K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
     K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
 #undef K3CASE
+    return nullptr;
+}
+
+static k3_kernel_t k3_pick_q8(int NBT, int PXW, int NC8) {     // fp8 operands: 3x3 stride 1
+#define K3Q(n, p, c) if (NBT == n && PXW == p && NC8 == c) return (k3_kernel_t)conv3_kernel<1, n, p, c, 9, 1, 1>
+    K3Q(2, 4, 2); K3Q(2, 2, 2); K3Q(1, 4, 2); K3Q(1, 2, 2); K3Q(2, 2, 4); K3Q(1, 2, 4);
+#undef K3Q
     return nullptr;
 }
 
@@ -651,7 +674,8 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     a.lds_scale_off = (int)lds;
     if (T != 1) lds += 2 * BN * sizeof(float);
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
-    k3_kernel_t k = (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
+    if (p.q8 && !(G == 1 && T == 9 && S == 1)) { if (err) *err = "conv3: fp8 operands are implemented for 3x3 stride-1 convs"; return -1; }
+    k3_kernel_t k = p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }

@@ -70,6 +70,10 @@ struct ConvPlan {
     int v3_G = 1;                         // 1 = conv, 4 = merged transposed conv (4 sub-pixel phases per block)
     int v3_T = 9;                         // taps: 9 (3x3 / merged convT) or 1 (1x1)
     int v3_S = 1;                         // stride (3x3 pad 1 only): 1 or 2
+    // fp8 operands (conv3, 3x3 stride 1): the input is [N][CinReal/32][H][W][32] e4m3 bytes holding x * act_scale; Cin
+    // above then counts 16-bit units (= CinReal / 2) so that every byte offset of the fp16 path carries over
+    bool q8 = false;
+    int CinReal = 0;
     ConvPhase phase[kMaxPhases];
     // device data
     f16* d_w = nullptr;
@@ -88,7 +92,14 @@ struct ConvPlan {
 // channel-chunk width, which is baked into the weight pack order.
 int conv_plan_create(ConvPlan* p, const float* weight, int Cin, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
-                     const float* scale, const float* shift, std::string* err, int hint_hw = 0);
+                     const float* scale, const float* shift, std::string* err, int hint_hw = 0,
+                     int quant = 0, float act_scale = 1.f);
+// `quant` = 1: e4m3 weights with one scale per output channel (224 / max|w|), folded together with `act_scale`
+// (what the producer of the fp8 input multiplied by) into the epilogue scale.  3x3 stride-1 pad-1 convs, Cin % 32 == 0.
+
+// fp32 -> OCP e4m3fn byte, round to nearest even, saturating to +-448 (host side of the weight packer; the device side
+// uses v_cvt_pk_fp8_f32)
+unsigned char f32_to_e4m3(float v);
 void conv_plan_destroy(ConvPlan* p);
 
 struct ConvIO {

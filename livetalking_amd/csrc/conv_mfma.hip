@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 namespace ltk {
@@ -440,10 +441,41 @@ double ConvPlan::macs_per_image(int H, int W) const {
         }                                                                             \
     } while (0)
 
-int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, int kh, int kw,
+unsigned char f32_to_e4m3(float v) {
+    // OCP e4m3fn: 1-4-3, bias 7, max 448 (0x7E), no infinities; subnormal step 2^-9
+    unsigned char sign = 0;
+    if (v < 0.f) { sign = 0x80; v = -v; }
+    if (!(v == v)) return 0x7F;                      // NaN
+    if (v >= 448.f) return sign | 0x7E;              // saturate (incl. the half-way case above 448)
+    if (v < 0.0009765625f) return sign;              // < 2^-10: rounds to zero (2^-10 itself is a tie -> even = 0)
+    int e;
+    (void)std::frexp(v, &e);                         // v = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                   // v = 1.x * 2^E
+    if (E < -6) E = -6;                              // subnormal range shares the exponent of the smallest normal
+    const float q = std::ldexp(v, 3 - E);            // in units of the spacing 2^(E-3)
+    float r = std::nearbyint(q);                     // round half to even (default rounding mode)
+    int mant = (int)r;                               // normals: 8..16, subnormals: 0..8
+    int be = E + 7;
+    if (E == -6 && mant < 8) return sign | (unsigned char)mant;             // subnormal (biased exponent 0)
+    if (mant == 16) { mant = 8; ++be; }
+    if (be > 15 || (be == 15 && mant - 8 > 6)) return sign | 0x7E;
+    return sign | (unsigned char)((be << 3) | (mant - 8));
+}
+
+int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
-                     const float* scale, const float* shift, std::string* err, int hint_hw) {
+                     const float* scale, const float* shift, std::string* err, int hint_hw, int quant, float act_scale) {
     *p = ConvPlan();
+    if (quant) {
+        if (transposed || kh != 3 || kw != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || CinArg % 32 != 0) {
+            if (err) *err = "fp8 operands: 3x3 stride-1 pad-1 convs with Cin % 32 == 0 only";
+            return -1;
+        }
+        p->q8 = true;
+    }
+    p->CinReal = CinArg;
+    // fp8: two channels per 16-bit unit; everything below (chunking, pack order, launch geometry) sees CinArg / 2 "channels"
+    const int CinReal = quant ? CinArg / 2 : CinArg;
     // channel-blocked layout: whole 16-channel blocks; inputs of <= 8 channels are plain [N][H][W][8]
     const int Cin = CinReal <= 8 ? 8 : (CinReal + 15) / 16 * 16;
     p->kh = kh; p->kw = kw; p->sh = sh; p->sw = sw; p->ph = ph; p->pw = pw;
@@ -563,6 +595,25 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
         if (!transposed) return weight[(((size_t)co * CinReal + ci) * kh + ky) * kw + kx];
         return weight[(((size_t)ci * Cout + co) * kh + ky) * kw + kx];
     };
+    // fp8: per-output-channel scale, and the 16-bit unit (two consecutive input channels, low byte first)
+    std::vector<float> wq_scale;
+    if (quant) {
+        wq_scale.assign(Cout, 1.f);
+        const size_t per = (size_t)CinArg * 9;
+        for (int co = 0; co < Cout; ++co) {
+            float m = 0.f;
+            for (size_t i = 0; i < per; ++i) m = std::max(m, std::fabs(weight[(size_t)co * per + i]));
+            if (m > 0.f) wq_scale[co] = 224.f / m;
+        }
+    }
+    auto wbits = [&](int co, int ci, int ky, int kx) -> uint16_t {
+        if (!quant) { const f16 h = (f16)wval(co, ci, ky, kx); uint16_t u; memcpy(&u, &h, 2); return u; }
+        if (ci >= CinReal) return 0;
+        const float s = wq_scale[co];
+        const float lo = weight[(((size_t)co * CinArg + 2 * ci) * 3 + ky) * 3 + kx] * s;
+        const float hi = weight[(((size_t)co * CinArg + 2 * ci + 1) * 3 + ky) * 3 + kx] * s;
+        return (uint16_t)(f32_to_e4m3(lo) | (f32_to_e4m3(hi) << 8));
+    };
 
     std::vector<PhaseMeta> metas(phases.size());
     for (size_t pi = 0; pi < phases.size(); ++pi) {
@@ -592,7 +643,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
                                 co = (tt / (kh * kw)) * 16 + c16; ky = pos / kw; kx = pos % kw;
                             }
                             f16* dst = base + ((((size_t)(nt * nchunks + c) * Tp + t) * NC8 + pl) * 32 + n) * 8;
-                            for (int j = 0; j < 8; ++j) dst[j] = (f16)wval(co, c8 * 8 + j, ky, kx);
+                            for (int j = 0; j < 8; ++j) { const uint16_t u = wbits(co, c8 * 8 + j, ky, kx); memcpy(&dst[j], &u, 2); }
                         }
                     }
     }
@@ -602,6 +653,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinReal, int Cout, in
     for (int i = 0; i < lCout; ++i) {
         const int co = p->gemm_1x1_expand ? ((i >> 4) / (kh * kw)) * 16 + (i & 15) : i;
         sc[i] = scale ? scale[co] : 1.f; sf[i] = shift ? shift[co] : 0.f;
+        if (quant) sc[i] /= wq_scale[co] * act_scale;        // acc = sum (w s_w)(x s_a)
     }
 
     p->w_bytes = packed.size() * sizeof(f16);

@@ -185,6 +185,8 @@ struct ltk_engine {
     // musetalk
     MtGraph* mt = nullptr;
     int mt_max_frames = 0;
+    int mt_fp8 = 0;                    // ltk_musetalk_set_fp8
+    float mt_fp8_ascale = 8.f;
     MtGraph* vae_enc = nullptr;           // AutoencoderKL encoder graph (avatar preparation), 2 images per face
     int vae_enc_faces = 0;
     MtGraph* whisper = nullptr;           // Whisper-tiny encoder graph (Audio2Feature)
@@ -915,7 +917,67 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
     return LTK_OK;
 }
 
+int ltk_f32_to_e4m3(const float* in, size_t n, uint8_t* out) {
+    if (!in || !out) return fail(LTK_E_INVALID, "bad arguments");
+    for (size_t i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);
+    return LTK_OK;
+}
+
+int ltk_conv2d_fp8(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin, const float* weight, int Cout,
+                   const float* scale, const float* shift, float act_scale, const void* d_res, int act, void* d_y, int iters,
+                   float* ms_avg) {
+    if (!e || !d_x || !weight || !d_y) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(hipSetDevice(e->device));
+    ConvPlan plan;
+    std::string err;
+    int rc = conv_plan_create(&plan, weight, Cin, Cout, 3, 3, 1, 1, 1, 1, false, 0, scale, shift, &err, H * W, 1, act_scale);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
+    ConvIO io;
+    io.partial = e->d_partial; io.partial_cap = e->partial_cap;
+    io.x = (const f16*)d_x; io.N = N; io.H = H; io.W = W; io.x_ld = plan.Cin; io.x_coff = 0;   // 16-bit units
+    io.y = (f16*)d_y; io.y_ld = Cout; io.y_coff = 0;
+    io.res = (const f16*)d_res; io.res_ld = Cout; io.res_coff = 0;
+    io.relu = 0; io.act = act;
+    hipStream_t s = e->compute;
+    std::lock_guard<std::mutex> g(e->mu);
+    rc = conv_launch(plan, io, s, &err);
+    if (!rc && iters > 0 && ms_avg) {
+        hipEvent_t t0, t1;
+        (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+        (void)hipEventRecord(t0, s);
+        for (int i = 0; i < iters && !rc; ++i) rc = conv_launch(plan, io, s, &err);
+        (void)hipEventRecord(t1, s);
+        (void)hipEventSynchronize(t1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        *ms_avg = ms / iters;
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    }
+    hipError_t he = hipStreamSynchronize(s);
+    conv_plan_destroy(&plan);
+    if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
+    if (he != hipSuccess) return fail(LTK_E_HIP, std::string("conv kernel: ") + hipGetErrorString(he));
+    return LTK_OK;
+}
+
 // ================================================================================ MuseTalk
+int ltk_musetalk_set_fp8(ltk_engine* e, int enable, float act_scale) {
+    if (!e) return fail(LTK_E_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->mt) return fail(LTK_E_STATE, "ltk_musetalk_set_fp8 must precede ltk_musetalk_load");
+    e->mt_fp8 = enable ? 1 : 0;
+    e->mt_fp8_ascale = act_scale > 0.f ? act_scale : 8.f;
+    return LTK_OK;
+}
+
+int ltk_musetalk_info(ltk_engine* e, double* macs_per_frame, double* macs_fp8_per_frame) {
+    if (!e) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    if (macs_per_frame) *macs_per_frame = mt_macs_per_frame(e->mt);
+    if (macs_fp8_per_frame) *macs_fp8_per_frame = mt_macs_fp8_per_frame(e->mt);
+    return LTK_OK;
+}
+
 int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae,
                       int max_frames) {
     if (!e || !unet_sd || !vae_sd || n_unet <= 0 || n_vae <= 0) return fail(LTK_E_INVALID, "bad arguments");
@@ -924,6 +986,7 @@ int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet
     if (e->mt) return fail(LTK_E_STATE, "a MuseTalk model is already loaded in this engine");
     CHK(hipSetDevice(e->device));
     MtGraph* mg = mt_graph_new();
+    mt_set_fp8(mg, e->mt_fp8, e->mt_fp8_ascale);
     const int rc = mt_build(mg, unet_sd, n_unet, vae_sd, n_vae, max_frames);
     if (rc) {
         const std::string msg = mt_graph_error(mg);

@@ -15,6 +15,10 @@ struct MtTensor;
 MtGraph* mt_graph_new();
 void mt_graph_delete(MtGraph* g);
 const char* mt_graph_error(const MtGraph* g);
+// before mt_build: run the ResnetBlock2D 3x3 convs on fp8 (e4m3) operands; act_scale = what GroupNorm+SiLU outputs are
+// multiplied by before the saturating conversion (<= 0 keeps the default 8)
+void mt_set_fp8(MtGraph* g, int on, float act_scale);
+double mt_macs_fp8_per_frame(const MtGraph* g);
 // builds U-Net then VAE decoder; returns 0 or a negative code
 int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames);
 // tensors the engine feeds / reads

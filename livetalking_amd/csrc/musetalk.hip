@@ -63,6 +63,7 @@ struct MtTensor {
     int ld = 0;       // channels of the underlying buffer
     int coff = 0;     // first channel of the view
     int H = 1, W = 1;
+    bool q8 = false;  // e4m3 bytes, [N][C/32][P][32]: C, ld, coff count real channels (multiples of 32), one byte each
     int P() const { return H * W; }
 };
 
@@ -93,7 +94,12 @@ struct MtGraph {
     f16* vt = nullptr;                        // transposed values scratch
     size_t vt_halfs = 0;                      // per frame
     int frames = 0;
+    // fp8 conv path (BASELINE configs[4]): the GroupNorm+SiLU in front of every ResnetBlock2D 3x3 conv writes e4m3
+    // (x * fp8_ascale, saturating) and the conv runs on fp8 operands; everything else stays fp16
+    bool fp8 = false;
+    float fp8_ascale = 8.f;
     double macs = 0;                          // conv / linear MACs per frame (attention excluded)
+    double macs_fp8 = 0;                      // ... of which on fp8 operands
     std::string err;
     MtTensor *t_latent = nullptr, *t_ctx = nullptr, *t_unet_out = nullptr, *t_vae_out = nullptr;
     MtTensor* whisper_states = nullptr;
@@ -103,6 +109,13 @@ struct MtGraph {
         t.buf = (int)buf_halfs.size();
         t.C = up16(C); t.ld = t.C; t.coff = 0; t.H = H; t.W = W;
         buf_halfs.push_back((size_t)t.C * H * W);
+        return t;
+    }
+    MtTensor alloc_q8(int C, int H, int W) {          // C % 32 == 0
+        MtTensor t;
+        t.buf = (int)buf_halfs.size();
+        t.C = C; t.ld = C; t.coff = 0; t.H = H; t.W = W; t.q8 = true;
+        buf_halfs.push_back((size_t)(C / 2) * H * W);
         return t;
     }
     static MtTensor view(const MtTensor& b, int coff, int C) {
@@ -148,11 +161,13 @@ struct MtGraph {
             wuse = wp.data();
         }
         macs += (double)CinR * Cout * kk * (stride == 2 ? y.P() : (ups ? x.P() : y.P()));
+        if (x.q8) macs_fp8 += (double)CinR * Cout * kk * y.P();
         std::vector<float> sc(CoutP, 1.f), sf(CoutP, 0.f);
         if (bias) memcpy(sf.data(), bias, Cout * sizeof(float));
         ConvPlan p;
         std::string e;
-        int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, pad_br, sc.data(), sf.data(), &e, x.P());
+        int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, pad_br, sc.data(), sf.data(), &e, x.P(),
+                                  x.q8 ? 1 : 0, fp8_ascale);
         if (rc) { err = name + ": " + e; return -1; }
         plans.push_back(p);
         MtOp op;
@@ -171,7 +186,7 @@ struct MtGraph {
         op.type = OP_GN; op.name = name; op.x = x; op.y = y; op.eps = eps; op.silu = silu; op.groups = 32;
         op.gamma = add_vec(g, x.C); op.beta = add_vec(b, x.C);
         ops.push_back(op);
-        named[name] = y;
+        if (!y.q8) named[name] = y;
         return 0;
     }
     int add_ln(const std::string& name, SD& sd, const std::string& prefix, const MtTensor& x, const MtTensor& y, float eps) {
@@ -269,7 +284,7 @@ int time_embedding_silu(SD& sd, float t, std::vector<float>* out) {
 int build_resnet(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& out, int Cin, int Cout,
                  const std::vector<float>* temb_silu, float eps) {
     const int H = x.H, W = x.W;
-    MtTensor t1 = g.alloc(Cin, H, W);
+    MtTensor t1 = (g.fp8 && Cin % 32 == 0) ? g.alloc_q8(Cin, H, W) : g.alloc(Cin, H, W);
     if (g.add_gn(p + ".norm1", sd, p + ".norm1", x, t1, eps, 1)) return -1;
     const float* w1 = sd.get(p + ".conv1.weight", (size_t)Cout * Cin * 9);
     const float* b1 = sd.get(p + ".conv1.bias", Cout);
@@ -288,7 +303,7 @@ int build_resnet(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, co
     }
     MtTensor h = g.alloc(Cout, H, W);
     if (g.add_conv(p + ".conv1", w1, bias1.data(), Cin, Cout, 3, 1, 1, t1, h, nullptr, 0, 0)) return -1;
-    MtTensor t2 = g.alloc(Cout, H, W);
+    MtTensor t2 = (g.fp8 && Cout % 32 == 0) ? g.alloc_q8(Cout, H, W) : g.alloc(Cout, H, W);
     if (g.add_gn(p + ".norm2", sd, p + ".norm2", h, t2, eps, 1)) return -1;
     MtTensor skip = x;
     if (sd.has(p + ".conv_shortcut.weight")) {
@@ -715,6 +730,7 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
             case OP_CONV: {
                 ConvIO io;
                 io.x = g.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
+                if (op.x.q8) { io.x_ld /= 2; io.x_coff /= 2; }      // 16-bit units of the fp8 tensor (conv_mfma.h: ConvPlan::q8)
                 io.y = g.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
                 io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
                 io.relu = 0; io.act = op.act; io.ups = op.ups;
@@ -728,8 +744,13 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                 const int P = op.x.P();
                 const int segs = gn_segments(nf, op.x.C, P);
                 launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
-                launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
-                                g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+                if (op.y.q8)
+                    launch_gn_apply_fp8(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                        g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)g.bufs[op.y.buf],
+                                        op.y.ld / 32, op.y.coff / 32, s);
+                else
+                    launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
                 break;
             }
             case OP_LN:
@@ -767,6 +788,9 @@ void mt_graph_delete(MtGraph* g) {
     delete g;
 }
 const char* mt_graph_error(const MtGraph* g) { return g->err.c_str(); }
+
+void mt_set_fp8(MtGraph* g, int on, float act_scale) { g->fp8 = on != 0; if (act_scale > 0.f) g->fp8_ascale = act_scale; }
+double mt_macs_fp8_per_frame(const MtGraph* g) { return g->macs_fp8; }
 
 int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames) {
     g->t_latent = new MtTensor(); g->t_ctx = new MtTensor(); g->t_unet_out = new MtTensor(); g->t_vae_out = new MtTensor();

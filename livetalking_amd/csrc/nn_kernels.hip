@@ -69,10 +69,11 @@ void launch_gn_stats(const f16* x, int N, int cbt, int cb0, int C, int P, int se
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
+template <bool FP8>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int CB, int P, int cpg,
                                                         float eps, const float* __restrict__ partial, int segs,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                                        f16* __restrict__ y, int y_cbt, int y_cb0) {
+                                                        f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale) {
     __shared__ float ab[2][16];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB;
@@ -99,26 +100,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     for (int c = 0; c < 8; ++c) { a8[c] = ab[0][half * 8 + c]; b8[c] = ab[1][half * 8 + c]; }
     const f16* xb = x + ((size_t)(n * x_cbt + x_cb0 + cb) * P) * 16 + half * 8;
     f16* yb = y + ((size_t)(n * y_cbt + y_cb0 + cb) * P) * 16 + half * 8;
+    // fp8: 16-channel block cb is the (cb & 1) half of the 32-byte pixel granule of 32-channel block cb >> 1
+    unsigned char* yq = reinterpret_cast<unsigned char*>(y) + ((size_t)(n * y_cbt + y_cb0 + (cb >> 1)) * P) * 32 + (cb & 1) * 16 + half * 8;
     const int p0 = blockIdx.y * 1024;
     const int p1 = min(P, p0 + 1024);
     for (int p = p0 + (tid >> 1); p < p1; p += 128) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)p * 16);
         f16x8 o;
+        float f[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float t = (float)v[c] * a8[c] + b8[c];
             if (silu) t = silu_f(t);
             o[c] = (f16)t;
+            f[c] = fminf(fmaxf(t * out_scale, -448.f), 448.f);
         }
-        *reinterpret_cast<f16x8*>(yb + (size_t)p * 16) = o;
+        if (FP8) {
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<int2*>(yq + (size_t)p * 32) = make_int2(w0, w1);
+        } else {
+            *reinterpret_cast<f16x8*>(yb + (size_t)p * 16) = o;
+        }
     }
 }
 
 void launch_gn_apply(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
                      int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
     const int CB = C / 16;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
-                       partial, segs, gamma, beta, silu, y, y_cbt, y_cb0);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
+                       partial, segs, gamma, beta, silu, y, y_cbt, y_cb0, 1.f);
+}
+
+void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
+                         int segs, const float* gamma, const float* beta, int silu, float out_scale, unsigned char* y, int y_cbt,
+                         int y_cb0, hipStream_t s) {
+    const int CB = C / 16;
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
+                       partial, segs, gamma, beta, silu, reinterpret_cast<f16*>(y), y_cbt, y_cb0, out_scale);
 }
 
 // =============================================================================================== LayerNorm

@@ -79,9 +79,13 @@ class Engine:
         self.max_frames = int(max_frames)
         del keep
 
-    def load_musetalk(self, unet_sd: Dict[str, object], vae_sd: Dict[str, object], max_frames: int = 16):
+    def load_musetalk(self, unet_sd: Dict[str, object], vae_sd: Dict[str, object], max_frames: int = 16, fp8: bool = False,
+                      fp8_act_scale: float = 0.0):
         """musetalk_avatar.py:57-67: diffusers-named state dicts of the U-Net (models/musetalkV15/unet.pth) and of
-        the sd-vae AutoencoderKL (post_quant_conv.*, decoder.*)."""
+        the sd-vae AutoencoderKL (post_quant_conv.*, decoder.*).  fp8: ResnetBlock2D 3x3 convs on e4m3 operands
+        (BASELINE configs[4])."""
+        if fp8:
+            _lib.check(self._lib.ltk_musetalk_set_fp8(self._h, 1, float(fp8_act_scale)))
         ua, un, k1 = self._named_tensors(unet_sd)
         va, vn, k2 = self._named_tensors(vae_sd)
         _lib.check(self._lib.ltk_musetalk_load(self._h, ua, un, va, vn, int(max_frames)))
@@ -215,6 +219,11 @@ class Engine:
         _lib.check(self._lib.ltk_musetalk_debug_get(self._h, name.encode(), int(shape[0]), out.ctypes.data, out.size))
         return out
 
+    def musetalk_info(self):
+        macs, macs8 = C.c_double(), C.c_double()
+        _lib.check(self._lib.ltk_musetalk_info(self._h, C.byref(macs), C.byref(macs8)))
+        return macs.value, macs8.value
+
     def musetalk_time(self, frames: int, iters: int):
         ms = C.c_float()
         macs = C.c_double()
@@ -279,6 +288,19 @@ class Engine:
         macs = C.c_double()
         _lib.check(self._lib.ltk_wav2lip_time_convs(self._h, int(frames), int(iters), C.byref(ms), C.byref(macs)))
         return ms.value, macs.value
+
+    def conv2d_fp8(self, d_x_ptr: int, N, H, W, Cin, weight: np.ndarray, Cout, scale=None, shift=None, act_scale: float = 8.0,
+                   d_res_ptr: int = 0, act: int = 0, d_y_ptr: int = 0, iters: int = 0) -> float:
+        """3x3 s1 p1 conv on e4m3 operands (include/ltk.h: ltk_conv2d_fp8); x is [N][Cin/32][H][W][32] bytes."""
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        sc = np.ascontiguousarray(scale, dtype=np.float32) if scale is not None else None
+        sf = np.ascontiguousarray(shift, dtype=np.float32) if shift is not None else None
+        ms = C.c_float(0)
+        _lib.check(self._lib.ltk_conv2d_fp8(
+            self._h, C.c_void_p(d_x_ptr), N, H, W, Cin, w.ctypes.data, Cout, sc.ctypes.data if sc is not None else None,
+            sf.ctypes.data if sf is not None else None, float(act_scale), C.c_void_p(d_res_ptr) if d_res_ptr else None, int(act),
+            C.c_void_p(d_y_ptr), iters, C.byref(ms)))
+        return ms.value
 
     def conv2d_f16(self, d_x_ptr: int, N, H, W, Cin, weight: np.ndarray, Cout, k, stride, pad, transposed=False,
                    out_pad=0, scale: Optional[np.ndarray] = None, shift: Optional[np.ndarray] = None,

@@ -34,3 +34,14 @@ def empty_cb16(n, channels, h, w, device="cuda", fill=None):
     if fill is None:
         return torch.empty(n, cb, h, w, 16, dtype=torch.float16, device=device)
     return torch.full((n, cb, h, w, 16), fill, dtype=torch.float16, device=device)
+
+
+def to_cb32_fp8(x_nchw, scale: float = 1.0):
+    """NCHW float -> e4m3 bytes [N][C/32][H][W][32] of saturate(x * scale) (C % 32 == 0): the operand layout of the fp8
+    conv path.  Returns (uint8 tensor, the dequantised NCHW float32 tensor = what the kernel multiplies, / scale)."""
+    import torch
+    n, c, h, w = x_nchw.shape
+    assert c % 32 == 0
+    q = (x_nchw.float() * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    packed = q.view(torch.uint8).view(n, c // 32, 32, h, w).permute(0, 1, 3, 4, 2).contiguous()
+    return packed, q.float() / scale

@@ -71,6 +71,34 @@ def _conv(sd: SD, p: str, x: Tensor, stride=1, pad=1) -> Tensor:
     return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=stride, padding=pad)
 
 
+# fp8 conv path (BASELINE.json configs[4]; include/ltk.h ltk_musetalk_set_fp8): emulation of what the engine does when it
+# is enabled -- the SiLU(GroupNorm(x)) in front of every ResnetBlock2D 3x3 conv is multiplied by `ascale`, saturated to
+# +-448 and rounded to OCP e4m3 (round to nearest even); the conv weights are rounded to e4m3 after a per-output-channel
+# scale 224 / max|w|; products and sums are fp32.  Off by default: the reference has no fp8 mode, this is OUR statement
+# of the quantised path, used to check the kernels, and its distance to the unquantised oracle is what the fp8 test reports.
+FP8 = {"on": False, "ascale": 8.0}
+
+
+def fp8_round(x: Tensor) -> Tensor:
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def fp8_weight(w: Tensor):
+    """-> (dequantised weight, per-output-channel scale)"""
+    m = w.abs().amax(dim=(1, 2, 3))
+    sw = torch.where(m > 0, 224.0 / m, torch.ones_like(m))
+    return fp8_round(w * sw[:, None, None, None]) / sw[:, None, None, None], sw
+
+
+def _conv3_q(sd: SD, p: str, x: Tensor) -> Tensor:
+    """3x3 s1 p1 conv of a GroupNorm+SiLU output: fp8 operands when FP8 is on and the channel count allows it."""
+    if not FP8["on"] or x.shape[1] % 32 != 0:
+        return _conv(sd, p, x)
+    a = float(FP8["ascale"])
+    wq, _ = fp8_weight(sd[p + ".weight"])
+    return F.conv2d(fp8_round(x * a) / a, wq, sd[p + ".bias"], padding=1)
+
+
 def _linear(sd: SD, p: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
@@ -109,12 +137,12 @@ def _tap(taps, name, t):
 def resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float, taps=None) -> Tensor:
     """diffusers ResnetBlock2D (output_scale_factor 1, no up/down)."""
     h = _tap(taps, p + ".norm1", F.silu(_gn(sd, p + ".norm1", x, groups, eps)))
-    h = _conv(sd, p + ".conv1", h)
+    h = _conv3_q(sd, p + ".conv1", h)
     if temb is not None:
         h = h + _linear(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
     _tap(taps, p + ".conv1", h)
     h = _tap(taps, p + ".norm2", F.silu(_gn(sd, p + ".norm2", h, groups, eps)))
-    h = _conv(sd, p + ".conv2", h)
+    h = _conv3_q(sd, p + ".conv2", h)
     if (p + ".conv_shortcut.weight") in sd:
         x = _tap(taps, p + ".conv_shortcut", _conv(sd, p + ".conv_shortcut", x, pad=0))
     return _tap(taps, p + ".conv2", x + h)

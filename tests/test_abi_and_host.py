@@ -144,3 +144,24 @@ def test_plugin_module_contract_against_reference_app():
     assert list(inspect.signature(mine.LipReal.__init__).parameters)[1:4] == ["opt", "model", "avatar"]
     assert list(inspect.signature(mine.LipReal.inference_batch).parameters)[1:] == ["index", "audiofeat_batch"]
     assert list(inspect.signature(mine.LipReal.paste_back_frame).parameters)[1:] == ["pred_frame", "idx"]
+
+
+def test_host_e4m3_conversion_matches_torch():
+    """The weight packer's fp32 -> OCP e4m3fn conversion (csrc/conv_mfma.hip f32_to_e4m3) against torch.float8_e4m3fn:
+    round to nearest even, subnormals, saturation at +-448."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    from livetalking_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-3, 0.02, 1, 30, 300)] +
+                          [np.array([0, 448, -448, 500, -1e9, 1e-9, 2 ** -10, 2 ** -9, 1.5 * 2 ** -9, 2.5 * 2 ** -9, 0.0155, 0.015625,
+                                     464, 447.9, 240, 232, 0.0146484375], np.float32)])
+    out = np.empty(vals.size, np.uint8)
+    assert lib.ltk_f32_to_e4m3(vals.ctypes.data, vals.size, out.ctypes.data) == 0
+    ref = torch.from_numpy(vals).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    diff = np.nonzero(out != ref)[0]
+    diff = [i for i in diff if (out[i] & 0x7F) or (ref[i] & 0x7F)]          # +0 vs -0 is not a difference
+    assert not diff, [(float(vals[i]), int(out[i]), int(ref[i])) for i in diff[:8]]

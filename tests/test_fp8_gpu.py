@@ -1,0 +1,124 @@
+"""fp8 conv path (BASELINE.json configs[4]; ltk_musetalk_set_fp8, conv3 Q=1 kernels, gn_apply fp8 writer).
+
+1. the fp8-operand conv kernel vs torch fp32 on the SAME quantised operands (the kernel's arithmetic is exact products
+   + fp32 sums): 3e-3 relative + 3e-3 absolute per element, relative L2 <= 2e-3 (measured 2e-4);
+2. the whole MuseTalk generator with the fp8 resnet convs vs the oracle's emulation of the same quantisation points
+   (oracle/musetalk_oracle.py FP8): relative L2 <= 3e-2 on the U-Net output and the decoded image (rounding decisions on
+   fp16-vs-fp32 GroupNorm outputs differ for ~1 % of the values), frames PSNR >= 38 dB;
+3. the quantisation cost itself, fp8 engine vs the UNQUANTISED fp32 oracle: reported, and frames PSNR >= 30 dB asserted.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+from livetalking_amd import synth  # noqa: E402
+from livetalking_amd.layout import empty_cb16, from_cb16, to_cb16, to_cb32_fp8  # noqa: E402
+from oracle import musetalk_oracle as M  # noqa: E402
+
+# (N, H, W, Cin, Cout, residual, act)
+CASES = [
+    (2, 64, 64, 512, 512, True, 0),        # VAE 512 @ 64^2
+    (1, 256, 256, 128, 128, True, 0),      # VAE 128 @ 256^2 (PXW 4 tiles)
+    (2, 128, 128, 256, 128, False, 3),
+    (2, 32, 32, 320, 320, False, 0),       # U-Net level 0
+    (3, 16, 16, 1280, 640, True, 0),       # split-K
+    (2, 8, 8, 2560, 1280, False, 0),
+    (1, 37, 21, 64, 96, False, 1),         # ragged tiles
+    (5, 4, 4, 1280, 1280, True, 0),
+]
+
+
+def psnr_u8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fp8_kernel(engine, case):
+    N, H, W, Cin, Cout, residual, act = case
+    g = torch.Generator(device="cpu").manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x[:, :, 0, 0] = 100.0                                   # saturates at 448 / 8 = 56
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    w[1] *= 37.0                                            # per-output-channel scales must differ
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    a_scale = 8.0
+    xq_bytes, xq = to_cb32_fp8(x.cuda(), a_scale)
+    wq, _ = M.fp8_weight(w)
+    ref = F.conv2d(xq, wq.cuda(), None, padding=1) * scale.cuda()[None, :, None, None] + shift.cuda()[None, :, None, None]
+    res_ptr = 0
+    if residual:
+        r = torch.randn(N, Cout, H, W, generator=g).half()
+        r_dev = to_cb16(r.cuda())
+        ref = ref + r.cuda().float()
+        res_ptr = r_dev.data_ptr()
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 3:
+        ref = F.silu(ref)
+    y = empty_cb16(N, Cout, H, W, fill=float("nan"))
+    ms = engine.conv2d_fp8(xq_bytes.data_ptr(), N, H, W, Cin, w.numpy(), Cout, scale.numpy(), shift.numpy(), a_scale, res_ptr, act,
+                           y.data_ptr(), iters=3)
+    got = from_cb16(y, Cout)
+    err = (got - ref).abs()
+    tol = 3e-3 * ref.abs() + 3e-3          # fp16 output rounding + fp32 summation order over K up to 23 040
+    bad = int((err > tol).sum())
+    rel = float((got - ref).norm() / ref.norm())
+    # same geometry in fp16 for the timing line
+    y16 = empty_cb16(N, Cout, H, W)
+    ms16 = engine.conv2d_f16(to_cb16(x.cuda()).data_ptr(), N, H, W, Cin, w.numpy(), Cout, 3, 1, 1, False, 0, scale.numpy(), shift.numpy(),
+                             0, False, y16.data_ptr(), iters=3)
+    print(f"[fp8conv] {case} rel_l2={rel:.2e} bad={bad} fp8 {ms*1e3:.1f} us  fp16 {ms16*1e3:.1f} us")
+    assert torch.isfinite(got).all()
+    assert bad == 0 and rel <= 2e-3, (case, rel, bad, float(err.max()))
+
+
+@pytest.mark.gpu
+def test_musetalk_fp8_vs_emulation_and_fp32():
+    from livetalking_amd.engine import Engine
+    B = 2
+    unet_sd = synth.musetalk_unet_state_dict()
+    vae_sd = synth.vae_decoder_state_dict()
+    eng = Engine(0)
+    try:
+        eng.load_musetalk(unet_sd, vae_sd, max_frames=B, fp8=True)
+        macs, macs8 = eng.musetalk_info()
+        print(f"[fp8] {macs8 / macs:.3f} of the conv/linear MACs on fp8 operands ({macs8 / 1e9:.1f} of {macs / 1e9:.1f} GMAC/frame)")
+        assert macs8 / macs > 0.5
+        usd = {k: torch.from_numpy(v) for k, v in unet_sd.items()}
+        vsd = {k: torch.from_numpy(v) for k, v in vae_sd.items()}
+        lat = np.concatenate(synth.musetalk_latents(B))
+        feat = synth.musetalk_whisper_feats(B)
+        got_lat, got_img, got_frames = eng.musetalk_forward_host(lat, feat)
+        with torch.no_grad():
+            pe = M.positional_encoding(torch.from_numpy(feat))
+            ref32_lat = M.unet_forward(usd, torch.from_numpy(lat), pe)
+            ref32_frames = M.decode_latents(vsd, ref32_lat)
+            M.FP8["on"] = True
+            try:
+                ref8_lat = M.unet_forward(usd, torch.from_numpy(lat), pe)
+                ref8_img = M.vae_decode(vsd, ref8_lat / M.VAE_SCALING)
+                ref8_frames = M.decode_latents(vsd, ref8_lat)
+                # the decoder alone on the engine's own latents separates U-Net and VAE differences
+            finally:
+                M.FP8["on"] = False
+
+        def rel(a, b):
+            return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-9))
+
+        r_lat, r_img = rel(got_lat, ref8_lat.numpy()), rel(got_img, ref8_img.numpy())
+        p_emul = psnr_u8(got_frames, np.asarray(ref8_frames))
+        p_fp32 = psnr_u8(got_frames, np.asarray(ref32_frames))
+        p_or = psnr_u8(np.asarray(ref8_frames), np.asarray(ref32_frames))
+        q_lat = rel(got_lat, ref32_lat.numpy())
+        print(f"[fp8] engine vs fp8 emulation: latents rel_l2={r_lat:.3e} image rel_l2={r_img:.3e} frames {p_emul:.1f} dB")
+        print(f"[fp8] engine vs fp32 oracle  : latents rel_l2={q_lat:.3e} frames {p_fp32:.1f} dB (emulation vs fp32 oracle: {p_or:.1f} dB)")
+        assert r_lat <= 3e-2 and r_img <= 3e-2 and p_emul >= 38.0
+        assert p_fp32 >= 30.0
+    finally:
+        eng.close()
