@@ -137,13 +137,21 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // ---- A staging descriptors: item (k, wave) = 64 consecutive 16-byte slots (32 patch pixels) of one channel block
     const int p64n = a.SLOTS >> 6;
     const int HW16 = (a.H >> a.ups) * (a.W >> a.ups) * 16;          // halfs per (source) channel block plane
-    int a_goff[MAXA];                         // element offset of this lane's 8 channels (chunk 0), -1 = no copy
+    // 32-bit BYTE offsets against a wave-uniform 64-bit base: the DMA then takes the SGPR-base + VGPR-offset form
+    // (one VGPR per descriptor, no 64-bit VALU add per copy).  Tensors are < 2^31 elements (checked by the host).
+    unsigned a_goff[MAXA];                    // byte offset of this lane's 8 channels (chunk 0), ~0u = no copy
     int a_ldst[MAXA];                         // wave-uniform LDS byte offset inside a stage
+    // The slot -> (image, row, column) decomposition below does not depend on the item.  In the persistent loop hipcc
+    // hoists it out of the item loop, keeps ~2 VGPRs per descriptor alive across the whole kernel, runs out of
+    // registers and reloads the spills from scratch at every item start -- with an s_waitcnt vmcnt(0) in front of
+    // every DMA of the first chunk.  An opaque copy of the lane id makes it per-item work (~100 VALU ops).
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i));
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
         const int s64 = k * 4 + wave;                       // wave-uniform
         const int cbj = s64 / p64n;
-        const int slot = (s64 - cbj * p64n) * 64 + lane;
+        const int slot = (s64 - cbj * p64n) * 64 + lane_i;
         const int pix = slot >> 1;
         const int half = (slot & 1) ^ ((pix >> 3) & 1);
         const int b = (PHW == 1) ? pix : (int)__umulhi((unsigned)pix, a.magicPHW);
@@ -153,35 +161,37 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
-        a_goff[k] = ok ? ((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) : -1;
+        a_goff[k] = ok ? (unsigned)((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) * 2u : ~0u;
         a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
     }
 
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
     constexpr int slab32 = T * NC8 * 32;
     const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w) + (size_t)(ntile * NBT) * a.nchunks * slab32;
-    int b_goff[MAXB];                         // uint4 offset at chunk 0, -1 = no copy
-#pragma unroll
-    for (int k = 0; k < MAXB; ++k) {
-        const int i = tid + k * 256;
-        const int sub = (NBT > 1 && i >= slab32) ? 1 : 0;
-        b_goff[k] = (i < NBT * slab32) ? (sub * a.nchunks * slab32 + (i - sub * slab32)) : -1;
-    }
+    // item tid + k*256 of the block's NBT sub-slabs; the second sub-slab starts nchunks*slab32 items after the first
+    const unsigned b_sub1 = (unsigned)(a.nchunks - 1) * slab32 * 16u;      // extra byte offset of sub-slab 1 items
 
     auto stage = [&](int c, int buf) {
         unsigned char* const Ab = smem + buf * STAGE;
         unsigned char* const Bb = Ab + A_BYTES;
-        const f16* xc = a.x + (size_t)c * NCB * HW16;
+        const unsigned char* xc = reinterpret_cast<const unsigned char*>(a.x + (size_t)c * NCB * HW16);
         if (!(a.ablate & 1)) {
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
-                if (a_goff[k] >= 0) GLDS16(xc + a_goff[k], Ab + a_ldst[k]);
+                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + a_ldst[k]);
         }
-        const uint4* wc = wsrc + (size_t)c * slab32;
+        const unsigned char* wc = reinterpret_cast<const unsigned char*>(wsrc + (size_t)c * slab32);
         if (!(a.ablate & 2)) {
+            unsigned tq = (unsigned)tid;           // opaque: otherwise the per-thread offsets are hoisted as 64-bit
+            asm volatile("" : "+v"(tq));           // kernel-lifetime values and spilled (see lane_i above)
 #pragma unroll
-            for (int k = 0; k < MAXB; ++k)
-                if (b_goff[k] >= 0) GLDS16(wc + b_goff[k], Bb + (k * 256 + wave * 64) * 16);
+            for (int k = 0; k < MAXB; ++k) {
+                const unsigned i = tq + k * 256u;
+                if (i < (unsigned)(NBT * slab32)) {
+                    const unsigned off = i * 16u + ((NBT > 1 && i >= (unsigned)slab32) ? b_sub1 : 0u);
+                    GLDS16(wc + off, Bb + (k * 256 + wave * 64) * 16);
+                }
+            }
         }
     };
 
@@ -338,8 +348,10 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     const int cout0 = ntile * BN;
     const int HWo = a.HoA * a.WoA;
     // output pixel of this lane in subtile j / phase g: image n and pixel index inside the output plane
+    int l31_e = l31;                       // same reason as lane_i: keep the epilogue's per-lane pixel arithmetic in the epilogue
+    asm volatile("" : "+v"(l31_e));
     auto out_px = [&](int j, int g, int* n_out, bool* ok) -> int {
-        const int m = (wave * PXW + j) * 32 + l31;
+        const int m = (wave * PXW + j) * 32 + l31_e;
         const int tx = m & TWm;
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
