@@ -140,7 +140,8 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // 32-bit BYTE offsets against a wave-uniform 64-bit base: the DMA then takes the SGPR-base + VGPR-offset form
     // (one VGPR per descriptor, no 64-bit VALU add per copy).  Tensors are < 2^31 elements (checked by the host).
     unsigned a_goff[MAXA];                    // byte offset of this lane's 8 channels (chunk 0), ~0u = no copy
-    int a_ldst[MAXA];                         // wave-uniform LDS byte offset inside a stage
+    // LDS destination of copy (k, wave) inside a stage: the NCB channel-block images are contiguous and SLOTS is a multiple
+    // of 64, so it is simply (k*4 + wave) KiB -- no table
     // The slot -> (image, row, column) decomposition below does not depend on the item.  In the persistent loop hipcc
     // hoists it out of the item loop, keeps ~2 VGPRs per descriptor alive across the whole kernel, runs out of
     // registers and reloads the spills from scratch at every item start -- with an s_waitcnt vmcnt(0) in front of
@@ -153,16 +154,15 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int cbj = s64 / p64n;
         const int slot = (s64 - cbj * p64n) * 64 + lane_i;
         const int pix = slot >> 1;
-        const int half = (slot & 1) ^ ((pix >> 3) & 1);
         const int b = (PHW == 1) ? pix : (int)__umulhi((unsigned)pix, a.magicPHW);
         const int rem = pix - b * PHW;
         const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
         const int px = rem - py * a.PW;
+        const int half = (slot & 1) ^ ((px >> 3) & 1);      // the two 16-B halves swap where bit 3 of the patch COLUMN is set
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
         a_goff[k] = ok ? (unsigned)((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) * 2u : ~0u;
-        a_ldst[k] = __builtin_amdgcn_readfirstlane((cbj * a.SLOTS + (s64 - cbj * p64n) * 64) * 16);
     }
 
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
@@ -178,7 +178,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         if (!(a.ablate & 1)) {
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
-                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + a_ldst[k]);
+                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024);
         }
         const unsigned char* wc = reinterpret_cast<const unsigned char*>(wsrc + (size_t)c * slab32);
         if (!(a.ablate & 2)) {
@@ -196,14 +196,24 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     };
 
     // ---- per-lane operand bases: this lane's pixel in each of the wave's PXW 32-pixel subtiles
-    int pixb[PXW];
+    // Byte address (inside a channel-block image) of this lane's 16-B operand for subtile j and column offset dx; the row
+    // offset dy * PW * 32 is wave-uniform.  The half swap follows the patch column only, so a tap costs ONE v_add per
+    // fragment (uniform stage/row offset + aj[j][dx]); with the swap on the pixel index every tap re-derived it: 6 VALU per
+    // fragment, 218 of the 385 non-MFMA instructions of a 72-MFMA chunk, which made the loop issue-bound.
+    constexpr int DXN = (T == 9 && G == 1) ? 3 : (G == 4 ? 2 : 1);
+    int aj[PXW][DXN];
 #pragma unroll
     for (int j = 0; j < PXW; ++j) {
         const int m = (wave * PXW + j) * 32 + l31;
         const int tx = m & TWm;
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
-        pixb[j] = (b < a.NB) ? ((b * a.PH + ty * S) * a.PW + tx * S) : 0;     // patch pixel slot
+        const bool in = b < a.NB;
+        const int prow = in ? (b * a.PH + ty * S) * a.PW : 0;
+        const int pcol = in ? tx * S : 0;
+#pragma unroll
+        for (int dx = 0; dx < DXN; ++dx)
+            aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ hh) << 4);
     }
 
     f32x16 acc[G][NBT][PXW];
@@ -217,15 +227,16 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 for (int r = 0; r < 16; ++r) acc[g][i][j][r] = 0.f;
 
     const int PS = a.SLOTS * 16;
-    // byte address of lane's operand (pixel slot p, k-half hh) inside a channel-block image
-    auto aoff = [&](int p) -> int { return p * 32 + ((((p >> 3) & 1) ^ hh) << 4); };
+    const int rowB = a.PW * 32;            // bytes per patch row of a channel-block image
     auto compute = [&](int buf) {
         const unsigned char* Ab = smem + buf * STAGE;
         const unsigned char* Bb = Ab + A_BYTES;
         // keep hipcc from hoisting the 9 x PXW swizzled operand addresses out of the chunk loop: they would
         // pin ~70 VGPRs and leave no room for the double-buffered fragments
 #pragma unroll
-        for (int j = 0; j < PXW; ++j) asm volatile("" : "+v"(pixb[j]));
+        for (int j = 0; j < PXW; ++j)
+#pragma unroll
+            for (int dx = 0; dx < DXN; ++dx) asm volatile("" : "+v"(aj[j][dx]));
 #pragma unroll
         for (int q = 0; q < NCB; ++q) {
             const int plane = 2 * q + hh;
@@ -236,12 +247,12 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 // lgkmcnt(0): one exposed LDS round trip per four MFMAs)
                 f16x8 xa[2][PXW], wf[2][NBT];
                 auto load_tap = [&](int t, int sl) {
-                    const int toff = (T == 9) ? ((t / 3) * a.PW + (t % 3)) : 0;
+                    const unsigned char* Ar = Ap + ((T == 9) ? (t / 3) * rowB : 0);      // wave-uniform
 #pragma unroll
                     for (int i = 0; i < NBT; ++i)
                         wf[sl][i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
 #pragma unroll
-                    for (int j = 0; j < PXW; ++j) xa[sl][j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + toff));
+                    for (int j = 0; j < PXW; ++j) xa[sl][j] = *reinterpret_cast<const f16x8*>(Ar + aj[j][(T == 9) ? t % 3 : 0]);
                 };
                 load_tap(0, 0);
                 if (T > 1) __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);       // reads of tap 0
@@ -274,7 +285,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 f16x8 xa[PXW];
                 // offset (0,0): taps 0..3 -> phases 0..3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j]));
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aj[j][0]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const f16x8 wf = wfrag(t);
@@ -284,7 +295,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
                 // offset (0,1): taps 4,5 -> phases 1,3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + 1));
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aj[j][G == 4 ? 1 : 0]);
                 {
                     const f16x8 w4 = wfrag(4), w5 = wfrag(5);
 #pragma unroll
@@ -295,7 +306,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
                 // offset (1,0): taps 6,7 -> phases 2,3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + a.PW));
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + aj[j][0]);
                 {
                     const f16x8 w6 = wfrag(6), w7 = wfrag(7);
 #pragma unroll
@@ -306,7 +317,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
                 // offset (1,1): tap 8 -> phase 3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + aoff(pixb[j] + a.PW + 1));
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + aj[j][G == 4 ? 1 : 0]);
                 {
                     const f16x8 w8 = wfrag(8);
 #pragma unroll
