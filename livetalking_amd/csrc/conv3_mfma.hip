@@ -69,9 +69,10 @@ struct K3Args {
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
 };
 
-__host__ __device__ constexpr int k3_maxa(int PXW, int NC8, int S = 1) {
-    // 16-byte A items per thread per chunk: (NC8/2) * SLOTS / 256; a stride-2 patch is ~4x the tile
-    return S == 2 ? (NC8 == 2 ? 10 : 20) : PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
+__host__ __device__ constexpr int k3_maxa(int PXW, int NC8, int S = 1, int T = 9) {
+    // 16-byte A items per thread per chunk: (NC8/2) * SLOTS / 256; a stride-2 patch is ~4x the tile; a 1x1 conv has no halo
+    return T == 1 ? (NC8 / 2) * PXW
+                  : S == 2 ? (NC8 == 2 ? 10 : 20) : PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
 }
 __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT * T * NC8 * 32 + 255) / 256; }
 
@@ -93,9 +94,10 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 template <int G, int NBT, int PXW, int NC8, int T, int S, int Q>
 __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem) {
     constexpr int BN = NBT * 32;
-    constexpr int MAXA = k3_maxa(PXW, NC8, S);
+    constexpr int MAXA = k3_maxa(PXW, NC8, S, T);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
     static_assert(G == 1 || (G == 4 && T == 9 && NBT == 1), "merged convT: 9 taps, 32 couts per block");
+    static_assert(NBT <= 2 || T == 1, "128-cout blocks: 1x1 convolutions only (accumulator budget)");
     static_assert(Q == 0 || G == 1, "fp8 operands: plain convolutions only");
     constexpr int MPP = Q ? 2 : 1;         // MFMAs per (cout subtile, pixel subtile) pair and k16 plane pair
 
@@ -188,7 +190,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             for (int k = 0; k < MAXB; ++k) {
                 const unsigned i = tq + k * 256u;
                 if (i < (unsigned)(NBT * slab32)) {
-                    const unsigned off = i * 16u + ((NBT > 1 && i >= (unsigned)slab32) ? b_sub1 : 0u);
+                    const unsigned off = i * 16u + (NBT > 1 ? (i / (unsigned)slab32) * b_sub1 : 0u);   // sub-slab s starts s*nchunks*slab32 items in
                     GLDS16(wc + off, Bb + (k * 256 + wave * 64) * 16);
                 }
             }
@@ -550,6 +552,7 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
     K3CASE(1, 2, 4, 2, 9); K3CASE(1, 2, 2, 2, 9); K3CASE(1, 1, 4, 2, 9); K3CASE(1, 1, 2, 2, 9);
     K3CASE(1, 2, 2, 4, 9); K3CASE(1, 1, 2, 4, 9);
     K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
+    K3CASE(1, 4, 2, 4, 1); K3CASE(1, 2, 2, 4, 1); K3CASE(1, 1, 2, 4, 1);
     K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
 #undef K3CASE
     return nullptr;
@@ -652,14 +655,14 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         NB = std::max(1, std::min(NB, io.N));
         PH = ((1 << l2h) - 1) * S + 1 + ext; PW = ((1 << l2w) - 1) * S + 1 + ext;
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
-        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S) * 256) --NB;
+        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S, T) * 256) --NB;
         npix = NB * PH * PW;
         SLOTS = (2 * npix + 63) / 64 * 64;
         const int tiles_x = (a.Wo + (1 << l2w) - 1) >> l2w, tiles_y = (a.Ho + (1 << l2h) - 1) >> l2h;
         const int tiles_n = (io.N + NB - 1) / NB;
         blocks = (long long)tiles_x * tiles_y * tiles_n;
         a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
-        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S) * 256 && npix < 32768;
+        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S, T) * 256 && npix < 32768;
     };
     bool fit = geom(PXW);
     if (PXW == 4) {
@@ -667,6 +670,8 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         if (!fit || blocks * nt < 448) { PXW = 2; fit = geom(PXW); }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
+    // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
+    if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && !(ev_nbt && atoi(ev_nbt) != 4)) NBT = 4;
     if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128) NBT = 1;
     const int BN = NBT * 32;
     a.n_ntiles = (p.lCout + BN - 1) / BN;

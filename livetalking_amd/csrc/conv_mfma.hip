@@ -564,7 +564,9 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
         }
     }
     if (p->v3) {
-        if (p->v3_T == 1) NC8 = (Cin % 64 == 0) ? 8 : 2;
+        // 1x1: 64-channel chunks; wide outputs take 32-channel chunks so that a 128-cout block (conv3_launch) still fits two
+        // resident blocks per CU
+        if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && env_int("LTK_GEMM_NC8", 4) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
         else NC8 = (Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4;
         if (p->v3_S == 2) NC8 = 2;

@@ -6,7 +6,10 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 timeout 600 python bench.py --steps 50 --warmup 5 > $O/bench_s1.json 2> $O/bench_s1.err; cat $O/bench_s1.json
 timeout 300 python bench.py --steps 10 --warmup 3 --sessions 16 --no-cpu-baseline > $O/bench_s16.json 2> $O/bench_s16.err; cat $O/bench_s16.json
+timeout 300 python bench.py --model musetalk --steps 6 --warmup 2 > $O/bench_mt.json 2> $O/bench_mt.err; cat $O/bench_mt.json
+timeout 300 python bench.py --model musetalk --fp8 --steps 6 --warmup 2 > $O/bench_mt_fp8.json 2> $O/bench_mt_fp8.err; cat $O/bench_mt_fp8.json
 cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/mt_trace -o r -- python $R/bench.py --model musetalk --steps 2 --warmup 1 > $O/mt_trace.log 2>&1
 BCMD="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- $BCMD > $O/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- $BCMD > $O/pmc_fetch.log 2>&1
