@@ -248,6 +248,12 @@ def main():
                          "kernel": "conv3_kernel + conv_mfma_kernel (the 54 conv/convT layers = one pass)",
                          "conv_stack_ms": round(conv_ms, 4), "flops_per_frame": 2 * (MACS_PER_FRAME - HEAD_MACS)},
         }
+        # BASELINE.json's second figure: sessions a GPU sustains at 25 fps each.  A step of S coalesced sessions must finish
+        # within the 0.64 s its 16 frames last (base_avatar.py:364-373 accounting), so the bound is throughput / 25 as long
+        # as the step latency stays below that.
+        step_ms = elapsed / args.steps * 1e3
+        out["sessions_25fps"] = {"per_gpu": int(value / world // 25), "step_latency_ms": round(step_ms, 3),
+                                 "latency_budget_ms": 1000.0 * B / 25, "note": "unpaced saturating rate / 25 fps"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

@@ -342,10 +342,36 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
     const std::vector<float> wkp = pad_heads_rows(wk, C, Cctx, heads, d, d16, 1.f), bkp = pad_heads_vec(bk, heads, d, d16, 1.f);
     const std::vector<float> wvp = pad_heads_rows(wv, C, Cctx, heads, d, d16, 1.f), bvp = pad_heads_vec(bv, heads, d, d16, 1.f);
     const std::vector<float> wop = pad_heads_cols(wo, C, heads, d, d16);
-    MtTensor q = g.alloc(Cp, x.H, x.W), k = g.alloc(Cp, ctx.H, ctx.W), v = g.alloc(Cp, ctx.H, ctx.W), o = g.alloc(Cp, x.H, x.W);
-    if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
-    if (g.add_conv(p + ".to_k", wkp.data(), bkp.data(), Cctx, Cp, 1, 1, 0, ctx, k, nullptr, 0, 0)) return -1;
-    if (g.add_conv(p + ".to_v", wvp.data(), bvp.data(), Cctx, Cp, 1, 1, 0, ctx, v, nullptr, 0, 0)) return -1;
+    // Projections that read the same tensor are ONE launch (rows of the weight matrices stacked, outputs = channel-block
+    // ranges of one buffer): q|k|v for self-attention, k|v for cross-attention.  These are 1-3 GFLOP GEMMs whose cost is
+    // the launch, not the math.
+    auto stack = [](std::initializer_list<const std::vector<float>*> parts) {
+        std::vector<float> o;
+        for (const std::vector<float>* v : parts) o.insert(o.end(), v->begin(), v->end());
+        return o;
+    };
+    const bool fuse = !getenv("LTK_MT_NO_QKV_FUSE");      // A/B switch
+    const bool self = fuse && x.buf == ctx.buf && x.coff == ctx.coff && x.C == ctx.C;
+    MtTensor q, k, v, o = g.alloc(Cp, x.H, x.W);
+    if (self) {
+        MtTensor qkv = g.alloc(3 * Cp, x.H, x.W);
+        const std::vector<float> w3 = stack({&wqp, &wkp, &wvp}), b3 = stack({&bqp, &bkp, &bvp});
+        if (g.add_conv(p + ".to_qkv", w3.data(), b3.data(), C, 3 * Cp, 1, 1, 0, x, qkv, nullptr, 0, 0)) return -1;
+        q = MtGraph::view(qkv, 0, Cp); k = MtGraph::view(qkv, Cp, Cp); v = MtGraph::view(qkv, 2 * Cp, Cp);
+    } else if (!fuse) {
+        q = g.alloc(Cp, x.H, x.W); k = g.alloc(Cp, ctx.H, ctx.W); v = g.alloc(Cp, ctx.H, ctx.W);
+        if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
+        if (g.add_conv(p + ".to_k", wkp.data(), bkp.data(), Cctx, Cp, 1, 1, 0, ctx, k, nullptr, 0, 0)) return -1;
+        if (g.add_conv(p + ".to_v", wvp.data(), bvp.data(), Cctx, Cp, 1, 1, 0, ctx, v, nullptr, 0, 0)) return -1;
+    } else {
+        q = g.alloc(Cp, x.H, x.W);
+        MtTensor kv = g.alloc(2 * Cp, ctx.H, ctx.W);
+        const std::vector<float> w2 = stack({&wkp, &wvp}), b2 = stack({&bkp, &bvp});
+        if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
+        if (g.add_conv(p + ".to_kv", w2.data(), b2.data(), Cctx, 2 * Cp, 1, 1, 0, ctx, kv, nullptr, 0, 0)) return -1;
+        k = MtGraph::view(kv, 0, Cp); v = MtGraph::view(kv, Cp, Cp);
+    }
+    g.named[p + ".to_q"] = q; g.named[p + ".to_k"] = k; g.named[p + ".to_v"] = v;
     g.add_attn(p, q, k, v, o, heads, d16);
     return g.add_conv(p + ".to_out.0", wop.data(), bo, Cp, C, 1, 1, 0, o, out, &res, 0, 0);
 }
@@ -695,13 +721,13 @@ int mt_graph_alloc(MtGraph& g, int frames) {
         if (hipMalloc((void**)&g.bufs[i], bytes) != hipSuccess) { g.err = "activation allocation failed"; return -4; }
         (void)hipMemset(g.bufs[i], 0, bytes);
     }
-    // GroupNorm partial stats: [N][C/16][segs][32] floats, C <= 2560, segs <= 64 -> bound by the op list
+    // GroupNorm partial stats: [N][C/16][segs][32] floats, C <= 2560, segs <= 256 -> bound by the op list
     size_t need = 0;
     for (const MtOp& op : g.ops)
         if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * gn_segments(frames, op.x.C, op.x.P()) * 32);
     // the segment count is chosen per launch from the launch's frame count: size for the worst case (1 frame)
     for (const MtOp& op : g.ops)
-        if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 64 * 32);
+        if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 256 * 32);
     g.gn_partial_floats = need;
     if (hipMalloc((void**)&g.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     if (g.vt_halfs) {

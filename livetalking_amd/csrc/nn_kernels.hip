@@ -21,8 +21,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // =============================================================================================== GroupNorm
 int gn_segments(int N, int C, int P) {
     const long long blocks = (long long)N * (C / 16);
+    // a bandwidth kernel needs thousands of blocks in flight (each thread keeps only a few 16-byte loads outstanding):
+    // 512 blocks ran the 128-channel 256^2 maps at 1.6 TB/s
     int segs = 1;
-    while (blocks * segs < 512 && P / (segs * 2) >= 256 && segs < 64) segs *= 2;
+    while (blocks * segs < 4096 && P / (segs * 2) >= 512 && segs < 256) segs *= 2;
     return segs;
 }
 
@@ -38,7 +40,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
     float s[8], q[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { s[c] = 0.f; q[c] = 0.f; }
-    for (int p = p0 + pl; p < p1; p += 128) {
+    int p = p0 + pl;
+    for (; p + 384 < p1; p += 512) {          // four independent loads in flight per thread
+        const f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (size_t)p * 16);
+        const f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 128) * 16);
+        const f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 256) * 16);
+        const f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 384) * 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float f0 = (float)v0[c], f1 = (float)v1[c], f2 = (float)v2[c], f3 = (float)v3[c];
+            s[c] += (f0 + f1) + (f2 + f3);
+            q[c] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        }
+    }
+    for (; p < p1; p += 128) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)p * 16);
 #pragma unroll
         for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s[c] += f; q[c] += f * f; }
@@ -75,16 +90,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
                                                         f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale) {
     __shared__ float ab[2][16];
+    __shared__ float red[2][16][17];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB;
+    {   // group statistics of this block's 16 channels: 16 threads per channel share the cpg x segs partial sums
+        const int c = cb * 16 + (tid & 15), sl = tid >> 4;
+        const int g0 = (c / cpg) * cpg;           // first channel of this channel's group
+        const int terms = cpg * segs;
+        float S = 0.f, Q = 0.f;
+        for (int i = sl; i < terms; i += 16) {
+            const int cc = g0 + i / segs, sg = i - (i / segs) * segs;
+            const float* pp = partial + ((size_t)(n * CB + (cc >> 4)) * segs + sg) * 32 + (cc & 15);
+            S += pp[0]; Q += pp[16];
+        }
+        red[0][tid & 15][sl] = S;
+        red[1][tid & 15][sl] = Q;
+    }
+    __syncthreads();
     if (tid < 16) {
         const int c = cb * 16 + tid;
-        const int g0 = (c / cpg) * cpg;           // first channel of this channel's group
         float S = 0.f, Q = 0.f;
-        for (int cc = g0; cc < g0 + cpg; ++cc) {
-            const float* pp = partial + ((size_t)(n * CB + (cc >> 4)) * segs) * 32 + (cc & 15);
-            for (int sg = 0; sg < segs; ++sg) { S += pp[sg * 32]; Q += pp[sg * 32 + 16]; }
-        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S += red[0][tid][i]; Q += red[1][tid][i]; }
         const float cnt = (float)cpg * (float)P;
         const float mean = S / cnt;
         const float var = fmaxf(Q / cnt - mean * mean, 0.f);

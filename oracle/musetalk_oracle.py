@@ -86,7 +86,9 @@ def fp8_round(x: Tensor) -> Tensor:
 def fp8_weight(w: Tensor):
     """-> (dequantised weight, per-output-channel scale)"""
     m = w.abs().amax(dim=(1, 2, 3))
-    sw = torch.where(m > 0, 224.0 / m, torch.ones_like(m))
+    # tensor / tensor: correctly rounded fp32 division like the engine's 224.f / m (torch evaluates `224.0 / m` as
+    # 224 * reciprocal(m), one ulp off for some m, which flips the e4m3 rounding of weights that sit on a tie)
+    sw = torch.where(m > 0, torch.full_like(m, 224.0) / m, torch.ones_like(m))
     return fp8_round(w * sw[:, None, None, None]) / sw[:, None, None, None], sw
 
 

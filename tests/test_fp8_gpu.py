@@ -79,6 +79,11 @@ def test_conv_fp8_kernel(engine, case):
                              0, False, y16.data_ptr(), iters=3)
     print(f"[fp8conv] {case} rel_l2={rel:.2e} bad={bad} fp8 {ms*1e3:.1f} us  fp16 {ms16*1e3:.1f} us")
     assert torch.isfinite(got).all()
+    if bad:
+        idx = torch.nonzero(err > tol)[:6]
+        for i in idx:
+            n_, c_, y_, x_ = [int(v) for v in i]
+            print(f"[fp8conv] bad at n={n_} c={c_} y={y_} x={x_}: ref={float(ref[n_, c_, y_, x_]):.5f} got={float(got[n_, c_, y_, x_]):.5f}")
     assert bad == 0 and rel <= 2e-3, (case, rel, bad, float(err.max()))
 
 
