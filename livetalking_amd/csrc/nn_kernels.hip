@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     unsigned char* yq = reinterpret_cast<unsigned char*>(y) + ((size_t)(n * y_cbt + y_cb0 + (cb >> 1)) * P) * 32 + (cb & 1) * 16 + half * 8;
     const int p0 = blockIdx.y * 1024;
     const int p1 = min(P, p0 + 1024);
-    for (int p = p0 + (tid >> 1); p < p1; p += 128) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)p * 16);
+    auto emit = [&](const f16x8 v, int p) {
         f16x8 o;
         float f[8];
 #pragma unroll
@@ -152,7 +151,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
         } else {
             *reinterpret_cast<f16x8*>(yb + (size_t)p * 16) = o;
         }
+    };
+    int p = p0 + (tid >> 1);
+    if (p0 + 1024 <= P) {                     // whole segment: all 8 loads of a thread in flight before the first store
+        f16x8 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f16x8*>(xb + (size_t)(p + i * 128) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) emit(v[i], p + i * 128);
+        return;
     }
+    for (; p < p1; p += 128) emit(*reinterpret_cast<const f16x8*>(xb + (size_t)p * 16), p);
 }
 
 void launch_gn_apply(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
@@ -171,35 +180,38 @@ void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P
 }
 
 // =============================================================================================== LayerNorm
+// 16 tokens x 16 channel slices per block: the transformer maps are small (1024 / 256 / 64 tokens per image), so the grid
+// needs short blocks to cover 256 CUs (64-token blocks left the 32^2 level at one block per CU, 1 TB/s)
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int cbt, int cb0, int C, int P, float eps,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          f16* __restrict__ y, int y_cbt, int y_cb0) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][16][17];
     const int tid = threadIdx.x;
-    const int tok = tid & 63, part = tid >> 6;
+    const int tok = tid & 15, part = tid >> 4;
     const int n = blockIdx.y;
-    const int p = blockIdx.x * 64 + tok;
+    const int p = blockIdx.x * 16 + tok;
     const bool ok = p < P;
     const int items = C >> 3;
     const f16* xb = x + ((size_t)(n * cbt + cb0) * P) * 16;
     float s = 0.f, q = 0.f;
     if (ok) {
-        for (int i = part; i < items; i += 4) {
+        for (int i = part; i < items; i += 16) {
             const f16x8 v = *reinterpret_cast<const f16x8*>(xb + ((size_t)(i >> 1) * P + p) * 16 + (i & 1) * 8);
 #pragma unroll
             for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s += f; q += f * f; }
         }
     }
-    red[0][part][tok] = s;
-    red[1][part][tok] = q;
+    red[0][tok][part] = s;
+    red[1][tok][part] = q;
     __syncthreads();
-    const float S = red[0][0][tok] + red[0][1][tok] + red[0][2][tok] + red[0][3][tok];
-    const float Q = red[1][0][tok] + red[1][1][tok] + red[1][2][tok] + red[1][3][tok];
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S += red[0][tok][i]; Q += red[1][tok][i]; }
     const float mean = S / (float)C;
     const float rstd = rsqrtf(fmaxf(Q / (float)C - mean * mean, 0.f) + eps);
     if (!ok) return;
     f16* yb = y + ((size_t)(n * y_cbt + y_cb0) * P) * 16;
-    for (int i = part; i < items; i += 4) {
+    for (int i = part; i < items; i += 16) {
         const size_t off = ((size_t)(i >> 1) * P + p) * 16 + (i & 1) * 8;
         const f16x8 v = *reinterpret_cast<const f16x8*>(xb + off);
         f16x8 o;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 
 void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float eps, const float* gamma, const float* beta,
                       f16* y, int y_cbt, int y_cb0, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((P + 63) / 64, N), dim3(256), 0, s, x, cbt, cb0, C, P, eps, gamma, beta, y, y_cbt, y_cb0);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((P + 15) / 16, N), dim3(256), 0, s, x, cbt, cb0, C, P, eps, gamma, beta, y, y_cbt, y_cb0);
 }
 
 // =============================================================================================== attention
