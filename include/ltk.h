@@ -238,10 +238,10 @@ int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats)
  * MACs one pass executes (27,788,599,296 x frames for wav2lip256). */
 int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
 
-/* Generic standalone NHWC fp16 conv used by kernel unit tests: x device fp16
- * [N][H][W][Cin], weight host fp32 torch layout ([Cout][Cin][kh][kw], or
- * [Cin][Cout][kh][kw] when transposed), scale/shift host fp32 [Cout], res
- * device fp16 [N][Ho][Wo][Cout] or NULL, y device fp16 [N][Ho][Wo][Cout]. */
+/* Generic standalone fp16 conv used by kernel unit tests and per-layer timing.  Activations are in the engine's
+ * channel-blocked layout: x device fp16 [N][Cin/16][H][W][16] ([N][H][W][8] when Cin <= 8), res / y device fp16
+ * [N][Cout/16][Ho][Wo][16]; weight host fp32 torch layout ([Cout][Cin][kh][kw], or [Cin][Cout][kh][kw] when
+ * transposed), scale/shift host fp32 [Cout] (NULL = 1 / 0).  livetalking_amd/layout.py converts from NCHW. */
 int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
                    const float* weight, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                    int transposed, int out_pad, const float* scale, const float* shift,

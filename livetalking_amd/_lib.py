@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltk_hip.so")
+LIB_PATH = os.environ.get("LTK_LIB") or os.path.join(_HERE, "libltk_hip.so")      # LTK_LIB: A/B runs against another build
 
 
 class LtkError(RuntimeError):

@@ -60,9 +60,6 @@ struct K3Args {
     int relu;                        // activation: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU
     int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
     int nitems;                      // work items (ksplit x pixel tiles x cout tiles); gridDim.x <= nitems
-    int stagger;                     // cycles the second resident block of each CU idles before it starts, so the
-                                     // two blocks of a CU run out of phase (one in its MFMA loop while the other
-                                     // is in its prologue / epilogue)
     int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
     int ablate;                      // measurement only (LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no residual read,
                                      // 16 no output store, 32 no LDS zero fill
@@ -418,64 +415,85 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // as a per-value runtime test hipcc if-converted it and every value paid for erff and exp
     auto epilogue = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
+        // Loop order: (phase, cout block) outside, the wave's PXW pixel subtiles inside.  The folded-BN scale/shift of a cout
+        // block is read ONCE (4 ds_read_b128) and serves all subtiles; with the subtile loop outside every 16-byte store
+        // waited for its own LDS round trip (64 reads per item, each followed by s_waitcnt lgkmcnt(0)): on the
+        // 64-channel layers, whose K loop is only 4 chunks, the epilogue was a third of the item.
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G; ++g) {
+            int obase[PXW], rbase[PXW];
+            bool okj[PXW];
 #pragma unroll
-        for (int j = 0; j < PXW; ++j) {
-            bool ok;
-            int n;
-            const int opx = out_px(j, g, &n, &ok);
-            const int obase = ((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16 + hh * 8;
-            const int rbase = ((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16 + hh * 4;
+            for (int j = 0; j < PXW; ++j) {
+                int n;
+                const int opx = out_px(j, g, &n, &okj[j]);
+                obase[j] = ((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16 + hh * 8;
+                rbase[j] = ((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16 + hh * 4;
+            }
 #pragma unroll
             for (int i = 0; i < NBT; ++i) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {        // channel block 2i+pr of this block's BN
-                    unsigned pk[2][2];
+                    if ((2 * i + pr) >= ncb_valid) continue;         // wave-uniform
+                    f32x4 sc[2], sf[2];
 #pragma unroll
                     for (int eo = 0; eo < 2; ++eo) {    // q4 = 2pr+eo: channels 8*q4 + 4*hh .. +3 of the 32-cout tile i
-                        const int q4 = 2 * pr + eo;
-                        const int cl = i * 32 + 8 * q4 + 4 * hh;
-                        f32x4 sc, sf;
+                        const int cl = i * 32 + 8 * (2 * pr + eo) + 4 * hh;
                         if constexpr (T == 1) {
-                            sc = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);
-                            sf = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
+                            sc[eo] = *reinterpret_cast<const f32x4*>(a.scale + cout0 + cl);
+                            sf[eo] = *reinterpret_cast<const f32x4*>(a.shift + cout0 + cl);
                         } else {
-                            sc = *reinterpret_cast<const f32x4*>(sbase + cl);
-                            sf = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
+                            sc[eo] = *reinterpret_cast<const f32x4*>(sbase + cl);
+                            sf[eo] = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
                         }
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[r] + sf[r];
-                        if (has_res && ok && (2 * i + pr) < ncb_valid) {
-                            const f16x4 rr = *reinterpret_cast<const f16x4*>(a.res + rbase + (2 * i + pr) * HWo16 + eo * 8);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                        }
-                        f16x4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float t = v[r];
-                            if constexpr (ACT == 1) t = fmaxf(t, 0.f);
-                            else if constexpr (ACT == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
-                            else if constexpr (ACT == 3) t = t / (1.f + __expf(-t));
-                            t = fminf(fmaxf(t, -65504.f), 65504.f);
-                            o[r] = (f16)t;
-                        }
-                        const uint2 u = *reinterpret_cast<const uint2*>(&o);
-                        pk[eo][0] = u.x; pk[eo][1] = u.y;
                     }
-                    // lanes 0-31 keep eo=0 (channels 0-3) and receive the partner's eo=0 (channels 4-7);
-                    // lanes 32-63 end with the eo=1 pair
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    if (ok && do_store && (2 * i + pr) < ncb_valid)
-                        *reinterpret_cast<uint4*>(a.y + obase + (2 * i + pr) * HWo16) = out;
+                    f16x4 rr[PXW][2];
+                    if (has_res) {
+#pragma unroll
+                        for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                            for (int eo = 0; eo < 2; ++eo)
+                                if (okj[j]) rr[j][eo] = *reinterpret_cast<const f16x4*>(a.res + rbase[j] + (2 * i + pr) * HWo16 + eo * 8);
+                    }
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int eo = 0; eo < 2; ++eo) {
+                            const int q4 = 2 * pr + eo;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[eo][r] + sf[eo][r];
+                            if (has_res && okj[j]) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += (float)rr[j][eo][r];
+                            }
+                            f16x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float t = v[r];
+                                if constexpr (ACT == 1) {
+                                    t = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);          // ReLU and the fp16 range in one op
+                                } else {
+                                    if constexpr (ACT == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                                    else if constexpr (ACT == 3) t = t / (1.f + __expf(-t));
+                                    t = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+                                }
+                                o[r] = (f16)t;
+                            }
+                            const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                            pk[eo][0] = u.x; pk[eo][1] = u.y;
+                        }
+                        // lanes 0-31 keep eo=0 (channels 0-3) and receive the partner's eo=0 (channels 4-7);
+                        // lanes 32-63 end with the eo=1 pair
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                        const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (okj[j] && do_store) *reinterpret_cast<uint4*>(a.y + obase[j] + (2 * i + pr) * HWo16) = out;
+                    }
                 }
             }
         }
-    }
     };
     if (a.relu == 1) epilogue(std::integral_constant<int, 1>{});
     else if (a.relu == 2) epilogue(std::integral_constant<int, 2>{});
@@ -712,7 +730,6 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         HIPCHK3(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured.push_back((const void*)k);
     }
-    a.stagger = 0;
     a.nitems = (int)nblk;
     const char* ev_pers = getenv("LTK_CONV_PERSIST");      // 0: one block per item
     const int persist_blocks = ev_pers ? atoi(ev_pers) : 512;
