@@ -67,7 +67,11 @@ def load_model(unet_state_dict=None, vae_state_dict=None, whisper_encoder_state_
     if max_frames is None:
         max_frames = int(os.environ.get("LTK_MT_MAX_FRAMES", "16"))
     eng = Engine(dev)
-    eng.load_musetalk(unet_state_dict, vae_state_dict, max_frames=max_frames)
+    # LTK_MT_FP8=1: the fp8 conv path of BASELINE.json configs[4] (ResnetBlock2D convs on e4m3 operands, include/ltk.h
+    # ltk_musetalk_set_fp8); LTK_MT_FP8_ASCALE overrides the activation scale (default 8)
+    fp8 = os.environ.get("LTK_MT_FP8", "0") not in ("", "0")
+    eng.load_musetalk(unet_state_dict, vae_state_dict, max_frames=max_frames, fp8=fp8,
+                      fp8_act_scale=float(os.environ.get("LTK_MT_FP8_ASCALE", "0")))
     ap = Audio2Feature(eng, whisper_encoder_state_dict)
     return MuseTalkModel(eng, ap)
 
