@@ -139,6 +139,20 @@ def main_musetalk(args):
     nt = min(fps_step, 64)
     ms, macs = eng.musetalk_time(nt, 3)
     achieved = 2.0 * macs / (ms * 1e-3) / 1e12
+    # WhisperASR.run_step's feature work (log-mel + whisper-tiny encoder + chunk slicing) for one session's 0.64-s step: the
+    # reference runs it on the render thread, outside inferfps (base_avatar.py:364-373 times inference_batch only); reported
+    # beside it because BASELINE configs[2] names it
+    eng.load_whisper(synth.whisper_encoder_state_dict())
+    pcm = synth.synthetic_audio(2.0)[: (20 + 2 * B) * 320]
+    d_chunks = torch.zeros(B, 50, 384, dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    for _ in range(5):
+        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
+    torch.cuda.synchronize()
+    whisper_ms = (time.perf_counter() - tw) / 5 * 1e3
     if rank == 0:
         out = {"metric": "inferfps", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -152,6 +166,9 @@ def main_musetalk(args):
                             "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
                             "kernel": "conv3_kernel / conv_mfma_kernel (U-Net + VAE conv and linear layers; attention excluded from the flop count)",
                             "pass_ms": round(ms, 4), "flops_per_frame": 2.0 * macs / nt}}
+        out["whisper"] = {"ms_per_session_step": round(whisper_ms, 3), "frames_per_step": B,
+                          "note": "log-mel + whisper-tiny encoder (1500 tokens) + chunk slicing, host PCM in, device features out; not in `value`",
+                          "fps_incl_whisper": round(fps_step / (elapsed / args.steps + S * whisper_ms * 1e-3), 2)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_musetalk()
         print(json.dumps(out), flush=True)

@@ -294,3 +294,33 @@ def musetalk_whisper_feats(batch: int, seed: int = 11) -> np.ndarray:
     """(B,50,384) audio feature stand-in with the value range of Whisper encoder states."""
     rng = np.random.default_rng(seed)
     return rng.standard_normal((batch, 50, 384)).astype(np.float32)
+
+
+def whisper_encoder_state_dict(seed: int = 2468) -> Dict[str, np.ndarray]:
+    """whisper-tiny ENCODER stand-in under transformers' key names (WhisperModel(...).encoder.state_dict()): d_model 384,
+    6 heads, 4 layers, ffn 1536, 1500 positions (avatars/musetalk/whisper/audio2feature.py:15-23 loads the real one)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    D, FF = 384, 1536
+    sd["conv1.weight"] = _w(rng, (D, 80, 3), 80 * 3)
+    sd["conv1.bias"] = (rng.standard_normal(D) * 0.02).astype(np.float32)
+    sd["conv2.weight"] = _w(rng, (D, D, 3), D * 3)
+    sd["conv2.bias"] = (rng.standard_normal(D) * 0.02).astype(np.float32)
+    pos = np.arange(1500)[:, None] * np.exp(-np.log(10000.0) / (D // 2 - 1) * np.arange(D // 2))[None, :]
+    sd["embed_positions.weight"] = np.concatenate([np.sin(pos), np.cos(pos)], axis=1).astype(np.float32)
+    for l in range(4):
+        p = f"layers.{l}"
+        for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[f"{p}.self_attn.{name}.weight"] = _w(rng, (D, D), D, gain=0.7)
+            if name != "k_proj":
+                sd[f"{p}.self_attn.{name}.bias"] = (rng.standard_normal(D) * 0.02).astype(np.float32)
+        for ln in ("self_attn_layer_norm", "final_layer_norm"):
+            sd[f"{p}.{ln}.weight"] = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+            sd[f"{p}.{ln}.bias"] = (0.05 * rng.standard_normal(D)).astype(np.float32)
+        sd[f"{p}.fc1.weight"] = _w(rng, (FF, D), D)
+        sd[f"{p}.fc1.bias"] = (rng.standard_normal(FF) * 0.02).astype(np.float32)
+        sd[f"{p}.fc2.weight"] = _w(rng, (D, FF), FF, gain=0.7)
+        sd[f"{p}.fc2.bias"] = (rng.standard_normal(D) * 0.02).astype(np.float32)
+    sd["layer_norm.weight"] = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    sd["layer_norm.bias"] = (0.05 * rng.standard_normal(D)).astype(np.float32)
+    return sd
