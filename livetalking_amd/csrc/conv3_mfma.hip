@@ -685,7 +685,8 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     bool fit = geom(PXW);
     if (PXW == 4) {
         const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
-        if (!fit || blocks * nt < 448) { PXW = 2; fit = geom(PXW); }
+        static const int pxw4_min = [] { const char* e = getenv("LTK_CONV_PXW4_MIN"); return e ? atoi(e) : 448; }();
+        if (!fit || blocks * nt < pxw4_min) { PXW = 2; fit = geom(PXW); }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
