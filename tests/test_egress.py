@@ -132,3 +132,97 @@ def test_device_egress_clock_and_requests():
     eg2 = egress.DeviceEgress(fe, 4, 8, egress.SRC_MUSETALK, 1, fmt="bgr24", enable_transition=False, watermark=None, clock=clk)
     eg2.speaking_frame(1, 0)
     assert fe.calls[-1][7] == -1.0 and fe.calls[-1][8] is False and eg2._out().shape == (4, 8, 3)
+
+
+class _FakePred:
+    def __init__(self, ptr):
+        self._p = ptr
+
+    def data_ptr(self):
+        return self._p
+
+
+class _FakeModel:
+    def __init__(self, engine):
+        self.engine = engine
+
+
+class _Out:
+    def __init__(self):
+        self.video, self.audio, self.started, self.stopped = [], [], False, False
+
+    def start(self):
+        self.started = True
+
+    def push_video_frame(self, f):
+        self.video.append(f)
+
+    def push_audio_frame(self, pcm, userdata=None):
+        self.audio.append((pcm.dtype, pcm.shape, userdata))
+
+    def stop(self):
+        self.stopped = True
+
+
+def test_process_frames_mixin_control_flow():
+    """The opt.egress process_frames loop (livetalking_amd/egress.py) against the control flow of
+    avatars/base_avatar.py:384-460: silent frames take the bank frame or the custom-action cycle (with its own mirror
+    index), speaking frames go through the composite, a failing frame is logged and dropped, audio is pushed as int16."""
+    import argparse
+    import queue
+    import threading
+
+    from livetalking_amd import egress
+    from livetalking_amd.hostshim import AudioFrameData
+
+    fe = _FakeEngine()
+    calls = fe.calls
+
+    def egress_frame(h, out, source, avatar_id, idx, d_pred, h_frame, speaking, alpha, keep, fmt, chroma):
+        if d_pred == 666:
+            raise RuntimeError("boom")
+        calls.append(("frame", source, idx, d_pred, None if h_frame is None else int(h_frame[0, 0, 0]), speaking))
+        return out
+
+    fe.egress_frame = egress_frame
+
+    class Sess(egress.DeviceEgressMixin):
+        _egress_source = egress.SRC_MUSETALK
+
+        def __init__(self):
+            self.opt = argparse.Namespace(egress="bgr24", enable_transition=False)
+            self.model = _FakeModel(fe)
+            self._aid = 5
+            self.frame_list_cycle = [np.zeros((4, 8, 3), np.uint8)] * 3
+            self.res_frame_queue = queue.Queue()
+            self.output = _Out()
+            self.custom_index = {2: 0}
+            self.custom_img_cycle = {2: [np.full((4, 8, 3), 10 + i, np.uint8) for i in range(2)]}
+            self.speaking = False
+
+    s = Sess()
+    pcm = np.full(320, 0.5, np.float32)
+    mk = lambda t: [AudioFrameData(pcm, t, {"k": t}), AudioFrameData(pcm, t, {"k": t})]    # noqa: E731
+    s.res_frame_queue.put((None, mk(1), 1))                      # silent: bank frame 1
+    s.res_frame_queue.put((_FakePred(111), mk(0), 2))            # speaking
+    s.res_frame_queue.put((_FakePred(666), mk(0), 0))            # composite fails: dropped, no audio either
+    for _ in range(3):
+        s.res_frame_queue.put((None, mk(2), 0))                  # custom action video: indices 0, 1, 1 (mirror)
+    ev = threading.Event()
+    th = threading.Thread(target=s.process_frames, args=(ev,))
+    th.start()
+    import time
+    t0 = time.time()
+    while len(s.output.video) < 5 and time.time() - t0 < 10:
+        time.sleep(0.01)
+    ev.set()
+    th.join(timeout=5)
+    assert not th.is_alive() and s.output.started and s.output.stopped
+    frames = [c for c in calls if c[0] == "frame"]
+    assert frames[0] == ("frame", egress.SRC_MUSETALK, 1, 0, None, False)
+    assert frames[1] == ("frame", egress.SRC_MUSETALK, 2, 111, None, True)
+    assert [f[4] for f in frames[2:]] == [10, 11, 11] and all(f[1] == egress.SRC_HOST for f in frames[2:])
+    assert s.custom_index[2] == 3 and s.speaking is False
+    assert len(s.output.video) == 5 and len(s.output.audio) == 10
+    assert s.output.audio[0][0] == np.int16 and s.output.audio[0][2] == {"k": 1}
+    assert calls[-1] == ("close", 7)
