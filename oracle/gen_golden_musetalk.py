@@ -8,8 +8,12 @@ What runs from the reference, unmodified (imported, never copied):
   avatars.audio_features.whisper.WhisperASR._feature2chunks  (whisper.py:35-56) + BaseASR._get_sliced_feature
                                                              (base_asr.py:91-133), via WhisperASR.run_step's arguments
   avatars.musetalk_avatar: mirror_index use                  (utils/image.py:26-32)
-The U-Net / VAE arithmetic itself lives in `diffusers` (absent): see oracle/musetalk_oracle.py (PARITY UNPINNED).
-Writes tests/golden/musetalk_host_golden.npz after asserting that the oracle restatements agree.
+  avatars.musetalk.models.syncnet.ResnetBlock2D              (syncnet.py:71-139, the in-tree twin of diffusers' ResnetBlock2D
+                                                             without temb, incl. the asymmetric-pad stride-2 downsample)
+  avatars.musetalk.whisper.whisper.model.MultiHeadAttention  (model.py:57-100: the same multi-head attention arithmetic as
+                                                             diffusers' Attention; pins head split + scaling)
+The U-Net / VAE graph itself lives in `diffusers` (absent): see oracle/musetalk_oracle.py (PARITY UNPINNED as a whole).
+Writes tests/golden/musetalk_host_golden.npz and musetalk_blocks_golden.npz after asserting that the oracle restatements agree.
 """
 from __future__ import annotations
 
@@ -68,6 +72,68 @@ def main():
     np.savez_compressed(os.path.join(args.out, "musetalk_host_golden.npz"), pe_table=pe_table.astype(np.float32), chunk_rows=rows,
                         chunk_rows_short=rows_short)
     print("wrote musetalk_host_golden.npz: pe_table", pe_table.shape, "chunk_rows", rows.shape, rows[0], rows[-1])
+
+    # ---- ResnetBlock2D + asymmetric-pad downsample: the reference's in-tree implementation (syncnet.py:71-139).  The module
+    # imports two diffusers classes for its attention block; they are stubbed, ResnetBlock2D itself is plain torch.
+    gen_golden._stub("diffusers.models")
+    gen_golden._stub("diffusers.models.attention", Attention=object, FeedForward=object)
+    gen_golden._stub("diffusers.utils")
+    gen_golden._stub("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+    from avatars.musetalk.models.syncnet import ResnetBlock2D
+    torch.manual_seed(7)
+    blocks = {"a": ResnetBlock2D(32, 64, norm_num_groups=32, eps=1e-6, downsample_factor=1),       # with conv_shortcut
+              "b": ResnetBlock2D(64, 64, norm_num_groups=32, eps=1e-6, downsample_factor=2)}       # identity skip + downsample
+    out = {}
+    with torch.no_grad():
+        for name, blk in blocks.items():
+            for prm in blk.parameters():               # default init leaves the norms at (1, 0): randomise everything
+                prm.copy_(torch.randn_like(prm) * (0.3 if prm.dim() == 1 else (2.0 / prm[0].numel()) ** 0.5))
+            for nm, prm in blk.named_parameters():
+                if nm.startswith("norm") and nm.endswith("weight"):
+                    prm.add_(1.0)
+            cin = 32 if name == "a" else 64
+            xin = torch.randn(2, cin, 13, 10)          # odd height: the bottom pad row matters
+            y = blk.eval()(xin)
+            sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+            # oracle: resnet() + downsample_asym() under the same tensor names
+            osd = {f"r.{k}": v for k, v in sd.items() if not k.startswith("downsample_conv")}
+            mine = musetalk_oracle.resnet(osd, "r", xin, None, 32, 1e-6)
+            if name == "b":
+                osd["d.weight"], osd["d.bias"] = sd["downsample_conv.weight"], sd["downsample_conv.bias"]
+                mine = musetalk_oracle.downsample_asym(osd, "d", mine)
+            err = float((mine - y).abs().max())
+            assert mine.shape == y.shape and err < 2e-5, f"ResnetBlock2D restatement drifted ({name}: {err})"
+            out[f"{name}_x"] = xin.numpy()
+            out[f"{name}_y"] = y.numpy()
+            for k, v in sd.items():
+                out[f"{name}_sd.{k}"] = v.numpy()
+            print(f"ResnetBlock2D {name}: out {tuple(y.shape)} max|restatement - reference| = {err:.2e}")
+    # ---- multi-head attention: the in-tree OpenAI Whisper MultiHeadAttention (avatars/musetalk/whisper/whisper/model.py:57-100)
+    # is the same operation as diffusers' Attention (separate q/k/v/out Linears, heads = contiguous channel slices,
+    # softmax(q k^T d^-0.5) v); it pins the head split and scaling of musetalk_oracle.attention for self- and cross-attention.
+    gen_golden._stub("ffmpeg")                      # whisper/audio.py imports it for file decoding only
+    from avatars.musetalk.whisper.whisper.model import MultiHeadAttention
+    torch.manual_seed(11)
+    mha = MultiHeadAttention(128, 8).eval()
+    with torch.no_grad():
+        for prm in mha.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.1 if prm.dim() == 1 else (1.0 / prm.shape[1]) ** 0.5))
+        xq = torch.randn(2, 37, 128)
+        xc = torch.randn(2, 50, 128)
+        y_self = mha(xq)
+        y_cross = mha(xq, xa=xc)
+        asd = {"m.to_q.weight": mha.query.weight, "m.to_q.bias": mha.query.bias, "m.to_k.weight": mha.key.weight,
+               "m.to_v.weight": mha.value.weight, "m.to_v.bias": mha.value.bias, "m.to_out.0.weight": mha.out.weight,
+               "m.to_out.0.bias": mha.out.bias}
+        e1 = float((musetalk_oracle.attention(asd, "m", xq, xq, 8) - y_self).abs().max())
+        e2 = float((musetalk_oracle.attention(asd, "m", xq, xc, 8) - y_cross).abs().max())
+        assert e1 < 2e-5 and e2 < 2e-5, f"attention restatement drifted ({e1}, {e2})"
+        print(f"MultiHeadAttention: self {e1:.2e}, cross {e2:.2e}")
+        out.update({"mha_xq": xq.numpy(), "mha_xc": xc.numpy(), "mha_y_self": y_self.numpy(), "mha_y_cross": y_cross.numpy()})
+        for k, v in asd.items():
+            out["mha_sd." + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(args.out, "musetalk_blocks_golden.npz"), **out)
+    print("wrote musetalk_blocks_golden.npz")
 
 
 if __name__ == "__main__":

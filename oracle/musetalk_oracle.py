@@ -24,11 +24,15 @@ algorithm for
     attention, resnet), 4 up blocks x 3 resnets with nearest-2x upsample + conv, GN-SiLU-conv_out,
 under diffusers' own state_dict key names, so a real checkpoint would load unchanged.
 
-PARITY UNPINNED: no diffusers build, config file, checkpoint or golden tensor exists in this
-container or in the reference tree to check this restatement against.  In-tree near-equivalents
-of the building blocks that were compared by reading: avatars/musetalk/models/syncnet.py:71-139
-(ResnetBlock2D: GN -> SiLU -> conv -> GN -> SiLU -> conv + 1x1 shortcut) and :142-181
-(AttentionBlock2D).  The HIP path is required to match THIS statement within the fp16 tolerance
+PARITY UNPINNED for the graph as a whole: no diffusers build, config file, checkpoint or golden tensor
+exists in this container or in the reference tree to check this restatement against.  What IS pinned:
+the ResnetBlock2D building block (GN -> SiLU -> conv -> GN -> SiLU -> conv + 1x1 shortcut) and the
+asymmetric-pad stride-2 downsample, against the reference's own in-tree implementation
+(avatars/musetalk/models/syncnet.py:71-139, imported with `diffusers` stubbed; golden tensors in
+tests/golden/musetalk_blocks_golden.npz), the positional encoding (unet.py:12-27) and the Whisper side
+(oracle/whisper_oracle.py calls the installed transformers).  Compared by reading only: syncnet.py:142-181
+(AttentionBlock2D: GN, 1x1 in, LN, attention, LN, GEGLU feed-forward, 1x1 out), whose attention and
+feed-forward are diffusers classes.  The HIP path is required to match THIS statement within the fp16 tolerance
 written in tests/test_musetalk_gpu.py.
 """
 from __future__ import annotations
@@ -137,7 +141,9 @@ def _tap(taps, name, t):
 
 
 def resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float, taps=None) -> Tensor:
-    """diffusers ResnetBlock2D (output_scale_factor 1, no up/down)."""
+    """diffusers ResnetBlock2D (output_scale_factor 1, no up/down).  Without temb this is the reference's in-tree
+    ResnetBlock2D (avatars/musetalk/models/syncnet.py:71-139): pinned against it by oracle/gen_golden_musetalk.py ->
+    tests/golden/musetalk_blocks_golden.npz (tests/test_musetalk_host.py)."""
     h = _tap(taps, p + ".norm1", F.silu(_gn(sd, p + ".norm1", x, groups, eps)))
     h = _conv3_q(sd, p + ".conv1", h)
     if temb is not None:
@@ -148,6 +154,12 @@ def resnet(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: 
     if (p + ".conv_shortcut.weight") in sd:
         x = _tap(taps, p + ".conv_shortcut", _conv(sd, p + ".conv_shortcut", x, pad=0))
     return _tap(taps, p + ".conv2", x + h)
+
+
+def downsample_asym(sd: SD, p: str, x: Tensor) -> Tensor:
+    """diffusers Downsample2D(padding=0): one zero row / column at the bottom / right, then Conv2d(k3, s2, p0).
+    Pinned (tests/golden/musetalk_blocks_golden.npz) against the in-tree equivalent, syncnet.py:112-121,136-138."""
+    return _conv(sd, p, F.pad(x, (0, 1, 0, 1)), stride=2, pad=0)
 
 
 def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, taps=None) -> Tensor:
@@ -296,8 +308,7 @@ def vae_encode_moments(sd: SD, x: Tensor, taps: Optional[Dict[str, Tensor]] = No
         for j in range(2):
             h = resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, None, VAE_GROUPS, VAE_EPS)
         if i < 3:
-            h = F.pad(h, (0, 1, 0, 1))
-            h = _conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride=2, pad=0)
+            h = downsample_asym(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h)
         if taps is not None:
             taps[f"encoder.down_blocks.{i}"] = h.detach().clone()
     h = resnet(sd, "encoder.mid_block.resnets.0", h, None, VAE_GROUPS, VAE_EPS)
