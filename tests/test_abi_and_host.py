@@ -165,3 +165,33 @@ def test_host_e4m3_conversion_matches_torch():
     diff = np.nonzero(out != ref)[0]
     diff = [i for i in diff if (out[i] & 0x7F) or (ref[i] & 0x7F)]          # +0 vs -0 is not a difference
     assert not diff, [(float(vals[i]), int(out[i]), int(ref[i])) for i in diff[:8]]
+
+
+def test_abi_argument_validation_without_gpu():
+    """Every entry point rejects NULL / out-of-range arguments with LTK_E_INVALID and a message, before touching HIP;
+    creating an engine on a box without a GPU fails with an error code instead of crashing (the product path fails loudly)."""
+    import ctypes as C
+
+    import torch
+    from livetalking_amd import _lib
+    lib = _lib.load()
+    E_INVALID = -1
+    null = C.c_void_p(None)
+    assert lib.ltk_paste_back(null, 0, 0, null, null, 0, null) == E_INVALID and b"bad arguments" in lib.ltk_last_error()
+    assert lib.ltk_paste_blend(null, 0, 0, null, null, 0, null) == E_INVALID
+    assert lib.ltk_wav2lip_infer(null, None, 0, null) < 0
+    assert lib.ltk_musetalk_infer(null, None, 0, null) < 0
+    assert lib.ltk_mel_step(null, null, 0, null, 0, null, null) < 0
+    assert lib.ltk_whisper_step(null, null, 0, 0, 0, 0, 0, null, null) < 0
+    assert lib.ltk_egress_open(null, 4, 4, C.byref(C.c_void_p())) == E_INVALID
+    assert lib.ltk_egress_frame(null, null, None, null, null) == E_INVALID
+    assert lib.ltk_musetalk_set_fp8(null, 1, 0.0) == E_INVALID
+    assert lib.ltk_f32_to_e4m3(null, 4, null) == E_INVALID
+    assert lib.ltk_conv2d_fp8(null, null, 1, 1, 1, 32, null, 32, null, null, 8.0, null, 0, null, 0, None) == E_INVALID
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        rc = lib.ltk_engine_create(0, C.byref(h))
+        assert rc < 0 and not h.value and lib.ltk_last_error()
+        from livetalking_amd.engine import Engine
+        with pytest.raises(Exception):
+            Engine(0)
