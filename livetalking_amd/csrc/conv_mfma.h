@@ -1,6 +1,6 @@
-// Implicit-GEMM NHWC fp16 convolution on gfx950 MFMA (v_mfma_f32_32x32x16_f16).
-// Host-side plan + launch interface.  See conv_mfma.hip for the kernel and
-// DESIGN.md §Kernels for the data layout.
+// Implicit-GEMM fp16 convolution on gfx950 MFMA (v_mfma_f32_32x32x16_f16) over channel-blocked activations
+// (CB16: [N][C/16][H][W][16]; network inputs of <= 8 channels are [N][H][W][8]).  Host-side plan + launch interface
+// shared by conv_mfma.hip (register-staged first-generation kernel) and conv3_mfma.hip (LDS-DMA kernel); DESIGN.md §2-3.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,12 +25,12 @@ struct ConvPhase {
 };
 
 struct ConvArgs {
-    const f16* x;           // input NHWC, pixel stride x_ld halfs, channels [x_coff, x_coff+Cin)
+    const f16* x;           // input CB16 buffer of x_ld channels; this tensor = channels [x_coff, x_coff+Cin)
     const f16* w;           // packed weights (see pack_weights)
     const float* scale;     // [Cout] folded BN scale
     const float* shift;     // [Cout] folded BN shift (+conv bias)
     const f16* res;         // residual (same pixel mapping as y) or nullptr
-    f16* y;                 // output NHWC
+    f16* y;                 // output CB16 buffer of y_ld channels, written at [y_coff, y_coff+Cout)
     int N, H, W;
     int x_ld, x_coff;
     int Ho, Wo;             // logical output grid one phase covers

@@ -1,4 +1,6 @@
-// Implicit-GEMM NHWC fp16 convolution for gfx950 (CDNA4) on MFMA.
+// Implicit-GEMM fp16 convolution for gfx950 (CDNA4) on MFMA, first generation (register-staged); activations are
+// channel-blocked CB16 ([N][C/16][H][W][16]), inputs of <= 8 channels [N][H][W][8].  Today it runs the 7x7, the
+// shallow strided 3x3 and the valid-padding layers; conv3_mfma.hip runs the rest.
 //
 // Replaces the torch.nn.Conv2d / ConvTranspose2d + BatchNorm2d(eval) + residual
 // + ReLU blocks of the reference generator (avatars/wav2lip/models/conv.py:5-44,
@@ -15,7 +17,7 @@
 //     contiguous, fully coalesced copy;
 //   * v_mfma_f32_32x32x16_f16 with the WEIGHTS as the row operand and the PIXELS
 //     as the column operand: a lane's 16 accumulators then are 4 groups of 4
-//     consecutive output channels of ONE pixel -> 8-byte NHWC stores, and the
+//     consecutive output channels of ONE pixel -> 8-byte stores into the pixel's channel block, and the
 //     folded BN scale/shift, residual add and ReLU are applied in registers;
 //   * channel-offset reads/writes (x_ld/x_coff, y_ld/y_coff) make the decoder's
 //     torch.cat skip connections (wav2lip_v2.py:146) free;

@@ -3,9 +3,10 @@
 // Host-side statement of the Wav2Lip-256 generator graph
 // (avatars/wav2lip/models/wav2lip_v2.py:12-91, forward :123-163) as a static
 // layer program over a device activation arena: every layer is one launch of
-// the MFMA implicit-GEMM kernel (conv_mfma.hip); torch.cat skip connections are
-// channel-offset writes into shared NHWC buffers; eval-mode BatchNorm is folded
-// into the epilogue scale/shift at load time.
+// the MFMA implicit-GEMM kernels (conv3_mfma.hip / conv_mfma.hip); torch.cat skip
+// connections are channel-block ranges of shared CB16 buffers; eval-mode BatchNorm
+// is folded into the epilogue scale/shift at load time.  The MuseTalk / Whisper /
+// VAE-encoder programs (musetalk.hip), frame egress and the test hooks follow.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

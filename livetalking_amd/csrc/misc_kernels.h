@@ -16,7 +16,7 @@ struct FacePtrs {
     const uint8_t* p[kPackMaxFrames];
 };
 
-// wav2lip_avatar.py:125-134: face u8 BGR [256][256][3] -> fp16 NHWC [256][256][8]
+// wav2lip_avatar.py:125-134: face u8 BGR [256][256][3] -> fp16 [256][256][8] (pixel-major, one 16-byte item per pixel)
 // = {masked b,g,r (rows >= 128 zero), b,g,r, 0, 0} / 255.
 void launch_pack_faces(const FacePtrs& faces, int nframes, f16* x0, hipStream_t s);
 
@@ -24,10 +24,10 @@ struct MelPtrs {
     const float* p[kPackMaxFrames];   // per frame: float32 [80][16]
 };
 
-// mel float32 [80][16] per frame -> fp16 NHWC [B][80][16][8] (channel 0 = value).
+// mel float32 [80][16] per frame -> fp16 [B][80][16][8] (pixel-major, channel 0 = value).
 void launch_pack_mel(const MelPtrs& mel, int nframes, f16* out, hipStream_t s);
 
-// face6 float32 NCHW [B][6][256][256] -> fp16 NHWC [B][256][256][8] (test hook).
+// face6 float32 NCHW [B][6][256][256] -> fp16 [B][256][256][8] (test hook).
 void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_t s);
 
 // wav2lip_v2.py:90-91 + wav2lip_avatar.py:138,145: 1x1 conv 32->3 + sigmoid;
@@ -39,7 +39,7 @@ struct OutPtrs {
 void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s);
 
-// fp16 NHWC (ld, coff, C channels) -> float32 NCHW (debug capture).
+// fp16 CB16 (or [N][H][W][8] when ld <= 8) channel range (ld, coff, C) -> float32 NCHW (debug capture).
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s);
 
 // audio.py:45-51 melspectrogram columns + mel.py:56-63 window gather.
