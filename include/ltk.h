@@ -232,6 +232,11 @@ int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6
 int ltk_debug_capture(ltk_engine* e, int enable);
 int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats);
 
+/* Tuning / A-B knobs (livetalking_amd/csrc/tune.h).  Every knob is read from the environment once per process; this call
+ * changes one in-process (sweep scripts, tests).  `name` with or without the LTK_ prefix.  Process-wide, not per engine:
+ * knobs that shape a plan (weight pack order) only affect plans created afterwards. */
+int ltk_debug_set_knob(const char* name, int value);
+
 /* Conv-stack only (no gather/pack, no head): used by bench.py to time the
  * dominant kernel family with HIP events.  Returns average milliseconds per
  * pass over `iters` passes of `frames` frames, and the number of conv/convT

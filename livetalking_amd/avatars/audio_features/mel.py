@@ -57,7 +57,7 @@ class MelASR(BaseASR):
         starts = window_starts(len(self.frames), self.stride_left_size, self.stride_right_size, self.fps, n_cols)
         torch = self._torch
         feat = torch.empty((len(starts), 80, MEL_STEP_SIZE), dtype=torch.float32,
-                           device=torch.device("cuda", self.engine.device))
+                           device=self.engine.torch_device)
         self.engine.mel_step(inputs, starts, feat.data_ptr())
         self.feat_queue.put(feat)
         self.frames = self.frames[-(self.stride_left_size + self.stride_right_size):]

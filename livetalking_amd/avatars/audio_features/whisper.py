@@ -42,7 +42,7 @@ class WhisperASR(BaseASR):
             return
         inputs = np.concatenate(self.frames).astype(np.float32, copy=False)
         torch = self._torch
-        feat = torch.empty((self.batch_size, 50, 384), dtype=torch.float32, device=torch.device("cuda", self.engine.device))
+        feat = torch.empty((self.batch_size, 50, 384), dtype=torch.float32, device=self.engine.torch_device)
         # whisper.py:71-73: audio_feat_win [0,5], start l/2, multiplier 2 -> rows [2*(i + l/2), +10)
         first_row = int((self.stride_left_size / 2) * 2)
         self.engine.whisper_step(inputs, self.batch_size, first_row, feat.data_ptr(), row_step=2, rows=10)

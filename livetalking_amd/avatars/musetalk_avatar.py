@@ -129,7 +129,7 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
         """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for bank index
         mirror_index(len, index+i)."""
         import torch
-        dev = torch.device("cuda", self.model.engine.device)
+        dev = self.model.engine.torch_device
         if isinstance(audiofeat_batch, torch.Tensor):
             feat = audiofeat_batch.to(device=dev, dtype=torch.float32).contiguous()
         else:                                               # list of (50,384) arrays from a foreign ASR
@@ -145,7 +145,7 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
         import torch
         if not isinstance(pred_frame, torch.Tensor):
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
-                torch.device("cuda", self.model.engine.device))
+                self.model.engine.torch_device)
         h, w = self._frame_hw
         out = np.empty((h, w, 3), dtype=np.uint8)
         self.model.engine.paste_blend(self._aid, int(idx), pred_frame.data_ptr(), out)

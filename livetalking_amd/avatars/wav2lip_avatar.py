@@ -132,7 +132,7 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         if isinstance(audiofeat_batch, torch.Tensor):
             return audiofeat_batch
         arr = np.ascontiguousarray(np.asarray(audiofeat_batch), dtype=np.float32)   # list of (80,16)
-        return torch.from_numpy(arr).to(torch.device("cuda", self.model.engine.device))
+        return torch.from_numpy(arr).to(self.model.engine.torch_device)
 
     def inference_batch(self, index, audiofeat_batch):
         """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for
@@ -151,7 +151,7 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         import torch
         if not isinstance(pred_frame, torch.Tensor):   # a float frame from a foreign inference_batch
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
-                torch.device("cuda", self.model.engine.device))
+                self.model.engine.torch_device)
         h, w = self._frame_hw
         out = np.empty((h, w, 3), dtype=np.uint8)
         self.model.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)

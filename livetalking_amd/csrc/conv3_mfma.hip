@@ -26,6 +26,7 @@
 // A-patch image in LDS, per channel block: [patch pixel][2 x 16 B], the two halves swapped where bit 3 of the
 // pixel slot is set, so the 16-lane groups of ds_read_b128 (32-B lane stride) hit 16 distinct 16-B slots.
 #include "conv_mfma.h"
+#include "tune.h"
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -35,7 +36,17 @@
 #include <type_traits>
 #include <vector>
 
+#ifndef LTK_ABLATE_BUILD
+#define LTK_ABLATE_BUILD 0          // 1: keep the measurement branches (scripts/conv_ablate.py); production kernels carry none
+#endif
+
 namespace ltk {
+
+#if LTK_ABLATE_BUILD
+#define ABL(a, bit) ((a).ablate & (bit))
+#else
+#define ABL(a, bit) 0
+#endif
 
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
@@ -61,8 +72,8 @@ struct K3Args {
     int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
     int nitems;                      // work items (ksplit x pixel tiles x cout tiles); gridDim.x <= nitems
     int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
-    int ablate;                      // measurement only (LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no residual read,
-                                     // 16 no output store, 32 no LDS zero fill
+    int ablate;                      // measurement builds only (make ABLATE=1, knob LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA,
+                                     // 8 no residual read, 16 no output store, 32 no LDS zero fill, 64 no epilogue, 128 epilogue math only
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
 };
 
@@ -125,7 +136,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     const int PHW = a.PH * a.PW;
 
     // ---- zero both A stages once: halo slots outside the image are never written by the DMA
-    if (!(a.ablate & 32)) {
+    if (!ABL(a, 32)) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         for (int i = tid * 16; i < A_BYTES; i += 256 * 16) {
             *reinterpret_cast<uint4*>(smem + i) = z;
@@ -174,13 +185,13 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         unsigned char* const Ab = smem + buf * STAGE;
         unsigned char* const Bb = Ab + A_BYTES;
         const unsigned char* xc = reinterpret_cast<const unsigned char*>(a.x + (size_t)c * NCB * HW16);
-        if (!(a.ablate & 1)) {
+        if (!ABL(a, 1)) {
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
                 if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024);
         }
         const unsigned char* wc = reinterpret_cast<const unsigned char*>(wsrc + (size_t)c * slab32);
-        if (!(a.ablate & 2)) {
+        if (!ABL(a, 2)) {
             unsigned tq = (unsigned)tid;           // opaque: otherwise the per-thread offsets are hoisted as 64-bit
             asm volatile("" : "+v"(tq));           // kernel-lifetime values and spilled (see lane_i above)
 #pragma unroll
@@ -339,9 +350,10 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int cur = (c - c_begin) & 1;
         __syncthreads();                   // vmcnt(0): chunk c landed; every wave left stage cur^1
         if (c + 1 < c_end) stage(c + 1, cur ^ 1);
-        if (!(a.ablate & 4)) compute(cur);
+        if (!ABL(a, 4)) compute(cur);
     }
 
+#if LTK_ABLATE_BUILD
     if (a.ablate & 64) return;             // measurement: no epilogue at all
     if (a.ablate & 128) {                  // measurement: epilogue arithmetic only keeps acc alive
         float t = 0.f;
@@ -354,6 +366,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         if (t == 12345.678f) a.y[0] = (f16)t;
         return;
     }
+#endif
     // ---- epilogue
     const int cout0 = ntile * BN;
     const int HWo = a.HoA * a.WoA;
@@ -405,8 +418,8 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // channel-blocked output.  No LDS round trip (the ds_write_b64 transposes cost more than the MFMAs on the
     // 64-channel layers).
     const int ncb_valid = min(BN / 16, (a.Cout - cout0) >> 4);
-    const bool has_res = a.res != nullptr && !(a.ablate & 8);
-    const bool do_store = !(a.ablate & 16);
+    const bool has_res = a.res != nullptr && !ABL(a, 8);
+    const bool do_store = !ABL(a, 16);
     const int cbo = cout0 >> 4;
     const int HWo16 = HWo * 16;
     const float* const sbase = reinterpret_cast<const float*>(smem + a.lds_scale_off);   // [2][BN] staged in the prologue
@@ -569,6 +582,7 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
     if (G == g && NBT == n && PXW == p && NC8 == c && T == t) return (k3_kernel_t)conv3_kernel<g, n, p, c, t>
     K3CASE(1, 2, 4, 2, 9); K3CASE(1, 2, 2, 2, 9); K3CASE(1, 1, 4, 2, 9); K3CASE(1, 1, 2, 2, 9);
     K3CASE(1, 2, 2, 4, 9); K3CASE(1, 1, 2, 4, 9);
+    K3CASE(1, 2, 1, 2, 9); K3CASE(1, 1, 1, 2, 9); K3CASE(1, 2, 1, 4, 9); K3CASE(1, 1, 1, 4, 9);      // 128-pixel tiles (small maps)
     K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
     K3CASE(1, 4, 2, 4, 1); K3CASE(1, 2, 2, 4, 1); K3CASE(1, 1, 2, 4, 1);
     K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
@@ -658,10 +672,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     // tile selection (does not change any output element's summation order)
     int NBT = (G == 4) ? 1 : ((p.lCout >= 64) ? 2 : 1);
     int PXW = (G == 1 && T == 9 && NC8 == 2 && S == 1) ? 4 : 2;
-    const char* ev_pxw = getenv("LTK_CONV_PXW");      // tuning sweeps only
-    const char* ev_nbt = getenv("LTK_CONV3_NBT");
-    if (ev_pxw && atoi(ev_pxw) == 2) PXW = 2;
-    if (ev_nbt && atoi(ev_nbt) == 1) NBT = 1;
+    const int kn_pxw = knob(K_CONV_PXW), kn_nbt = knob(K_CONV3_NBT);      // tuning sweeps only (0 = heuristic)
+    if (kn_pxw == 2 || (kn_pxw == 1 && G == 1 && T == 9 && S == 1)) PXW = kn_pxw;
+    if (kn_nbt == 1) NBT = 1;
     int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0;
     long long blocks = 0;
     auto geom = [&](int pxw) -> bool {
@@ -685,22 +698,18 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     bool fit = geom(PXW);
     if (PXW == 4) {
         const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
-        static const int pxw4_min = [] { const char* e = getenv("LTK_CONV_PXW4_MIN"); return e ? atoi(e) : 448; }();
-        if (!fit || blocks * nt < pxw4_min) { PXW = 2; fit = geom(PXW); }
+        if (!fit || blocks * nt < knob(K_CONV_PXW4_MIN)) { PXW = 2; fit = geom(PXW); }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
-    if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && !(ev_nbt && atoi(ev_nbt) != 4)) NBT = 4;
+    if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && (kn_nbt == 0 || kn_nbt == 4)) NBT = 4;
     if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128) NBT = 1;
     const int BN = NBT * 32;
     a.n_ntiles = (p.lCout + BN - 1) / BN;
-    const char* ev_split = getenv("LTK_SPLITK");      // 0: never split (batch-size independent summation order)
-    const char* ev_abl = getenv("LTK_ABLATE");
-    const int allow_split = ev_split ? atoi(ev_split) : 1;
-
-    const int ablate = ev_abl ? atoi(ev_abl) : 0;
-    a.ablate = ablate;
-    int ksplit = allow_split ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
+    a.ablate = LTK_ABLATE_BUILD ? knob(K_ABLATE) : 0;
+    // LTK_SPLITK=0: never split (batch-size independent summation order); LTK_KSPLIT=n forces a factor (sweeps)
+    int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
+    if (knob(K_KSPLIT) > 0) ksplit = std::max(1, std::min(std::min(knob(K_KSPLIT), kMaxKSplit), a.nchunks));
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
     }
@@ -732,8 +741,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         configured.push_back((const void*)k);
     }
     a.nitems = (int)nblk;
-    const char* ev_pers = getenv("LTK_CONV_PERSIST");      // 0: one block per item
-    const int persist_blocks = ev_pers ? atoi(ev_pers) : 512;
+    const int persist_blocks = knob(K_CONV_PERSIST);      // 0: one block per item
     const long long grid = (persist_blocks > 0 && nblk > persist_blocks) ? persist_blocks : nblk;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, stream, a);
     HIPCHK3(hipGetLastError());

@@ -27,6 +27,7 @@
 // LDS (dynamic, one array - keeps hipcc from draining vmcnt per k-step):
 //   [2 x A planes][2 x B slab][tap table]
 #include "conv_mfma.h"
+#include "tune.h"
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -405,11 +406,6 @@ static conv_kernel_t pick_kernel(int NC8, int NBT, bool tt9, int mode, int need)
     return nullptr;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 static int ceil_log2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -490,7 +486,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     struct Tap { int ky, kx, dy, dx; };
     std::vector<std::vector<Tap>> phases;
     std::vector<std::pair<int, int>> phase_off;
-    const bool v3_on = env_int("LTK_CONV_V3", 1) != 0;
+    const bool v3_on = knob(K_CONV_V3) != 0;
     const bool is_convT_s2 = transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && out_pad == 1;
     if (v3_on && is_convT_s2 && Cin % 16 == 0) {
         // conv3 merged transposed conv: ONE phase of 9 taps over a 2x2 input neighbourhood, in the tap order the
@@ -531,12 +527,12 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     }
 
     if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 &&
-        ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && env_int("LTK_CONV_V3_S2", 1) &&
+        ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && knob(K_CONV_V3_S2) &&
         // measured (scripts/conv_sweep.py, 16 frames): the 2x-strided LDS operand reads make conv3 slower than the
         // register-staged kernel on the wide, shallow downsamples (16->32 @256^2: 29 vs 18 us); it wins where the
         // K loop is deep and split-K fills the chip (256->512 @16^2: 18 vs 27 us, 512->512 @8^2: 19 vs 46 us).
         // The asymmetric-pad form exists only in conv3.
-        (Cin >= 256 || out_pad == 1 || env_int("LTK_CONV_V3_S2", 1) == 2)) {
+        (Cin >= 256 || out_pad == 1 || knob(K_CONV_V3_S2) == 2)) {
         p->v3 = true; p->v3_G = 1; p->v3_T = 9; p->v3_S = 2;
     }
     if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {
@@ -556,7 +552,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
         NBT = lCout >= 128 ? 4 : (lCout >= 64 ? 2 : 1);
         NC8 = (Cin8 >= 4) ? 4 : 2;
         // tuning overrides (sweeps): LTK_CONV_NBT / LTK_CONV_NC8 apply where legal
-        const int fn = env_int("LTK_CONV_NBT", 0), fc = env_int("LTK_CONV_NC8", 0);
+        const int fn = knob(K_CONV_NBT), fc = knob(K_CONV_NC8);
         if (fn == 1 || fn == 2 || fn == 4) NBT = std::min(NBT, fn);
         if (fc == 2 || (fc == 4 && Cin8 >= 4)) NC8 = fc;
         if (strided || Tmax > 9) { NC8 = 2; NBT = std::min(NBT, 2); }   // large patches: 10 staging items, 2 planes
@@ -568,16 +564,19 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     if (p->v3) {
         // 1x1: 64-channel chunks; wide outputs take 32-channel chunks so that a 128-cout block (conv3_launch) still fits two
         // resident blocks per CU
-        if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && env_int("LTK_GEMM_NC8", 4) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
+        if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && knob(K_GEMM_NC8) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
-        else NC8 = (Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4;
+        else {
+            NC8 = (Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4;
+            if (knob(K_CONV3_NC8) == 2 || (knob(K_CONV3_NC8) == 4 && Cin % 32 == 0)) NC8 = knob(K_CONV3_NC8);
+        }
         if (p->v3_S == 2) NC8 = 2;
         NBT = 2;
     }
     p->NC8 = NC8; p->NBT = NBT;      // NBT here = the widest block the staging registers allow
     p->tt9 = (!transposed && kh == 3 && kw == 3 && NC8 >= 2);
     p->nphase = (int)phases.size();
-    p->mode = env_int("LTK_CONV_MODE", 1);
+    p->mode = knob(K_CONV_MODE);
     const int Tp = (NC8 == 1) ? ((Tmax + 1) / 2 * 2) : Tmax;
     p->Tp = Tp;
     if (!p->v3) {
@@ -723,8 +722,8 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     // tile: TW x TH output pixels x NB images, 256 rows
     int l2w = std::min(5, ceil_log2(a.Wo));
     int l2h = std::min(8 - l2w, ceil_log2(a.Ho));
-    const int forced_nbt = env_int("LTK_CONV_NBT", 0);
-    const int min_blocks = env_int("LTK_CONV_MIN_BLOCKS", 512);
+    const int forced_nbt = knob(K_CONV_NBT);
+    const int min_blocks = knob(K_CONV_MIN_BLOCKS);
     int NBT = std::min(p.NBT, 2);
     if (forced_nbt == 1 || forced_nbt == 2 || forced_nbt == 4) NBT = std::min(p.NBT, forced_nbt);
     const int maxpix = max_a_items(NC8, NBT) * 256 / NC8;

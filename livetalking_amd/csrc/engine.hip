@@ -25,6 +25,7 @@
 #include "misc_kernels.h"
 #include "musetalk.h"
 #include "nn_kernels.h"
+#include "tune.h"
 
 using namespace ltk;
 
@@ -296,7 +297,7 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
     std::vector<float> wfold;
     L->res_folded = false;
     if (d.residual && !d.transposed && d.cin == d.cout && (d.k & 1) && d.sh == 1 && d.sw == 1 && d.pad == d.k / 2 &&
-        getenv("LTK_NO_FOLD_RESIDUAL") == nullptr) {
+        !knob(K_NO_FOLD_RESIDUAL)) {
         bool ok = true;
         for (int c = 0; c < d.cout; ++c) ok = ok && fabsf(sc[c]) >= 1e-3f;
         if (ok) {
@@ -371,7 +372,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             Layer L;
             // the 4x4 "valid" conv on the 4x4 map: a 1x1 conv over the flattened map (needs in_ld % 64 == 0)
             const bool flat = !bl.d.transposed && bl.d.pad == 0 && bl.d.k > 1 && bl.d.k == H && bl.d.k == W &&
-                              bl.d.cin % 64 == 0 && getenv("LTK_NO_FLATTEN") == nullptr;
+                              bl.d.cin % 64 == 0 && !knob(K_NO_FLATTEN);
             if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, flat ? in_ld : 0))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
             if (flat) {
@@ -449,7 +450,7 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // the aux stream beside the face encoder instead of in front of it.
 int run_convs(ltk_engine* e, int nf, hipStream_t s) {
     std::string err;
-    const bool fork = !e->capture && e->aux && getenv("LTK_NO_AUX_STREAM") == nullptr;
+    const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM);
     bool joined = !fork;
     if (fork) {
         CHK(hipEventRecord(e->ev_fork, s));
@@ -629,8 +630,7 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
     CHK(hipSetDevice(e->device));
     int rc = build_program(e, sd, n);
     if (rc) return rc;
-    const char* mb = getenv("LTK_MICROBATCH");
-    e->micro_batch = mb ? atoi(mb) : 0;
+    e->micro_batch = knob(K_MICROBATCH);
     if (e->micro_batch <= 0 || e->micro_batch > max_frames) e->micro_batch = max_frames;
     e->max_frames = max_frames;
     const int arena_frames = e->micro_batch;
@@ -837,6 +837,11 @@ int ltk_debug_capture(ltk_engine* e, int enable) {
     std::lock_guard<std::mutex> g(e->mu);
     e->capture = enable != 0;
     if (!enable) { e->taps.clear(); e->tap_shape.clear(); }
+    return LTK_OK;
+}
+
+int ltk_debug_set_knob(const char* name, int value) {
+    if (knob_set(name, value)) return fail(LTK_E_INVALID, std::string("unknown knob ") + (name ? name : "(null)"));
     return LTK_OK;
 }
 

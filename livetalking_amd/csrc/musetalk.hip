@@ -24,6 +24,7 @@
 
 #include "../../include/ltk.h"
 #include "conv_mfma.h"
+#include "tune.h"
 #include "musetalk.h"
 #include "nn_kernels.h"
 
@@ -350,7 +351,7 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
         for (const std::vector<float>* v : parts) o.insert(o.end(), v->begin(), v->end());
         return o;
     };
-    const bool fuse = !getenv("LTK_MT_NO_QKV_FUSE");      // A/B switch
+    const bool fuse = !knob(K_MT_NO_QKV_FUSE);      // A/B switch
     const bool self = fuse && x.buf == ctx.buf && x.coff == ctx.coff && x.C == ctx.C;
     MtTensor q, k, v, o = g.alloc(Cp, x.H, x.W);
     if (self) {

@@ -1,0 +1,38 @@
+// Tuning / A-B knobs of the engine.  Every knob is an integer read from the environment ONCE per process (first use,
+// normally ltk_engine_create) and kept in a table; the launch path reads the table, never getenv.  Sweep scripts and
+// tests change a knob in-process through ltk_debug_set_knob (include/ltk.h).
+#pragma once
+
+namespace ltk {
+
+enum Knob {
+    K_CONV_V3 = 0,        // LTK_CONV_V3        1: conv3 (LDS-DMA) kernels where they apply
+    K_CONV_V3_S2,         // LTK_CONV_V3_S2     1: conv3 stride-2 for deep layers, 2: for all, 0: never
+    K_CONV_NBT,           // LTK_CONV_NBT       conv_mfma: cap of 32-cout subtiles per block (0 = plan's choice)
+    K_CONV_NC8,           // LTK_CONV_NC8       conv_mfma: channel planes per chunk (0 = plan's choice)
+    K_GEMM_NC8,           // LTK_GEMM_NC8       conv3 1x1: 4 = 32-channel chunks for wide outputs
+    K_CONV_MODE,          // LTK_CONV_MODE      conv_mfma: 0 double-buffered LDS, 1 single buffer + register prefetch
+    K_CONV_MIN_BLOCKS,    // LTK_CONV_MIN_BLOCKS conv_mfma: narrow the block until the grid has this many blocks
+    K_CONV_PXW,           // LTK_CONV_PXW       conv3: force 2 (256-pixel tiles); 0 = heuristic
+    K_CONV3_NBT,          // LTK_CONV3_NBT      conv3: force 32-cout subtiles per block (1, 2, 4); 0 = heuristic
+    K_CONV_PXW4_MIN,      // LTK_CONV_PXW4_MIN  conv3: 512-pixel tiles only when they still give this many items
+    K_SPLITK,             // LTK_SPLITK         0: never split the channel loop (batch-size independent summation order)
+    K_KSPLIT,             // LTK_KSPLIT         conv3: force this split factor (sweeps); 0 = heuristic
+    K_CONV_PERSIST,       // LTK_CONV_PERSIST   conv3: resident grid size above which a launch walks items persistently
+    K_NO_FOLD_RESIDUAL,   // LTK_NO_FOLD_RESIDUAL 1: keep the residual read instead of folding it into the centre tap
+    K_NO_FLATTEN,         // LTK_NO_FLATTEN     1: run the 4x4 valid conv as a conv, not as a flattened 1x1
+    K_NO_AUX_STREAM,      // LTK_NO_AUX_STREAM  1: audio encoder on the compute stream
+    K_MICROBATCH,         // LTK_MICROBATCH     wav2lip frames per arena pass (0 = min(max_frames, 256))
+    K_MT_NO_QKV_FUSE,     // LTK_MT_NO_QKV_FUSE 1: separate q / k / v projection launches
+    K_SPLITK_FUSED,       // LTK_SPLITK_FUSED   1: the last-arriving block of a split-K group reduces the slabs (no finish launch)
+    K_HEAD_FUSED,         // LTK_HEAD_FUSED     1: output_block conv 80->32 + 1x1 head + sigmoid in one launch
+    K_CONV3_NC8,          // LTK_CONV3_NC8      conv3 3x3: channel planes per chunk (2 = 16 channels, 4 = 32); 0 = by map size
+    K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
+    K_COUNT
+};
+
+int knob(Knob k);
+// returns 0, or -1 when `name` (without the LTK_ prefix or with it) is not a knob
+int knob_set(const char* name, int value);
+
+}  // namespace ltk

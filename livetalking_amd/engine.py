@@ -51,6 +51,12 @@ class Engine:
     def sync(self):
         _lib.check(self._lib.ltk_engine_sync(self._h))
 
+    @property
+    def torch_device(self):
+        """Where the plugin allocates the device buffers it hands to this engine."""
+        import torch
+        return torch.device("cuda", self.device)
+
     # ------------------------------------------------------------------ model
     @staticmethod
     def _named_tensors(state_dict: Dict[str, object]):
@@ -274,6 +280,12 @@ class Engine:
         pred = np.empty((B, 3, 256, 256), dtype=np.float32)
         _lib.check(self._lib.ltk_wav2lip_forward_host(self._h, mel.ctypes.data, face6.ctypes.data, B, pred.ctypes.data))
         return pred
+
+    @staticmethod
+    def set_knob(name: str, value: int):
+        """Process-wide tuning knob (csrc/tune.h); sweeps and A/B tests only."""
+        lib = _lib.load()
+        _lib.check(lib.ltk_debug_set_knob(name.encode(), int(value)))
 
     def debug_capture(self, enable: bool):
         _lib.check(self._lib.ltk_debug_capture(self._h, 1 if enable else 0))

@@ -4,7 +4,8 @@ Deployed as a drop-in, `avatars.base_avatar`, `avatars.
 audio_features.base_asr`, `registry` and `utils.image` are the reference's own,
 unmodified modules and are used as they are.  Outside the reference tree (unit
 tests, bench, the GPU box) minimal stand-ins with the same names, fields and
-queue protocol are used so the plugin can be driven headless:
+queue protocol can be used so the plugin can be driven headless - only when
+LTK_ALLOW_STANDIN=1 is set; otherwise the import fails loudly:
 
   AudioFrameData   avatars/base_avatar.py:57-61
   BaseAvatar       avatars/base_avatar.py:64-124 (only the fields the plugin reads)
@@ -21,13 +22,22 @@ from typing import Any, Dict
 
 import numpy as np
 
+import os
+
 try:  # drop-in: the reference tree is on sys.path
     from avatars.base_avatar import AudioFrameData, BaseAvatar  # type: ignore
     from avatars.audio_features.base_asr import BaseASR  # type: ignore
     from registry import register  # type: ignore
     from utils.image import mirror_index  # type: ignore
     USING_REFERENCE_HOST = True
-except Exception:  # noqa: BLE001 - any import problem means "not inside the reference tree"
+except ImportError as _ex:  # not inside a LiveTalking checkout (anything else - a broken checkout - propagates)
+    # A deployment that reaches this branch would run sessions without TTS or stream-out: refuse unless the
+    # caller asked for the headless stand-ins (tests, bench, the GPU box set LTK_ALLOW_STANDIN=1).
+    if os.environ.get("LTK_ALLOW_STANDIN", "0") in ("", "0"):
+        raise ImportError(
+            "livetalking_amd: the reference host modules (avatars.base_avatar, avatars.audio_features.base_asr, registry, "
+            "utils.image) are not importable - start from the LiveTalking checkout (scripts/run_amd.py) or set "
+            "LTK_ALLOW_STANDIN=1 for the headless stand-ins (" + str(_ex) + ")") from _ex
     USING_REFERENCE_HOST = False
 
     @dataclass

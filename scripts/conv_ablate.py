@@ -25,7 +25,7 @@ MASKS = [int(m) for m in os.environ.get("ABLATE_MASKS", "0,3,4,24,27,31,63,95,12
 
 def main():
     eng = Engine(0)
-    os.environ["LTK_CONV_V3"] = "1"
+    Engine.set_knob("CONV_V3", 1)          # needs the measurement build: make -C livetalking_amd/csrc clean all ABLATE=1
     print(f"frames={N}; us per launch by LTK_ABLATE mask")
     print("layer".ljust(16) + "".join(f"{m:>8d}" for m in MASKS))
     for (name, H, W, Cin, Cout, k, s, p, tr, op, res) in LAYERS:
@@ -38,15 +38,12 @@ def main():
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
         for m in MASKS:
-            if os.environ.get("ABLATE_STAGGER"):
-                os.environ["LTK_STAGGER"] = str(m)
-                m = 0
-            os.environ["LTK_ABLATE"] = str(m)
+            Engine.set_knob("ABLATE", m)
             ms = eng.conv2d_f16(x.data_ptr(), N, H, W, Cin, w, Cout, k, s, p, tr, op, sc, sf,
                                 x.data_ptr() if res else 0, True, y.data_ptr(), iters=10)
             row += f"{ms*1e3:8.0f}"
         print(row, flush=True)
-    os.environ["LTK_ABLATE"] = "0"
+    Engine.set_knob("ABLATE", 0)
     eng.close()
 
 

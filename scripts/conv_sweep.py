@@ -83,15 +83,15 @@ def main():
         sf = np.zeros(Cout, np.float32)
         row = name.ljust(16)
         for v3, mode, nbt, nc8 in variants:
-            os.environ.pop("LTK_CONV_PXW", None); os.environ.pop("LTK_CONV3_NBT", None)
+            Engine.set_knob("CONV_PXW", 0); Engine.set_knob("CONV3_NBT", 0)
             if isinstance(v3, str):
-                if "pxw2" in v3: os.environ["LTK_CONV_PXW"] = "2"
-                if "nbt1" in v3: os.environ["LTK_CONV3_NBT"] = "1"
+                if "pxw2" in v3: Engine.set_knob("CONV_PXW", 2)
+                if "nbt1" in v3: Engine.set_knob("CONV3_NBT", 1)
                 v3 = 1
-            os.environ["LTK_CONV_V3"] = str(v3)
-            os.environ["LTK_CONV_MODE"] = str(mode)
-            os.environ["LTK_CONV_NBT"] = str(nbt)
-            os.environ["LTK_CONV_NC8"] = str(nc8)
+            Engine.set_knob("CONV_V3", v3)
+            Engine.set_knob("CONV_MODE", mode)
+            Engine.set_knob("CONV_NBT", nbt)
+            Engine.set_knob("CONV_NC8", nc8)
             try:
                 ms = eng.conv2d_f16(x.data_ptr(), N, H, W, Cin, w, Cout, k, s, p, tr, op, sc, sf,
                                     x.data_ptr() if res else 0, True, y.data_ptr(), iters=10)

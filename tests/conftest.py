@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("LTK_ALLOW_STANDIN", "1")   # headless stand-ins of the reference's base classes (livetalking_amd/hostshim.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -60,8 +60,8 @@ def _pair(v):
 
 
 def run_case(eng, case, seed, v3=1):
-    import os
-    os.environ["LTK_CONV_V3"] = str(v3)   # read when the layer plan is created
+    from livetalking_amd.engine import Engine
+    Engine.set_knob("CONV_V3", v3)        # read when the layer plan is created
     N, H, W, Cin, Cout, k, stride, pad, transposed, out_pad, residual = case
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g).half().float()
@@ -143,6 +143,6 @@ def test_conv_first_generation_kernel(engine):
     try:
         report = _run_all(engine, CASES, 0)
     finally:
-        import os
-        os.environ["LTK_CONV_V3"] = "1"
+        from livetalking_amd.engine import Engine
+        Engine.set_knob("CONV_V3", 1)
     assert not report, "\n".join(report)

@@ -106,13 +106,13 @@ def test_infer_batching_invariance(engine, golden_dir):
         assert int(d.max()) <= 2 and psnr_u8(got.cpu().numpy(), ref.cpu().numpy()) >= 55.0
     # LTK_SPLITK=0: no split-K anywhere -> every output element has ONE summation order whatever the
     # launch's frame count, and coalescing is bit-exact
-    import os
-    os.environ["LTK_SPLITK"] = "0"
+    from livetalking_amd.engine import Engine
+    Engine.set_knob("SPLITK", 0)
     try:
         engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr(), a.data_ptr())])
         engine.wav2lip_infer([(aid, 7, 3, mel.data_ptr(), b.data_ptr())])
         engine.wav2lip_infer([(aid, 3, 4, mel.data_ptr(), a2.data_ptr()), (aid, 7, 3, mel.data_ptr(), b2.data_ptr())])
     finally:
-        del os.environ["LTK_SPLITK"]
+        Engine.set_knob("SPLITK", 1)
     assert torch.equal(a2, a) and torch.equal(b2, b)
     engine.release_avatar(aid)
