@@ -45,32 +45,7 @@ sys.path.insert(0, REPO)
 from oracle import mel_oracle, paste_oracle, plugin_oracle, synth, wav2lip_oracle  # noqa: E402
 
 
-def _stub(name, **attrs):
-    m = types.ModuleType(name)
-    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
-    for k, v in attrs.items():
-        setattr(m, k, v)
-    sys.modules[name] = m
-    return m
-
-
-def install_stubs():
-    import transformers.audio_utils  # noqa: F401  (import before stubbing)
-
-    def cv2_resize(src, dsize, *a, **k):
-        return paste_oracle.resize_linear_u8(np.ascontiguousarray(src), dsize)
-
-    _stub("cv2", resize=cv2_resize, putText=lambda *a, **k: None, FONT_HERSHEY_SIMPLEX=0,
-          imread=lambda p: None)
-    _stub("av", AudioFrame=object, VideoFrame=object)
-    _stub("resampy")
-    _stub("soundfile")
-    _stub("edge_tts")
-    filters = _stub("librosa.filters",
-                    mel=lambda sr, n_fft, n_mels, fmin, fmax: mel_oracle.mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
-    _stub("librosa",
-          stft=lambda y, n_fft, hop_length, win_length: mel_oracle.stft(y, n_fft, hop_length, win_length),
-          filters=filters)
+from oracle.ref_loop import install_stubs  # noqa: E402  (stub modules for the reference's third-party imports)
 
 
 def sample_positions(shape, n=64, seed=99):

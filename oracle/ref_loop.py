@@ -84,12 +84,16 @@ class FakePlayer:
         self.audio = []
         self.events = []
         self.order = []          # 'v' / 'a' in arrival order
+        self.bad = []            # frames a real player could not have taken
         self._lock = threading.Lock()
 
     def push_video(self, frame):
         with self._lock:
-            assert isinstance(frame, np.ndarray) and frame.dtype == np.uint8 and frame.ndim == 3 and frame.flags["C_CONTIGUOUS"]
-            self.video.append(frame.copy())
+            # what VideoFrame.from_ndarray(frame, "bgr24") needs (server/webrtc.py:190-193)
+            if not (isinstance(frame, np.ndarray) and frame.dtype == np.uint8 and frame.ndim == 3 and frame.shape[2] == 3
+                    and frame.flags["C_CONTIGUOUS"]):
+                self.bad.append((len(self.video), type(frame).__name__, getattr(frame, "dtype", None), getattr(frame, "shape", None)))
+            self.video.append(np.array(frame, copy=True))
             self.order.append("v")
 
     def push_audio(self, frame, eventpoint=None):
@@ -153,6 +157,8 @@ def run_session(session, audio: np.ndarray, n_steps: int, batch_size: int, timeo
     silence), start the reference's render thread, wait until n_steps*B (+ tail_steps*B silent) frames arrived, stop."""
     player = FakePlayer()
     session.output._player = player                     # what HumanPlayer.__init__ does (server/webrtc.py:186-188)
+    # asr.warm_up() (base_asr.py:76-82) ran in the session constructor on an empty queue: its l+r chunks were timeout
+    # silence.  Speech for n_steps steps plus the r look-ahead chunks the last step's windows reach into.
     n_chunks = n_steps * 2 * batch_size
     assert len(audio) >= n_chunks * 320
     for c in range(n_chunks):
@@ -166,15 +172,20 @@ def run_session(session, audio: np.ndarray, n_steps: int, batch_size: int, timeo
         time.sleep(0.01)
     quit_event.set()
     t.join(timeout=30)
-    alive = [th.name for th in threading.enumerate() if th is not threading.current_thread() and th.is_alive()
-             and th.name != "ltk-coalesce" and not th.daemon]
+    def others():
+        return [th.name for th in threading.enumerate() if th is not threading.current_thread() and th.is_alive()
+                and th.name != "ltk-coalesce" and not th.daemon]
+    t1 = time.time()
+    while others() and time.time() - t1 < 5.0:      # the TTS thread polls its queue with a 1 s timeout (tts/base_tts.py:45)
+        time.sleep(0.05)
+    alive = others()
     return player, {"render_joined": not t.is_alive(), "leftover_threads": alive, "wall_s": time.time() - t0}
 
 
 def summarize(player: FakePlayer, coords, n_speech_frames: int, sub: int = 4):
     """Compact, comparable record of what a session delivered."""
     v = player.video
-    out = {"n_video": len(v), "n_audio": len(player.audio),
+    out = {"n_video": len(v), "n_audio": len(player.audio), "n_bad_frames": len(player.bad),
            "order": "".join(player.order[: 3 * n_speech_frames])}
     crc_full, outside_crc, box_sub = [], [], []
     for i, f in enumerate(v[:n_speech_frames]):
@@ -250,10 +261,12 @@ def main():
     ap.add_argument("--egress", default="", help="plugin modes: opt.egress (bgr24 / i420) -> DeviceEgressMixin.process_frames")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)        # enter_reference() moves to a scratch CWD
 
     from oracle import synth
     sd_np = synth.wav2lip_state_dict(1234) if args.net == "wav2lip" else None
-    avatar = synth.wav2lip_avatar(n_frames=args.frames, full_hw=(360, 640), box=160, seed=0)
+    fr, fa, co = synth.wav2lip_avatar(n_frames=args.frames, full_hw=(360, 640), box=160, seed=0)
+    avatar = ([np.ascontiguousarray(f) for f in fr], [np.ascontiguousarray(f) for f in fa], co)   # as cv2.imread returns them
     audio = synth.synthetic_audio(4.0 + 0.64 * args.steps)
     extra = {"egress": args.egress} if args.egress else None
     session, model = build_session(args.mode, os.path.abspath(args.ref), args.net, args.batch, avatar, sd_np, extra)
