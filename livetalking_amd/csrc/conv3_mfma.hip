@@ -26,6 +26,7 @@
 // A-patch image in LDS, per channel block: [patch pixel][2 x 16 B], the two halves swapped where bit 3 of the
 // pixel slot is set, so the 16-lane groups of ds_read_b128 (32-B lane stride) hit 16 distinct 16-B slots.
 #include "conv_mfma.h"
+#include "misc_kernels.h"
 #include "tune.h"
 
 #include <hip/hip_fp16.h>
@@ -99,8 +100,17 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 // v_mfma_f32_32x32x16_fp8_fp8 (bytes 0-7, then 8-15): half the LDS / DMA / HBM bytes per MAC at the same MFMA rate.
 // The host packs the fp8 weights as pairs in 16-bit units (conv_plan_create, quant = 1) so that byte i of an A
 // fragment and byte i of a B fragment are the same input channel.
-template <int G, int NBT, int PXW, int NC8, int T, int S, int Q>
-__device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem) {
+// HEAD = 1 (output_block of the Wav2Lip generator, wav2lip_v2.py:89-91): the block's 32 output channels do not go to
+// memory; the epilogue applies the 1x1 conv 32 -> 3 + bias, the sigmoid, *255 and the uint8 truncation of
+// wav2lip_avatar.py:138,145 on the fp32 accumulators and writes the 3 bytes of every pixel to its frame's own output.
+struct HeadArgs {
+    const float* w;                  // [3][32] weights, then [3] bias (fp32)
+    OutPtrs outs;                    // per frame: uint8 [256][256][3]
+};
+
+template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0>
+__device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem, const HeadArgs* hd = nullptr) {
+    static_assert(HEAD == 0 || (G == 1 && NBT == 1 && T == 9 && S == 1 && Q == 0), "fused head: the 3x3 32-cout output conv");
     constexpr int BN = NBT * 32;
     constexpr int MAXA = k3_maxa(PXW, NC8, S, T);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
@@ -386,6 +396,48 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         return oy * a.WoA + ox;
     };
 
+    if constexpr (HEAD) {
+        // lane (l31, hh) holds channels 8*q4 + 4*hh + r (q4, r = 0..3) of pixel l31 of each subtile: 16 of the 32 channels;
+        // the partner lane (l31, hh^1) holds the other 16
+        const float* const sb = reinterpret_cast<const float*>(smem + a.lds_scale_off);   // [2][32] staged in the prologue
+        float p[PXW][3];
+#pragma unroll
+        for (int j = 0; j < PXW; ++j) p[j][0] = p[j][1] = p[j][2] = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {         // four channels at a time: the 80 scale/shift/weight values never live at once
+            const int cl = 8 * q4 + 4 * hh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sb + cl), sf = *reinterpret_cast<const f32x4*>(sb + 32 + cl);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(hd->w + cl), w1 = *reinterpret_cast<const f32x4*>(hd->w + 32 + cl),
+                        w2 = *reinterpret_cast<const f32x4*>(hd->w + 64 + cl);
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = __builtin_amdgcn_fmed3f(acc[0][0][j][4 * q4 + r] * sc[r] + sf[r], 0.f, 65504.f);   // BN + ReLU (conv.py:12-19)
+                    p[j][0] += v * w0[r]; p[j][1] += v * w1[r]; p[j][2] += v * w2[r];
+                }
+        }
+        const float b0 = hd->w[96], b1 = hd->w[97], b2 = hd->w[98];
+#pragma unroll
+        for (int j = 0; j < PXW; ++j) {
+            bool ok;
+            int n;
+            const int opx = out_px(j, 0, &n, &ok);
+            const float t0 = p[j][0] + __shfl_xor(p[j][0], 32), t1 = p[j][1] + __shfl_xor(p[j][1], 32),
+                        t2 = p[j][2] + __shfl_xor(p[j][2], 32);
+            const float s0 = 1.f / (1.f + __expf(-(t0 + b0)));
+            const float s1 = 1.f / (1.f + __expf(-(t1 + b1)));
+            const float s2 = 1.f / (1.f + __expf(-(t2 + b2)));
+            unsigned char* const o = ok ? hd->outs.p[n] : nullptr;
+            if (o && hh == 0) {      // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
+                unsigned char* q = o + (size_t)opx * 3;
+                q[0] = (unsigned char)(unsigned)(s0 * 255.f);
+                q[1] = (unsigned char)(unsigned)(s1 * 255.f);
+                q[2] = (unsigned char)(unsigned)(s2 * 255.f);
+            }
+        }
+        return;
+    }
     if (a.partial) {
         // split-K: raw fp32 partial sums, slab ks; lane holds 4 consecutive couts per register group
 #pragma unroll
@@ -532,6 +584,19 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     }
 }
 
+template <int PXW>
+__global__ __launch_bounds__(256, 2) void conv3_head_kernel(const K3Args a, const HeadArgs h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    for (int item = first; item < a.nitems; item += nblk) {
+        if (item != first) __syncthreads();
+        conv3_item<1, 1, PXW, 2, 9, 1, 0, 1>(a, item, smem, &h);
+    }
+}
+
 // split-K finish: y = relu((sum_s partial[s]) * scale + shift + res) -> fp16.  One thread = one pixel x 8 couts;
 // consecutive threads = the two halves of a channel block, then consecutive pixels.
 __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restrict__ partial, int ksplit, long long Mtot, int HWo,
@@ -592,7 +657,7 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
 
 static k3_kernel_t k3_pick_q8(int NBT, int PXW, int NC8) {     // fp8 operands: 3x3 stride 1
 #define K3Q(n, p, c) if (NBT == n && PXW == p && NC8 == c) return (k3_kernel_t)conv3_kernel<1, n, p, c, 9, 1, 1>
-    K3Q(2, 4, 2); K3Q(2, 2, 2); K3Q(1, 4, 2); K3Q(1, 2, 2); K3Q(2, 2, 4); K3Q(1, 2, 4);
+    K3Q(2, 4, 2); K3Q(2, 2, 2); K3Q(1, 4, 2); K3Q(1, 2, 2); K3Q(2, 2, 4); K3Q(1, 2, 4); K3Q(2, 1, 2); K3Q(1, 1, 2);
 #undef K3Q
     return nullptr;
 }
@@ -616,12 +681,23 @@ static unsigned magic_u16_(int d) { return (unsigned)((0x100000000ull + (unsigne
 
 constexpr int kMaxKSplit = 32;
 
-// Split-K factor of a launch with `base` blocks and `nchunks` channel chunks: only under-filled grids are
-// split, every split keeps >= 2 chunks.  Depends on the batch size through `base`: outputs of launches with
-// different splits differ by fp32 summation order only.
-static int k3_ksplit(long long base, int nchunks) {
-    if (base >= 200 || nchunks < 4) return 1;
-    int s = (int)((256 + base - 1) / base);
+// Split-K factor of a launch with `base` items and `nchunks` channel chunks: only under-filled grids are split, every
+// split keeps >= 2 chunks.  Depends on the batch size through `base`: outputs of launches with different splits
+// differ by fp32 summation order only.  `cap` > 0 (3x3 / transposed / strided layers): split only below 128 items,
+// towards 256 items, at most `cap` ways -- measured (profiles/r02_conv_sweep.txt): a second split of a 192-item
+// transposed conv costs 55.7 us against 41.9 unsplit (the fp32 slabs + finish launch outweigh the fill), while 16..64
+// item launches on 4^2 / 8^2 maps are 15-25 % faster at 4 (conv) / 4-8 (transposed) splits.  cap == 0 (1x1 layers on
+// 1x1 maps, K up to 8192): fill the chip.
+static int k3_ksplit(long long base, int nchunks, int cap) {
+    if (nchunks < 4) return 1;
+    int s;
+    if (cap > 0) {
+        if (base >= 128) return 1;
+        s = std::min(cap, (int)((256 + base - 1) / base));
+    } else {
+        if (base >= 200) return 1;
+        s = (int)((256 + base - 1) / base);
+    }
     s = std::min(s, std::min(nchunks / 2, kMaxKSplit));
     return std::max(s, 1);
 }
@@ -695,20 +771,38 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
         return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S, T) * 256 && npix < 32768;
     };
-    bool fit = geom(PXW);
-    if (PXW == 4) {
-        const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
-        if (!fit || blocks * nt < knob(K_CONV_PXW4_MIN)) { PXW = 2; fit = geom(PXW); }
+    bool fit;
+    if (G == 1 && T == 9 && S == 1 && kn_pxw == 0 && kn_nbt == 0) {
+        // 3x3 stride 1: the largest tile that still gives the chip ~1.5 items per CU.  Measured per layer and frame count
+        // (scripts/conv_sweep2.py, profiles/r02_conv_sweep.txt): with fewer items a launch runs one wave per SIMD and
+        // cannot hide its own DMA latency -- at 16 frames 128 ch @32^2 takes 22.8 us as 128 items of 256 px x 64 ch and
+        // 10.7 us as 512 items of 128 px x 32 ch -- while smaller tiles than needed re-read the weight slab for nothing.
+        static const int cand[6][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};      // {PXW, NBT}
+        fit = false;
+        for (int ci = 0; ci < 6; ++ci) {
+            const int pxw = cand[ci][0], nbt = cand[ci][1];
+            // 512 px x 32 ch only for the layers that have no more than 32 output channels
+            if ((pxw == 4 && NC8 != 2) || (nbt == 2 && p.lCout < 64) || (pxw == 4 && nbt == 1 && p.lCout >= 64)) continue;
+            if (!geom(pxw)) continue;
+            fit = true; PXW = pxw; NBT = nbt;
+            if (blocks * ((p.lCout + 32 * nbt - 1) / (32 * nbt)) >= 384) break;
+        }
+    } else {
+        fit = geom(PXW);
+        if (PXW == 4) {
+            const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
+            if (!fit || blocks * nt < knob(K_CONV_PXW4_MIN)) { PXW = 2; fit = geom(PXW); }
+        }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
     if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && (kn_nbt == 0 || kn_nbt == 4)) NBT = 4;
-    if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128) NBT = 1;
+    if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128 && !(G == 1 && T == 9 && S == 1)) NBT = 1;
     const int BN = NBT * 32;
     a.n_ntiles = (p.lCout + BN - 1) / BN;
     a.ablate = LTK_ABLATE_BUILD ? knob(K_ABLATE) : 0;
     // LTK_SPLITK=0: never split (batch-size independent summation order); LTK_KSPLIT=n forces a factor (sweeps)
-    int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks) : 1;
+    int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks, T == 1 ? 0 : (G == 4 ? 8 : 4)) : 1;
     if (knob(K_KSPLIT) > 0) ksplit = std::max(1, std::min(std::min(knob(K_KSPLIT), kMaxKSplit), a.nchunks));
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
@@ -731,6 +825,11 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     if (T != 1) lds += 2 * BN * sizeof(float);
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
     if (p.q8 && !(G == 1 && T == 9 && S == 1)) { if (err) *err = "conv3: fp8 operands are implemented for 3x3 stride-1 convs"; return -1; }
+    const bool head = io.head_w != nullptr && io.head_outs != nullptr;
+    if (head && !(G == 1 && T == 9 && S == 1 && !p.q8 && NC8 == 2 && NBT == 1 && p.lCout == 32 && (PXW == 4 || PXW == 2) && ksplit == 1)) {
+        if (err) *err = "conv3: fused head needs the 3x3 stride-1 32-cout configuration";
+        return -1;
+    }
     k3_kernel_t k = p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
@@ -743,6 +842,20 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     a.nitems = (int)nblk;
     const int persist_blocks = knob(K_CONV_PERSIST);      // 0: one block per item
     const long long grid = (persist_blocks > 0 && nblk > persist_blocks) ? persist_blocks : nblk;
+    if (head) {
+        typedef void (*k3_head_t)(const K3Args, const HeadArgs);
+        const k3_head_t kh = PXW == 4 ? (k3_head_t)conv3_head_kernel<4> : (k3_head_t)conv3_head_kernel<2>;
+        if (std::find(configured.begin(), configured.end(), (const void*)kh) == configured.end()) {
+            HIPCHK3(hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured.push_back((const void*)kh);
+        }
+        HeadArgs h;
+        h.w = io.head_w;
+        h.outs = *reinterpret_cast<const OutPtrs*>(io.head_outs);
+        hipLaunchKernelGGL(kh, dim3((unsigned)grid), dim3(256), lds, stream, a, h);
+        HIPCHK3(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, stream, a);
     HIPCHK3(hipGetLastError());
     if (ksplit > 1) {

@@ -448,7 +448,9 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // Enqueue the 54 conv/convT layers for frames [0, nf) of the arena on `s`.  The audio encoder has no
 // dependency on the face encoder until decoder block 0 (wav2lip_v2.py:132-142): its 13 small launches run on
 // the aux stream beside the face encoder instead of in front of it.
-int run_convs(ltk_engine* e, int nf, hipStream_t s) {
+// `head_outs` != nullptr: the last layer (output_block.0) also applies the 1x1 head + sigmoid and writes the uint8 frames
+// (one launch and one 4 MB/frame round trip of the 32-channel map less); the caller then skips launch_head.
+int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr) {
     std::string err;
     const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM);
     bool joined = !fork;
@@ -485,6 +487,7 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s) {
         io.relu = 1;
         io.partial = on_aux ? e->d_partial_aux : e->d_partial;
         io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;
+        if (head_outs && Lp == &e->layers.back()) { io.head_w = e->d_head; io.head_outs = head_outs; }
         int rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
         if (e->capture) {
@@ -712,10 +715,14 @@ static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mel
     if (faces) launch_pack_faces(*faces, nf, e->buf[B_X0], s);
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
     launch_pack_mel(*mels, nf, e->buf[B_MEL], s);
-    int rc = run_convs(e, nf, s);
+    // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
+    const bool fused = outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
+    int rc = run_convs(e, nf, s, fused ? outs : nullptr);
     if (rc) return rc;
-    launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, outs, d_pred_f32, s);
-    CHK(hipGetLastError());
+    if (!fused) {
+        launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, outs, d_pred_f32, s);
+        CHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -865,9 +872,19 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
     CHK(hipEventCreate(&t1));
+    // the conv stack as ltk_wav2lip_infer runs it: with the output head fused into the last conv (knob HEAD_FUSED), frames
+    // going to a scratch buffer
+    const int mbs = std::min(e->micro_batch, kPackMaxFrames);
+    uint8_t* d_frames = nullptr;
+    OutPtrs op;
+    const bool fused = knob(K_HEAD_FUSED) != 0;
+    if (fused) {
+        CHK(hipMalloc((void**)&d_frames, (size_t)std::min(mbs, frames) * 65536 * 3));
+        for (int i = 0; i < kPackMaxFrames; ++i) op.p[i] = i < std::min(mbs, frames) ? d_frames + (size_t)i * 65536 * 3 : nullptr;
+    }
     auto pass = [&]() -> int {   // the same micro-batch schedule ltk_wav2lip_infer uses
         int rc = 0;
-        for (int f0 = 0; f0 < frames && !rc; f0 += e->micro_batch) rc = run_convs(e, std::min(e->micro_batch, frames - f0), e->compute);
+        for (int f0 = 0; f0 < frames && !rc; f0 += mbs) rc = run_convs(e, std::min(mbs, frames - f0), e->compute, fused ? &op : nullptr);
         return rc;
     };
     int rc = pass();  // warm
@@ -880,8 +897,9 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     float ms = 0.f;
     CHK(hipEventElapsedTime(&ms, t0, t1));
     *ms_per_pass = ms / iters;
-    if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - 32.0 * 3 * 65536) * frames;
+    if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - (fused ? 0.0 : 32.0 * 3 * 65536)) * frames;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    if (d_frames) (void)hipFree(d_frames);
     return LTK_OK;
 }
 

@@ -58,6 +58,7 @@ class FakeEngine:
     """Stands in for the HIP engine: records calls, fills nothing."""
     device = 0
     max_frames = 64
+    torch_device = "cpu"
 
     def __init__(self):
         self.mel_calls, self.infer_calls = [], []
