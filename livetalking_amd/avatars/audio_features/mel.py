@@ -39,7 +39,7 @@ class MelASR(BaseASR):
     def __init__(self, opt, parent=None, engine=None):
         super().__init__(opt, parent)
         if engine is None:
-            engine = parent.model.engine
+            engine = getattr(parent, "engine", None) or parent.model.engine
         self.engine = engine
         import torch  # device buffers only
         self._torch = torch

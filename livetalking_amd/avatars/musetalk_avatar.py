@@ -18,62 +18,118 @@ import glob
 import os
 import pickle
 import threading
+import weakref
 
 import numpy as np
 
 from ..egress import SRC_MUSETALK, DeviceEgressMixin
 from ..engine import Engine
 from ..hostshim import BaseAvatar, register
+from ..scheduler import get_scheduler
+from ..sharding import EnginePool, visible_devices
 from .audio_features.whisper import Audio2Feature, WhisperASR
 
 
 class MuseTalkModel:
-    """Opaque `model` object (the reference's tuple vae, unet, pe, timesteps, audio_processor)."""
+    """Opaque `model` object (the reference's tuple vae, unet, pe, timesteps, audio_processor).  One engine + Whisper
+    encoder per GPU (sharding.EnginePool); a session is pinned to one of them when it is constructed."""
 
-    def __init__(self, engine: Engine, audio_processor: Audio2Feature):
-        self.engine = engine
-        self.audio_processor = audio_processor
+    def __init__(self, engine_or_pool, audio_processors):
+        if isinstance(engine_or_pool, EnginePool):
+            self.pool = engine_or_pool
+        else:
+            self.pool = EnginePool([getattr(engine_or_pool, "device", 0)], lambda d: engine_or_pool)
+        self.engines = self.pool.engines
+        self.audio_processors = audio_processors if isinstance(audio_processors, (list, tuple)) else [audio_processors]
         self._avatars = {}
         self._lock = threading.Lock()
 
-    def avatar_id(self, avatar) -> int:
+    @property
+    def engine(self) -> Engine:
+        return self.engines[0]
+
+    @property
+    def audio_processor(self) -> Audio2Feature:
+        return self.audio_processors[0]
+
+    def place(self, session) -> int:
+        slot = self.pool.place(id(session))
+        weakref.finalize(session, self.pool.release, id(session))
+        return slot
+
+    def avatar_id(self, avatar, slot: int = 0) -> int:
         frame_list, mask_list, coord_list, mask_coords_list, latent_list = avatar
-        key = id(latent_list)
+        key = (id(latent_list), slot)
         with self._lock:
             aid = self._avatars.get(key)
             if aid is None:
-                aid = self.engine.register_musetalk_avatar(latent_list, frame_list, coord_list, mask_list, mask_coords_list)
+                aid = self.engines[slot].register_musetalk_avatar(latent_list, frame_list, coord_list, mask_list, mask_coords_list)
                 self._avatars[key] = aid
             return aid
 
 
-def _device_index() -> int:
-    return int(os.environ.get("LTK_DEVICE", "0"))
+# AutoencoderKL checkpoints published before diffusers 0.13 (sd-vae-ft-mse among them) store the mid-block attention under
+# the old AttentionBlock names; AutoencoderKL.from_pretrained renames them on load (diffusers
+# ModelMixin._convert_deprecated_attention_blocks), which is why the reference (vae.py:24) never sees them.  The engine
+# looks tensors up by the current names, so the same renaming happens here.
+_DEPRECATED_ATTN = (("query", "to_q"), ("key", "to_k"), ("value", "to_v"), ("proj_attn", "to_out.0"))
+
+
+def convert_deprecated_vae_attention(sd: dict) -> dict:
+    out = {}
+    for k, v in sd.items():
+        nk = k
+        if ".attentions." in k:
+            for old, new in _DEPRECATED_ATTN:
+                for leaf in ("weight", "bias"):
+                    if k.endswith(f".{old}.{leaf}"):
+                        nk = k[: -len(f"{old}.{leaf}")] + f"{new}.{leaf}"
+            if nk.endswith(".weight") and getattr(v, "ndim", 0) == 4 and tuple(v.shape[2:]) == (1, 1) and \
+                    any(nk.endswith(f".{n}.weight") for _, n in _DEPRECATED_ATTN):
+                v = v.reshape(v.shape[0], v.shape[1])          # some exports keep the projections as 1x1 convs
+        out[nk] = v
+    return out
+
+
+def _read_vae_checkpoint():
+    import torch
+    from safetensors.torch import load_file   # sd-vae ships diffusion_pytorch_model.safetensors / .bin
+    p = os.path.join("models", "sd-vae", "diffusion_pytorch_model.safetensors")
+    return load_file(p) if os.path.exists(p) else torch.load(p.replace(".safetensors", ".bin"), map_location="cpu")
 
 
 def load_model(unet_state_dict=None, vae_state_dict=None, whisper_encoder_state_dict=None, max_frames=None, device=None):
     """The reference reads models/musetalkV15/unet.pth, models/sd-vae and models/whisper
     (avatars/musetalk/utils/utils.py:16-37, audio2feature.py:15-23); state dicts may be passed directly (tests and
-    the bench use seeded synthetic weights: none of those checkpoints exists in the reference tree)."""
+    the bench use seeded synthetic weights: none of those checkpoints exists in the reference tree).
+    One engine per GPU of LTK_DEVICES (default: every visible GPU), or just `device`."""
     import torch
     if unet_state_dict is None:
         unet_state_dict = torch.load(os.path.join("models", "musetalkV15", "unet.pth"), map_location="cpu")
     if vae_state_dict is None:
-        from safetensors.torch import load_file   # sd-vae ships diffusion_pytorch_model.safetensors / .bin
-        p = os.path.join("models", "sd-vae", "diffusion_pytorch_model.safetensors")
-        vae_state_dict = load_file(p) if os.path.exists(p) else torch.load(p.replace(".safetensors", ".bin"), map_location="cpu")
+        vae_state_dict = _read_vae_checkpoint()
+    vae_state_dict = convert_deprecated_vae_attention(vae_state_dict)
     vae_state_dict = {k: v for k, v in vae_state_dict.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
-    dev = _device_index() if device is None else int(device)
+    if whisper_encoder_state_dict is None:
+        from transformers import WhisperModel   # the checkpoint reader the reference uses (audio2feature.py:20-23)
+        whisper_encoder_state_dict = WhisperModel.from_pretrained("./models/whisper").encoder.state_dict()
     if max_frames is None:
-        max_frames = int(os.environ.get("LTK_MT_MAX_FRAMES", "16"))
-    eng = Engine(dev)
+        max_frames = int(os.environ.get("LTK_MT_MAX_FRAMES", "64"))
     # LTK_MT_FP8=1: the fp8 conv path of BASELINE.json configs[4] (ResnetBlock2D convs on e4m3 operands, include/ltk.h
     # ltk_musetalk_set_fp8); LTK_MT_FP8_ASCALE overrides the activation scale (default 8)
     fp8 = os.environ.get("LTK_MT_FP8", "0") not in ("", "0")
-    eng.load_musetalk(unet_state_dict, vae_state_dict, max_frames=max_frames, fp8=fp8,
-                      fp8_act_scale=float(os.environ.get("LTK_MT_FP8_ASCALE", "0")))
-    ap = Audio2Feature(eng, whisper_encoder_state_dict)
-    return MuseTalkModel(eng, ap)
+
+    def factory(dev):
+        eng = Engine(dev)
+        eng.load_musetalk(unet_state_dict, vae_state_dict, max_frames=max_frames, fp8=fp8,
+                          fp8_act_scale=float(os.environ.get("LTK_MT_FP8_ASCALE", "0")))
+        return eng
+
+    devices = visible_devices() if device is None else [int(device)]
+    cap = int(os.environ.get("LTK_SESSIONS_PER_GPU", "0")) or (1 << 30)
+    pool = EnginePool(devices, factory, capacity_per_gpu=cap)
+    aps = [Audio2Feature(eng, whisper_encoder_state_dict) for eng in pool.engines]
+    return MuseTalkModel(pool, aps)
 
 
 def read_imgs(img_list):
@@ -105,9 +161,10 @@ def load_avatar(avatar_id):
 
 def warm_up(batch_size, model):
     """One forward on ones, as the reference does (musetalk_avatar.py:93-108)."""
-    n = min(batch_size, model.engine.mt_max_frames)
-    model.engine.musetalk_forward_host(np.ones((n, 8, 32, 32), np.float32), np.ones((n, 50, 384), np.float32),
-                                       want_image=False, want_frames=False)
+    for eng in model.engines:
+        n = min(batch_size, eng.mt_max_frames)
+        eng.musetalk_forward_host(np.ones((n, 8, 32, 32), np.float32), np.ones((n, 50, 384), np.float32),
+                                  want_image=False, want_frames=False)
 
 
 @register("avatar", "musetalk")
@@ -119,17 +176,20 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
         self.model = model
         (self.frame_list_cycle, self.mask_list_cycle, self.coord_list_cycle, self.mask_coords_list_cycle,
          self.input_latent_list_cycle) = avatar
-        self._aid = model.avatar_id(avatar)
+        self._slot = model.place(self)                  # this session's GPU for its whole life
+        self.engine = model.engines[self._slot]
+        self._aid = model.avatar_id(avatar, self._slot)
         h, w = self.frame_list_cycle[0].shape[:2]
         self._frame_hw = (int(h), int(w))
-        self.asr = WhisperASR(opt, self, model.audio_processor)
+        self._sched = get_scheduler(self.engine, "musetalk")
+        self.asr = WhisperASR(opt, self, model.audio_processors[self._slot])
         self.asr.warm_up()
 
     def inference_batch(self, index, audiofeat_batch):
         """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for bank index
         mirror_index(len, index+i)."""
         import torch
-        dev = self.model.engine.torch_device
+        dev = self.engine.torch_device
         if isinstance(audiofeat_batch, torch.Tensor):
             feat = audiofeat_batch.to(device=dev, dtype=torch.float32).contiguous()
         else:                                               # list of (50,384) arrays from a foreign ASR
@@ -138,15 +198,15 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
         if feat.shape[0] != B:
             raise ValueError(f"expected {B} whisper chunks, got {feat.shape[0]}")
         pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=dev)
-        self.model.engine.musetalk_infer([(self._aid, int(index), B, feat.data_ptr(), pred.data_ptr())])
+        self._sched.infer(self._aid, int(index), B, feat.data_ptr(), pred.data_ptr())
         return [pred[i] for i in range(B)]
 
     def paste_back_frame(self, pred_frame, idx: int):
         import torch
         if not isinstance(pred_frame, torch.Tensor):
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
-                self.model.engine.torch_device)
+                self.engine.torch_device)
         h, w = self._frame_hw
         out = np.empty((h, w, 3), dtype=np.uint8)
-        self.model.engine.paste_blend(self._aid, int(idx), pred_frame.data_ptr(), out)
+        self.engine.paste_blend(self._aid, int(idx), pred_frame.data_ptr(), out)
         return out

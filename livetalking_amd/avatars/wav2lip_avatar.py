@@ -8,8 +8,8 @@ Module contract the reference's app.py relies on (app.py:128-151,99):
   inference_batch(index, audiofeat_batch) and paste_back_frame(pred_frame, idx)
                                           (wav2lip_avatar.py:98-147)
 
-What changes underneath: the model handle owns a per-GPU `Engine`
-(libltk_hip.so); the avatar bank is uploaded to HBM once per avatar;
+What changes underneath: the model handle owns one `Engine` (libltk_hip.so) per
+GPU and pins every session to the least-loaded one; the avatar bank is uploaded to HBM once per avatar;
 `inference_batch` returns device handles (uint8 256x256x3 crops, already
 truncated the way paste_back_frame's astype(uint8) does) instead of float
 numpy frames; `paste_back_frame` composites on the GPU and returns the same
@@ -21,6 +21,7 @@ import glob
 import os
 import pickle
 import threading
+import weakref
 
 import numpy as np
 
@@ -28,36 +29,44 @@ from ..egress import SRC_WAV2LIP, DeviceEgressMixin
 from ..engine import Engine
 from ..hostshim import BaseAvatar, mirror_index, register
 from ..scheduler import get_scheduler
+from ..sharding import EnginePool, visible_devices
 from .audio_features.mel import MelASR
 
-_ENGINES = {}
-_ENGINES_LOCK = threading.Lock()
-
-
 class Wav2LipModel:
-    """Opaque `model` object handed back to app.py; process-global, shared by sessions."""
+    """Opaque `model` object handed back to app.py; process-global, shared by sessions (app.py:62-63).  Owns one engine
+    per GPU (sharding.EnginePool); a session is pinned to one of them when it is constructed."""
 
-    def __init__(self, engine: Engine):
-        self.engine = engine
-        self._avatars = {}          # id(face_list) -> engine avatar id
+    def __init__(self, engine_or_pool):
+        if isinstance(engine_or_pool, EnginePool):
+            self.pool = engine_or_pool
+        else:                                   # a single engine (tests hand in a fake one)
+            self.pool = EnginePool([getattr(engine_or_pool, "device", 0)], lambda d: engine_or_pool)
+        self.engines = self.pool.engines
+        self._avatars = {}          # (id(face_list), engine slot) -> engine avatar id
         self._lock = threading.Lock()
 
-    def avatar_id(self, avatar) -> int:
+    @property
+    def engine(self) -> Engine:
+        """The first engine (single-GPU callers, warm-up of a one-GPU deployment)."""
+        return self.engines[0]
+
+    def place(self, session) -> int:
+        slot = self.pool.place(id(session))
+        weakref.finalize(session, self.pool.release, id(session))      # session_manager.remove_session just drops the object
+        return slot
+
+    def avatar_id(self, avatar, slot: int = 0) -> int:
         frame_list, face_list, coord_list = avatar
-        key = id(face_list)
+        key = (id(face_list), slot)
         with self._lock:
             aid = self._avatars.get(key)
-            if aid is None:
-                aid = self.engine.register_avatar(face_list, frame_list, coord_list)
+            if aid is None:                     # first session of this avatar on this GPU: upload the bank replica
+                aid = self.engines[slot].register_avatar(face_list, frame_list, coord_list)
                 self._avatars[key] = aid
             return aid
 
     def eval(self):
         return self
-
-
-def _device_index() -> int:
-    return int(os.environ.get("LTK_DEVICE", "0"))
 
 
 def _state_dict_from_checkpoint(path):
@@ -70,15 +79,20 @@ def _state_dict_from_checkpoint(path):
 def load_model(path, state_dict=None, max_frames=None, device=None):
     """`path` is the reference's ./models/wav2lip.pth; `state_dict` may be passed
     directly (tests / bench use seeded synthetic weights: there is no checkpoint
-    in the reference tree)."""
+    in the reference tree).  One engine per GPU of LTK_DEVICES (default: every visible GPU), or just `device`."""
     if state_dict is None:
         state_dict = _state_dict_from_checkpoint(path)
-    dev = _device_index() if device is None else int(device)
     if max_frames is None:
         max_frames = int(os.environ.get("LTK_MAX_FRAMES", "256"))
-    eng = Engine(dev)
-    eng.load_wav2lip(state_dict, max_frames=max_frames)
-    return Wav2LipModel(eng)
+
+    def factory(dev):
+        eng = Engine(dev)
+        eng.load_wav2lip(state_dict, max_frames=max_frames)
+        return eng
+
+    devices = visible_devices() if device is None else [int(device)]
+    cap = int(os.environ.get("LTK_SESSIONS_PER_GPU", "0")) or (1 << 30)
+    return Wav2LipModel(EnginePool(devices, factory, capacity_per_gpu=cap))
 
 
 def read_imgs(img_list):
@@ -108,8 +122,9 @@ def warm_up(batch_size, model, modelres=256):
     """One forward on ones, as the reference does, to fault in kernels and arena."""
     mel = np.ones((batch_size, 80, 16), dtype=np.float32)
     img = np.ones((batch_size, 6, modelres, modelres), dtype=np.float32)
-    n = min(batch_size, model.engine.max_frames)
-    model.engine.wav2lip_forward_host(mel[:n], img[:n])
+    for eng in model.engines:
+        n = min(batch_size, eng.max_frames)
+        eng.wav2lip_forward_host(mel[:n], img[:n])
 
 
 @register("avatar", "wav2lip")
@@ -120,11 +135,13 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         super().__init__(opt)
         self.model = model
         self.frame_list_cycle, self.face_list_cycle, self.coord_list_cycle = avatar
-        self._aid = model.avatar_id(avatar)
+        self._slot = model.place(self)                  # this session's GPU for its whole life
+        self.engine = model.engines[self._slot]
+        self._aid = model.avatar_id(avatar, self._slot)
         h, w = self.frame_list_cycle[0].shape[:2]
         self._frame_hw = (int(h), int(w))
-        self._sched = get_scheduler(model.engine)
-        self.asr = MelASR(opt, self, engine=model.engine)
+        self._sched = get_scheduler(self.engine)
+        self.asr = MelASR(opt, self, engine=self.engine)
         self.asr.warm_up()
 
     def _mel_to_device(self, audiofeat_batch):
@@ -132,7 +149,7 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         if isinstance(audiofeat_batch, torch.Tensor):
             return audiofeat_batch
         arr = np.ascontiguousarray(np.asarray(audiofeat_batch), dtype=np.float32)   # list of (80,16)
-        return torch.from_numpy(arr).to(self.model.engine.torch_device)
+        return torch.from_numpy(arr).to(self.engine.torch_device)
 
     def inference_batch(self, index, audiofeat_batch):
         """Returns batch_size device handles (uint8 [256][256][3] BGR), item i for
@@ -151,8 +168,8 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         import torch
         if not isinstance(pred_frame, torch.Tensor):   # a float frame from a foreign inference_batch
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
-                self.model.engine.torch_device)
+                self.engine.torch_device)
         h, w = self._frame_hw
         out = np.empty((h, w, 3), dtype=np.uint8)
-        self.model.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)
+        self.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)
         return out

@@ -129,7 +129,7 @@ class DeviceEgressMixin:
 
     def _make_egress(self):
         h, w = self.frame_list_cycle[0].shape[:2]
-        return DeviceEgress(self.model.engine, h, w, self._egress_source, self._aid, fmt=getattr(self.opt, "egress", "bgr24"),
+        return DeviceEgress(getattr(self, "engine", None) or self.model.engine, h, w, self._egress_source, self._aid, fmt=getattr(self.opt, "egress", "bgr24"),
                             enable_transition=bool(getattr(self.opt, "enable_transition", False)))
 
     def process_frames(self, quit_event, *args, **kwargs):
@@ -155,7 +155,21 @@ class DeviceEgressMixin:
                         cyc = self.custom_img_cycle[audiotype]
                         custom = cyc[mirror_index(len(cyc), cidx[audiotype])]
                         cidx[audiotype] += 1
-                    frame = eg.silent_frame(idx, custom)
+                    try:
+                        frame = eg.silent_frame(idx, custom)
+                    except ValueError:
+                        # a custom-action clip of another size than the avatar: the reference pushes it as it is
+                        # (base_avatar.py:410-416, 449-452); host frame, host watermark when OpenCV is there
+                        frame = np.ascontiguousarray(custom)
+                        try:
+                            import cv2  # type: ignore
+                            cv2.putText(frame, WATERMARK_TEXT, WATERMARK_ORG, cv2.FONT_HERSHEY_SIMPLEX, 0.3, WATERMARK_COLOR, 1)
+                        except Exception:  # noqa: BLE001
+                            pass
+                    except Exception as e:  # noqa: BLE001 - log and drop the frame, like the speaking path below
+                        import logging
+                        logging.getLogger(__name__).warning("silent frame error: %s", e)
+                        continue
                 else:
                     self.speaking = True
                     try:

@@ -1,101 +1,155 @@
 """Cross-session batching of `inference_batch` calls.
 
-N session threads call `infer()` concurrently (avatars/base_avatar.py:366, one
-inference thread per session).  With LTK_COALESCE_MS unset (default 0) every
-call goes straight to the engine - the engine already lets calls from
-different threads queue back-to-back on its compute stream.  With
-LTK_COALESCE_MS > 0 a dispatcher thread gathers the requests that arrive within
-that window (bounded by the engine's max_frames) and issues ONE
-ltk_wav2lip_infer with nreq > 1, so small per-session batches fill the GPU.
-A session's frames keep their order: a request is one contiguous
-(index .. index+batch) span and each session has at most one request in flight.
+N session threads call `infer()` concurrently (avatars/base_avatar.py:366: one inference thread per session, all
+sharing one model object, app.py:62-63,99).  The engine runs one call at a time per GPU, so requests that arrive while
+a call is in flight would otherwise queue behind it one by one, each as its own 16-frame launch sequence.  The
+scheduler batches them instead (continuous batching):
+
+* an idle engine takes a request immediately, in the caller's thread - a single session pays no hop and no window;
+* while a call is in flight, new requests collect in a queue; when the call returns, everything queued (up to the
+  engine's max_frames) goes down as ONE engine call with nreq > 1, which is how 16 sessions per GPU fill the chip
+  (256 frames per launch sequence instead of 16);
+* LTK_COALESCE_MS > 0 additionally holds a batch open for that long after its first request (fixed window; useful when
+  sessions are paced by the same clock and arrive within a millisecond of each other).
+
+A session's frames keep their order: a request is one contiguous (index .. index+batch) span, a session has at most
+one request in flight (its inference thread blocks in `infer()`), and every request's frames land in its own output
+tensor.  One scheduler per (engine, kind); kinds: "wav2lip" -> Engine.wav2lip_infer, "musetalk" -> Engine.musetalk_infer.
 """
 from __future__ import annotations
 
+import collections
 import os
-import queue
 import threading
 import time
 
 
 class _Req:
-    __slots__ = ("aid", "index", "batch", "mel", "out", "done", "err")
+    __slots__ = ("args", "batch", "done", "err")
 
-    def __init__(self, aid, index, batch, mel, out):
-        self.aid, self.index, self.batch, self.mel, self.out = aid, index, batch, mel, out
+    def __init__(self, args, batch):
+        self.args, self.batch = args, batch
         self.done = threading.Event()
         self.err = None
 
 
-class DirectScheduler:
-    def __init__(self, engine):
+class BatchingScheduler:
+    def __init__(self, engine, kind: str = "wav2lip", window_ms: float = 0.0, max_frames: int = 0):
         self.engine = engine
+        self.kind = kind
+        self._call = engine.wav2lip_infer if kind == "wav2lip" else engine.musetalk_infer
+        self.window = max(0.0, float(window_ms)) * 1e-3
+        self._max_frames = int(max_frames)
+        self._cv = threading.Condition()
+        self._pending = collections.deque()
+        self._busy = False
+        self._handoff = False
+        self._closed = False
+        self._worker = None
+        self.stats = {"calls": 0, "requests": 0, "frames": 0, "max_requests_per_call": 0}
 
-    def infer(self, aid, index, batch, mel_ptr, out_ptr):
-        self.engine.wav2lip_infer([(aid, index, batch, mel_ptr, out_ptr)])
+    def _limit(self) -> int:
+        if self._max_frames > 0:
+            return self._max_frames
+        lim = getattr(self.engine, "max_frames" if self.kind == "wav2lip" else "mt_max_frames", 0)
+        return int(lim) if lim else 1 << 30
 
-    def close(self):
-        pass
-
-
-class CoalescingScheduler:
-    def __init__(self, engine, window_ms: float):
-        self.engine = engine
-        self.window = window_ms * 1e-3
-        self.q: "queue.Queue[_Req]" = queue.Queue()
-        self._stop = False
-        self._thread = threading.Thread(target=self._run, name="ltk-coalesce", daemon=True)
-        self._thread.start()
-
-    def infer(self, aid, index, batch, mel_ptr, out_ptr):
-        r = _Req(aid, index, batch, mel_ptr, out_ptr)
-        self.q.put(r)
+    def infer(self, aid, index, batch, in_ptr, out_ptr):
+        """Blocks until this request's frames are ready.  Raises what the engine raised for the call that carried it."""
+        r = _Req((aid, index, batch, in_ptr, out_ptr), int(batch))
+        with self._cv:
+            self._pending.append(r)
+            leader = not self._busy
+            if leader:
+                self._busy = True
+        if leader:
+            # idle engine: run the call in this thread (no hop); whatever queued up meanwhile goes to the worker
+            if self.window > 0.0:
+                time.sleep(self.window)
+            self._run_one_batch()
+            with self._cv:
+                if self._pending:
+                    self._handoff = True
+                    if self._worker is None:
+                        self._worker = threading.Thread(target=self._work, name="ltk-batch", daemon=True)
+                        self._worker.start()
+                    self._cv.notify_all()
+                else:
+                    self._busy = False
         r.done.wait()
         if r.err is not None:
             raise r.err
 
-    def _run(self):
-        while not self._stop:
-            try:
-                first = self.q.get(timeout=0.1)
-            except queue.Empty:
-                continue
-            group, frames = [first], first.batch
-            deadline = time.perf_counter() + self.window
-            while frames < self.engine.max_frames:
-                left = deadline - time.perf_counter()
-                if left <= 0:
-                    break
-                try:
-                    r = self.q.get(timeout=left)
-                except queue.Empty:
-                    break
-                if frames + r.batch > self.engine.max_frames:
-                    self.q.put(r)
-                    break
-                group.append(r)
-                frames += r.batch
-            try:  # every request's frames land in its own output tensor (ltk_w2l_req.d_pred)
-                self.engine.wav2lip_infer([(r.aid, r.index, r.batch, r.mel, r.out) for r in group])
-            except Exception as ex:  # noqa: BLE001 - hand the error to every waiting caller
-                for r in group:
-                    r.err = ex
-            for r in group:
-                r.done.set()
+    def _take_batch(self):
+        """Under the lock: the queued requests that fit one engine call (FIFO)."""
+        group, frames, lim = [], 0, self._limit()
+        while self._pending and (not group or frames + self._pending[0].batch <= lim):
+            q = self._pending.popleft()
+            group.append(q)
+            frames += q.batch
+        return group, frames
+
+    def _run_one_batch(self):
+        with self._cv:
+            group, frames = self._take_batch()
+        if not group:
+            return
+        err = None
+        try:
+            self._call([q.args for q in group])
+        except Exception as ex:  # noqa: BLE001 - every caller of this batch gets the error
+            err = ex
+        with self._cv:
+            self.stats["calls"] += 1
+            self.stats["requests"] += len(group)
+            self.stats["frames"] += frames
+            self.stats["max_requests_per_call"] = max(self.stats["max_requests_per_call"], len(group))
+        for q in group:
+            q.err = err
+            q.done.set()
+
+    def _work(self):
+        """Worker: owns the engine between a leader's hand-off and the moment the queue runs empty."""
+        while True:
+            with self._cv:
+                while not self._handoff and not self._closed:
+                    self._cv.wait()
+                if self._closed:
+                    return
+                self._handoff = False
+            while True:
+                with self._cv:
+                    if not self._pending:
+                        self._busy = False
+                        break
+                self._run_one_batch()
 
     def close(self):
-        self._stop = True
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+
+
+# kept under the old names for callers that construct them directly
+class DirectScheduler(BatchingScheduler):
+    def __init__(self, engine, kind: str = "wav2lip"):
+        super().__init__(engine, kind, 0.0)
+
+
+class CoalescingScheduler(BatchingScheduler):
+    def __init__(self, engine, window_ms: float, kind: str = "wav2lip"):
+        super().__init__(engine, kind, window_ms)
 
 
 _SCHEDULERS = {}
 _LOCK = threading.Lock()
 
 
-def get_scheduler(engine):
+def get_scheduler(engine, kind: str = "wav2lip"):
     with _LOCK:
-        s = _SCHEDULERS.get(id(engine))
+        key = (id(engine), kind)
+        s = _SCHEDULERS.get(key)
         if s is None:
-            ms = float(os.environ.get("LTK_COALESCE_MS", "0"))
-            s = CoalescingScheduler(engine, ms) if ms > 0 else DirectScheduler(engine)
-            _SCHEDULERS[id(engine)] = s
+            s = BatchingScheduler(engine, kind, float(os.environ.get("LTK_COALESCE_MS", "0")))
+            _SCHEDULERS[key] = s
         return s

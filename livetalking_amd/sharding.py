@@ -7,8 +7,8 @@ exchange step, xGMI unused.  Two deployment shapes use the same assignment:
 
 * one process per GPU (bench.py under torch.distributed.run): rank r serves
   `shard_for_rank(...)`;
-* one process, several GPUs (`EnginePool`): `create_session` picks the least
-  loaded engine, replicating weights / banks on first use.
+* one process, several GPUs (`EnginePool`, what the plugin modules' load_model builds): a new session goes to the least
+  loaded engine; weights are replicated at load time, avatar banks on first use per engine.
 """
 from __future__ import annotations
 
@@ -61,27 +61,48 @@ class LeastLoaded:
 
 
 class EnginePool:
-    """One engine (weights replica) per visible GPU inside one process."""
+    """One engine (weights replica) per GPU inside ONE process - the reference's deployment shape (a single process and
+    a single `device`, utils/device.py:4-10, with every session sharing one model object, app.py:62-63,99) widened to the
+    node: `engines[i]` lives on `devices[i]`, a session is placed on the least-loaded engine when it is created
+    (server/session_manager.py:56-94 is the caller) and released when it goes away.  No data ever crosses engines.
+    The same device may be listed more than once (two engines on one GPU: tests)."""
 
-    def __init__(self, state_dict, devices: Sequence[int], max_frames: int = 256, capacity_per_gpu: int = 16,
-                 engine_factory=None):
-        if engine_factory is None:
-            from .engine import Engine
-
-            def engine_factory(dev):
-                e = Engine(dev)
-                e.load_wav2lip(state_dict, max_frames=max_frames)
-                return e
+    def __init__(self, devices: Sequence[int], engine_factory, capacity_per_gpu: int = 1 << 30):
         self.devices = list(devices)
+        if not self.devices:
+            raise ValueError("EnginePool needs at least one device")
         self.engines = [engine_factory(d) for d in self.devices]
         self.placer = LeastLoaded(len(self.devices), capacity_per_gpu)
 
-    def engine_for(self, session_id):
-        return self.engines[self.placer.place(session_id)]
+    def place(self, session_key) -> int:
+        """Index of the engine that serves this session (stable for the session's lifetime)."""
+        return self.placer.place(session_key)
 
-    def release(self, session_id):
-        self.placer.release(session_id)
+    def engine_for(self, session_key):
+        return self.engines[self.place(session_key)]
+
+    def release(self, session_key) -> None:
+        self.placer.release(session_key)
+
+    def load(self) -> List[int]:
+        return list(self.placer.load)
 
     def close(self):
         for e in self.engines:
             e.close()
+
+
+def visible_devices() -> List[int]:
+    """LTK_DEVICES="0,1,2" (explicit list, repeats allowed) > LTK_DEVICE=n (one GPU) > every GPU the process sees."""
+    import os
+    env = os.environ.get("LTK_DEVICES", "").strip()
+    if env:
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    if os.environ.get("LTK_DEVICE", "").strip():
+        return [int(os.environ["LTK_DEVICE"])]
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        n = 0
+    return list(range(n)) if n > 0 else [0]

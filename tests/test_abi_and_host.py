@@ -7,6 +7,7 @@ import os
 import re
 import sys
 import threading
+import time
 import types
 
 import numpy as np
@@ -115,6 +116,42 @@ def test_coalescing_scheduler_groups_concurrent_sessions():
     total = sorted(r for call in eng.infer_calls for r in call)
     assert total == [(1, 0, 16, 1000, 2000), (1, 16, 16, 1001, 2001), (1, 32, 16, 1002, 2002)]
     assert len(eng.infer_calls) < 3, "requests inside the window must share a launch"
+
+
+def test_continuous_batching_without_a_window():
+    """Default scheduler (no window): an idle engine takes a request at once in the caller's thread; requests that arrive
+    while that call is in flight go down together as ONE call afterwards; errors reach exactly the callers of the failed call."""
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+
+    class SlowEngine(FakeEngine):
+        def wav2lip_infer(self, reqs, stream=0):
+            if any(r[0] == 99 for r in reqs):
+                raise RuntimeError("boom")
+            time.sleep(0.15)
+            super().wav2lip_infer(reqs, stream)
+
+    eng = SlowEngine()
+    sch = scheduler.BatchingScheduler(eng, "wav2lip")
+    first = threading.Thread(target=sch.infer, args=(1, 0, 16, 1000, 2000))
+    first.start()
+    time.sleep(0.05)                                     # the first call is now in flight
+    late = [threading.Thread(target=sch.infer, args=(1, 16 * i, 16, 1000 + i, 2000 + i)) for i in (1, 2, 3)]
+    for t in late:
+        t.start()
+    for t in [first] + late:
+        t.join(timeout=10)
+        assert not t.is_alive()
+    assert [len(c) for c in eng.infer_calls] == [1, 3], eng.infer_calls
+    assert sorted(r[1] for r in eng.infer_calls[1]) == [16, 32, 48]
+    assert sch.stats["max_requests_per_call"] == 3 and sch.stats["frames"] == 64
+    # a lone request right after: again alone, again in the caller's thread
+    sch.infer(1, 64, 16, 1, 2)
+    assert len(eng.infer_calls) == 3 and len(eng.infer_calls[2]) == 1
+    with pytest.raises(RuntimeError, match="boom"):
+        sch.infer(99, 0, 16, 1, 2)
+    sch.infer(1, 80, 16, 1, 2)                           # the scheduler survives a failed call
+    sch.close()
 
 
 def test_least_loaded_placement_and_round_robin():
