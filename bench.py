@@ -1,59 +1,659 @@
 #!/usr/bin/env python3
-"""inferfps bench of the MI355X-native Wav2Lip-256 render hot path.
+"""inferfps bench of the MI355X-native LiveTalking render hot path (BASELINE.json: "inferfps/GPU + max concurrent
+25 fps sessions, wav2lip256 & MuseTalk").
 
-A "step" is one `LipReal.inference_batch`-equivalent pass (bank gather + mask +
-pack, the 55 conv/convT layers, sigmoid*255 + uint8 truncation) over one batch
-of B=16 frames per session, with the avatar bank, the weights and the mel
-windows already resident in HBM (avatars/base_avatar.py:364-373 defines
-inferfps as frames / wall time of inference_batch).  BASELINE.json configs[1]:
-wav2lip256, 1 session, 16-frame batch, fp16 on 1x MI355X.
+A "step" is one `inference_batch` call per session (avatars/base_avatar.py:366) - bank gather + mask + pack, the conv
+stack, head, uint8 frames - issued through the PLUGIN surface (`LipReal.inference_batch` / `MuseReal.inference_batch`:
+torch.empty of the outputs, scheduler, ctypes marshalling included), with the avatar bank, the weights and the audio
+features already resident in HBM.  inferfps = frames / wall time of those calls (base_avatar.py:364-373).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sessions S] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sessions S] [--batch B] [--model wav2lip|musetalk] [--fp8]
 
-N>1 is launched by torch.distributed.run (one rank per GPU, RCCL only for the
-barrier / max-over-ranks reduction; sessions are independent, so the data path
-has no collective).  Rank 0 prints ONE JSON line.
+Default (N=1): the timed line is BASELINE.json configs[1] (wav2lip256, 1 session, 16-frame batch, fp16).  Rank 0 then
+adds, OUTSIDE the timed region (each in its own subprocess, so `ms_per_step x steps` stays what was timed):
+  also[]        configs[3]'s per-GPU share (16 wav2lip sessions on one GPU, saturating and paced at 25 fps),
+                configs[2] (MuseTalk + Whisper step) and configs[4]'s per-GPU share (4 MuseTalk sessions, fp8 conv path)
+  paced         the largest number of 25-fps wav2lip sessions one GPU sustains (bisection, engine level)
+  cpu_baseline  the reference's LipReal.inference_batch on the host cores (kind "reference" when a LiveTalking checkout
+                is importable, else the oracle port), B=16 and B=1 (configs[0]), median of 5
+  roofline.traffic  HBM bytes per pass from two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) of the conv stack
+
+N>1: sessions are independent (app.py:62-63,99), so rank r owns its own engine, bank replica and sessions: no collective
+on the data path, xGMI unused.  Launched either by the driver (`python -m torch.distributed.run ... bench.py --gpus N`:
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment) or directly (`python bench.py --gpus N` spawns the N ranks
+itself).  Ranks meet on a gloo (CPU) barrier on both sides of the timed region and rank 0 takes the max elapsed time;
+`--dry-ranks` runs that protocol without touching a GPU (CPU test of the launcher).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("LTK_ALLOW_STANDIN", "1")     # headless: stand-ins of the reference's BaseAvatar/BaseASR (hostshim.py)
 
-MACS_PER_FRAME = 27_788_599_296       # SURVEY.md Appendix A (conv + convT + head)
-HEAD_MACS = 32 * 3 * 65536
+MACS_PER_FRAME = 27_788_599_296       # SURVEY.md Appendix A (54 conv/convT layers + the 1x1 head)
 PEAK_F16_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+PEAK_FP8_TFLOPS = 5000.0              # MI355X_MICROARCH.md: dense fp8 MFMA (MX-scaled instruction)
+REF_ROOT = os.environ.get("LTK_REFERENCE", "/root/reference")
 
 
-def cpu_baseline(batch: int, budget_s: float = 20.0):
-    """The oracle restatement of LipReal.inference_batch (fp32, torch CPU) on the
-    host cores, bounded sample."""
+# ---------------------------------------------------------------------------------------------------------------
+# ranks
+# ---------------------------------------------------------------------------------------------------------------
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (what torch.distributed.run would do), relay
+    rank 0's line.  Fails loudly when the box has fewer GPUs than ranks."""
+    n = args.gpus
+    if not args.dry_ranks:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this box has {have}", file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LTK_DEVICE=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+class Ranks:
+    """Barrier and max-over-ranks on the CPU (gloo): the data path has no collective to share a communicator with."""
+
+    def __init__(self):
+        self.rank, self.world, self.local_rank = rank_env()
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self, sync_gpu=True):
+        if sync_gpu:
+            import torch
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather_max(self, value: float):
+        """(max over ranks, list of every rank's value)."""
+        if self.dist is None:
+            return value, [value]
+        import torch
+        t = torch.tensor([value], dtype=torch.float64)
+        allv = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(allv, t)
+        vals = [float(v.item()) for v in allv]
+        return max(vals), vals
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# session drivers (plugin surface)
+# ---------------------------------------------------------------------------------------------------------------
+class SessionThreads:
+    """S sessions, each with its own thread calling `inference_batch` once per step - the reference's concurrency model
+    (one inference thread per session, base_avatar.py:475-481).  S == 1 runs in the caller's thread."""
+
+    def __init__(self, sessions, feats, stride):
+        self.sessions, self.feats, self.stride = sessions, feats, stride
+        self.S = len(sessions)
+        self.busy = [0.0] * self.S          # per session: seconds inside inference_batch (the reference's counttime)
+        self.frames = [0] * self.S
+        self._step = 0
+        self._err = None
+        if self.S > 1:
+            self._go = threading.Barrier(self.S + 1)
+            self._done = threading.Barrier(self.S + 1)
+            self._stop = False
+            self._due = None
+            self._threads = [threading.Thread(target=self._run, args=(i,), daemon=True) for i in range(self.S)]
+            for t in self._threads:
+                t.start()
+
+    def _one(self, i, step):
+        s = self.sessions[i]
+        t = time.perf_counter()
+        pred = s.inference_batch(step * s.batch_size + self.stride * i, self.feats[i])
+        self.busy[i] += time.perf_counter() - t
+        self.frames[i] += len(pred)
+
+    def _run(self, i):
+        while True:
+            self._go.wait()
+            if self._stop:
+                return
+            try:
+                if self._due is not None:                      # paced: every session asks at its own due time
+                    while time.perf_counter() < self._due:
+                        time.sleep(0.0005)
+                self._one(i, self._step)
+            except Exception as ex:  # noqa: BLE001
+                self._err = ex
+            self._done.wait()
+
+    def step(self, step, due=None):
+        if self.S == 1:
+            self._one(0, step)
+            return
+        self._step, self._due = step, due
+        self._go.wait()
+        self._done.wait()
+        if self._err is not None:
+            raise self._err
+
+    def close(self):
+        if self.S > 1:
+            self._stop = True
+            self._go.wait()
+
+
+def paced_sessions(drv: SessionThreads, first_step: int, periods: int, B: int):
+    """Every session asks for its next B frames once per B/25 s (what a 25 fps render loop does).  A period is met when
+    the last session's frames are ready before the next period starts."""
+    period = B / 25.0
+    drv.busy = [0.0] * drv.S
+    drv.frames = [0] * drv.S
+    lat = []
+    t0 = time.perf_counter() + 0.05
+    for p in range(periods):
+        due = t0 + p * period
+        if drv.S == 1:
+            while time.perf_counter() < due:
+                time.sleep(0.0005)
+        drv.step(first_step + p, due=due)
+        lat.append(time.perf_counter() - due)
+    per_session = [f / b if b > 0 else 0.0 for f, b in zip(drv.frames, drv.busy)]
+    return {"sessions": drv.S, "fps_per_session_required": 25, "periods": periods, "period_ms": period * 1e3,
+            "latency_ms_mean": round(1e3 * sum(lat) / len(lat), 2), "latency_ms_max": round(1e3 * max(lat), 2),
+            "inferfps_per_session_min": round(min(per_session), 1), "inferfps_per_session_mean": round(sum(per_session) / len(per_session), 1),
+            "sustained": bool(max(lat) < period and min(per_session) >= 25.0),
+            "note": "inferfps per session = frames / time inside inference_batch (base_avatar.py:364-373)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def run_wav2lip(args, ranks: Ranks):
+    import argparse as ap
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(ranks.local_rank)
+    os.environ["LTK_DEVICE"] = str(ranks.local_rank)
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd import synth  # seeded synthetic input generators (product-side; nothing from oracle/)
+
+    S, B = args.sessions, args.batch
+    frames_per_step = S * B
+    if frames_per_step > 4096:
+        raise SystemExit("bench.py: at most 4096 frames per step (use --paced-capacity for the session capacity)")
+    if frames_per_step > 256:
+        os.environ.setdefault("LTK_MICROBATCH", "256")     # activation arena for 256 frames; larger steps run as micro-batches
+    model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=frames_per_step, device=ranks.local_rank)
+    eng = model.engine
+    plugin.warm_up(B, model, 256)
+    avatar = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
+    opt = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=0)
+    sessions = []
+    for s in range(S):
+        o = ap.Namespace(**vars(opt))
+        o.sessionid = s
+        sessions.append(plugin.LipReal(o, model, avatar))
+    # mel windows resident in HBM: one (B,80,16) block per session, made by the HIP mel kernel
+    audio = synth.synthetic_audio(4.0)
+    n_chunks = 20 + 2 * B
+    starts = [int(16 + i * 3.2) for i in range(B)]
+    d_mel = torch.zeros(S, B, 80, 16, dtype=torch.float32, device="cuda")
+    for s in range(S):
+        off = (s * 977) % (len(audio) - n_chunks * 320)
+        eng.mel_step(audio[off: off + n_chunks * 320], starts, d_mel[s].data_ptr())
+    drv = SessionThreads(sessions, [d_mel[s] for s in range(S)], stride=7)
+
+    for i in range(args.warmup):
+        drv.step(i)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        drv.step(args.warmup + i)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                     # this rank's own time (reported per rank)
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, _ = ranks.gather_max(elapsed)
+    _, per_rank = ranks.gather_max(own)
+    value = ranks.world * args.steps * frames_per_step / elapsed_max
+
+    paced = paced_sessions(drv, args.warmup + args.steps, args.paced, B) if args.paced > 0 else None
+    sched = dict(sessions[0]._sched.stats)
+    drv.close()
+    # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass, the head fused into the last):
+    # HIP events on the engine's own streams around the conv stack only (no gather/pack), averaged over 10 passes of the
+    # same workload.  One "launch" below = one pass of the conv stack over min(frames_per_step, 256) frames.
+    nf_pass = min(frames_per_step, 256)
+    conv_ms, conv_macs = eng.time_convs(nf_pass, 10)
+    achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
+    out = None
+    if ranks.rank == 0:
+        out = {
+            "metric": "inferfps", "value": round(value, 2), "unit": "frames/s", "n_gpus": ranks.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"wav2lip256, {S} session(s)/GPU, {B}-frame batch, fp16 activations / fp32 accumulate, through LipReal.inference_batch",
+                       "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": f"session-sharded x{ranks.world} (no collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
+                         "kernel": "conv3_kernel + conv_mfma_kernel (the 54 conv/convT layers + fused head = one pass)",
+                         "conv_stack_ms": round(conv_ms, 4), "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass},
+            "per_rank_fps": [round(args.steps * frames_per_step / t, 1) for t in per_rank],
+            "scheduler": sched,
+        }
+        if paced is not None:
+            out["paced"] = paced
+    for eng_ in model.engines:
+        eng_.close()
+    return out
+
+
+def run_musetalk(args, ranks: Ranks, shared=None):
+    """BASELINE.json configs[2] / configs[4]: MuseTalk (Whisper audio feat + U-Net + VAE decoder).  A step = one
+    MuseReal.inference_batch per session (latent gather + PE + U-Net + VAE decode + uint8 BGR) with latents, weights and
+    whisper chunks resident in HBM; the Whisper step (run_step's work, outside inferfps in the reference too) is timed
+    beside it."""
+    import argparse as ap
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(ranks.local_rank)
+    os.environ["LTK_DEVICE"] = str(ranks.local_rank)
+    os.environ["LTK_MT_FP8"] = "1" if args.fp8 else "0"
+    import livetalking_amd.avatars.musetalk_avatar as plugin
+    from livetalking_amd import synth
+
+    S, B = args.sessions, args.batch
+    fps_step = S * B
+    shared = shared if shared is not None else {}
+    if "unet" not in shared:
+        shared["unet"], shared["vae"], shared["whisper"] = (synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(),
+                                                           synth.whisper_encoder_state_dict())
+    model = plugin.load_model(shared["unet"], shared["vae"], shared["whisper"], max_frames=min(fps_step, 64), device=ranks.local_rank)
+    eng = model.engine
+    macs_all, macs_fp8 = eng.musetalk_info()
+    n = 8
+    lats = synth.musetalk_latents(n)
+    frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(720, 1280), box=320, seed=0)
+    avatar = (frames, [np.full((480, 480, 3), 128, np.uint8)] * n, [(480, 200, 800, 520)] * n, [(400, 120, 880, 600)] * n, lats)
+    sessions = []
+    for s in range(S):
+        sessions.append(plugin.MuseReal(ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=s), model, avatar))
+    d_feat = torch.from_numpy(synth.musetalk_whisper_feats(fps_step)).cuda().reshape(S, B, 50, 384)
+    drv = SessionThreads(sessions, [d_feat[s] for s in range(S)], stride=3)
+    for i in range(args.warmup):
+        drv.step(i)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        drv.step(args.warmup + i)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, _ = ranks.gather_max(elapsed)
+    _, per_rank = ranks.gather_max(own)
+    value = ranks.world * args.steps * fps_step / elapsed_max
+    sched = dict(sessions[0]._sched.stats)
+    drv.close()
+    nt = min(fps_step, 64)
+    ms, macs = eng.musetalk_time(nt, 3)
+    achieved = 2.0 * macs / (ms * 1e-3) / 1e12
+    # roofline peak: MAC-weighted blend of the fp8 peak (layers on e4m3 operands) and the fp16 peak (everything else)
+    f8 = macs_fp8 / macs_all if args.fp8 else 0.0
+    peak = 1.0 / (f8 / PEAK_FP8_TFLOPS + (1.0 - f8) / PEAK_F16_TFLOPS)
+    # WhisperASR.run_step's feature work (log-mel + whisper-tiny encoder + chunk slicing) for one session's 0.64-s step: the
+    # reference runs it on the render thread, outside inferfps (base_avatar.py:364-373 times inference_batch only)
+    pcm = synth.synthetic_audio(2.0)[: (20 + 2 * B) * 320]
+    d_chunks = torch.zeros(B, 50, 384, dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    for _ in range(5):
+        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
+    torch.cuda.synchronize()
+    whisper_ms = (time.perf_counter() - tw) / 5 * 1e3
+    out = None
+    if ranks.rank == 0:
+        out = {"metric": "inferfps", "value": round(value, 2), "unit": "frames/s", "n_gpus": ranks.world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "fp8(e4m3)+f16" if args.fp8 else "f16", "data": "synthetic",
+               "config": {"workload": f"musetalk (U-Net + VAE decoder), {S} session(s)/GPU, {B}-frame batch, through MuseReal.inference_batch, " +
+                                      (f"fp8 e4m3 operands on the resnet 3x3 convs ({f8:.0%} of the MACs), fp16 elsewhere, fp32 accumulate"
+                                       if args.fp8 else "fp16 activations / fp32 accumulate"),
+                          "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": fps_step,
+                          "parallelism": f"session-sharded x{ranks.world} (no collective)"},
+               "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                            "frac": round(achieved / peak, 5), "traffic": None,
+                            "peak_note": "MAC-weighted blend of 5 PF (fp8 layers) and 2.5 PF (fp16 layers)" if args.fp8 else "dense fp16 MFMA",
+                            "kernel": "conv3_kernel / conv_mfma_kernel (U-Net + VAE conv and linear layers; attention excluded from the flop count)",
+                            "pass_ms": round(ms, 4), "frames_per_pass": nt, "flops_per_frame": 2.0 * macs / nt},
+               "sessions_25fps": {"per_gpu": int(value / ranks.world // 25), "note": "saturating rate / 25 fps"},
+               "per_rank_fps": [round(args.steps * fps_step / t, 1) for t in per_rank],
+               "scheduler": sched,
+               "whisper": {"ms_per_session_step": round(whisper_ms, 3), "frames_per_step": B,
+                           "note": "log-mel + whisper-tiny encoder (1500 tokens) + chunk slicing, host PCM in, device features out; not in `value`",
+                           "fps_incl_whisper": round(fps_step / (elapsed_max / args.steps + S * whisper_ms * 1e-3), 2)}}
+    for e in model.engines:
+        e.close()
+    return out
+
+
+def paced_capacity(args):
+    """The largest number of 25-fps wav2lip256 sessions ONE GPU sustains: every session asks for its next B frames once
+    per B/25 s, all requests of a period go down coalesced (<= 4096 frames per engine call); a session count is
+    sustained when every period's last frame is ready before the next period starts.  Engine level (hundreds of Python
+    session threads would measure the GIL, and those threads are the reference's own unchanged code)."""
+    import torch
+    from livetalking_amd import synth
+    from livetalking_amd.engine import Engine
+    B = args.batch
+    os.environ.setdefault("LTK_MICROBATCH", "256")
+    eng = Engine(0)
+    eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=4096)
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
+    aid = eng.register_avatar(faces, frames, coords)
+    SMAX = 1024
+    d_mel = torch.randn(B, 80, 16, dtype=torch.float32, device="cuda")
+    d_pred = torch.zeros(4096 // B, B, 256, 256, 3, dtype=torch.uint8, device="cuda")      # outputs are overwritten per call
+    period = B / 25.0
+    per_call = 4096 // B
+
+    def run_period(S, i):
+        reqs = [(aid, i * B + 7 * s, B, d_mel.data_ptr(), d_pred[s % per_call].data_ptr()) for s in range(S)]
+        for j in range(0, S, per_call):
+            eng.wav2lip_infer(reqs[j:j + per_call])
+
+    def sustained(S, periods=3):
+        run_period(S, 0)
+        t0 = time.perf_counter() + 0.02
+        worst = 0.0
+        for p in range(periods):
+            due = t0 + p * period
+            while time.perf_counter() < due:
+                time.sleep(0.0005)
+            run_period(S, 1 + p)
+            worst = max(worst, time.perf_counter() - due)
+        return worst < period, worst
+
+    tested = []
+    lo, hi = 16, SMAX            # invariant: lo sustained (or smallest), hi not (or the cap)
+    ok, w = sustained(lo)
+    tested.append((lo, round(w * 1e3, 1), ok))
+    best_lat = w if ok else None
+    if ok:
+        while hi - lo > 16:
+            mid = (lo + hi) // 2 // 16 * 16
+            ok, w = sustained(mid)
+            tested.append((mid, round(w * 1e3, 1), ok))
+            if ok:
+                lo, best_lat = mid, w
+            else:
+                hi = mid
+    eng.close()
+    return {"max_sessions_25fps": lo if best_lat is not None else 0, "period_ms": period * 1e3,
+            "latency_ms_at_max": round(best_lat * 1e3, 1) if best_lat is not None else None,
+            "tested": [{"sessions": s, "latency_ms": l, "sustained": o} for s, l, o in tested],
+            "note": "bisection in steps of 16 sessions, 3 paced periods per trial, requests of a period coalesced (engine level)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline, HBM traffic
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(batch: int):
+    """LipReal.inference_batch on the host cores: the reference's own class from a LiveTalking checkout when one is
+    importable (kind "reference": build container), else the oracle restatement (kind "port": the GPU box).  fp32
+    torch CPU, all cores, seeded synthetic weights / bank / audio; median of 5 after one warm-up, B=batch and B=1."""
     import numpy as np
     import torch
     from livetalking_amd import synth
     from oracle import mel_oracle, plugin_oracle   # the checker, timed here as the CPU baseline only
     torch.set_num_threads(min(64, os.cpu_count() or 1))   # more threads only add contention on this model size
-    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(1234).items()}
+    sd_np = synth.wav2lip_state_dict(1234)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     frames, faces, coords = synth.wav2lip_avatar(n_frames=8, full_hw=(360, 640), box=160, seed=0)
     audio = synth.synthetic_audio(2.0)
-    feats = mel_oracle.mel_chunks(audio[: (20 + 2 * batch) * 320], 20 + 2 * batch)
-    plugin_oracle.inference_batch(sd, faces, 0, 1, feats[:1])  # warm-up (B=1)
-    n, t_total = 0, 0.0
-    while True:
-        t0 = time.perf_counter()
-        plugin_oracle.inference_batch(sd, faces, n * batch, batch, feats)
-        t_total += time.perf_counter() - t0
-        n += 1
-        if t_total >= budget_s * 0.5 or n >= 4:
-            break
-    return {"value": round(n * batch / t_total, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n} x inference_batch(B={batch}) fp32 torch-CPU oracle, seeded synthetic weights/bank/audio"}
+    kind, call = "port", None
+    if os.path.exists(os.path.join(REF_ROOT, "avatars", "wav2lip_avatar.py")):
+        try:
+            from oracle import ref_loop
+            cwd = os.getcwd()
+            ref_loop.enter_reference(REF_ROOT)
+            import avatars.wav2lip_avatar as ref_plugin
+            from avatars.wav2lip.models import Wav2Lip
+            os.chdir(cwd)
+            net = Wav2Lip().eval()
+            net.load_state_dict(sd)
+            lip = ref_plugin.LipReal.__new__(ref_plugin.LipReal)
+            lip.model = net
+            lip.frame_list_cycle, lip.face_list_cycle, lip.coord_list_cycle = frames, faces, coords
+
+            def call(index, B, feats):          # noqa: F811
+                lip.batch_size = B
+                return lip.inference_batch(index, feats)
+            kind = "reference"
+        except Exception:  # noqa: BLE001 - fall back to the port
+            call = None
+    if call is None:
+        def call(index, B, feats):
+            return plugin_oracle.inference_batch(sd, faces, index, B, feats)
+
+    def median_fps(B):
+        feats = mel_oracle.mel_chunks(audio[: (20 + 2 * B) * 320], 20 + 2 * B)
+        call(0, B, feats)
+        ts = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            call((i + 1) * B, B, feats)
+            ts.append(time.perf_counter() - t0)
+        return B / float(np.median(ts))
+
+    fb, f1 = median_fps(batch), median_fps(1)
+    what = "the reference's LipReal.inference_batch (avatars/wav2lip_avatar.py:116-139)" if kind == "reference" else \
+        "oracle port of LipReal.inference_batch"
+    return {"value": round(fb, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": f"median of 5 x {what}, B={batch}, fp32 torch-CPU, seeded synthetic weights/bank/audio",
+            "b1": {"value": round(f1, 3), "unit": "frames/s", "sample": "same, B=1 (BASELINE.json configs[0])"}}
+
+
+def measure_traffic(args):
+    """HBM bytes per conv-stack pass from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
+    and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), KiB
+    units.  Each pass profiles `bench.py --sub convpasses` (P conv-stack passes of the same workload)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    passes = 6
+    tot = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ltk_pmc_")
+        cmd = [exe, "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--sub", "convpasses",
+               "--sessions", str(args.sessions), "--batch", str(args.batch), "--steps", str(passes)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+        db = sqlite3.connect(dbs[0])
+        names = [t[0] for t in db.execute("select name from sqlite_master where type in ('table','view')")]
+        view = "counters_collection" if "counters_collection" in names else None
+        if view is None:
+            return None, "no counters_collection view in the rocprofv3 database"
+        v = 0.0
+        for k, c, val in db.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+            if c == counter and "conv" in k and "finish" not in k or (c == counter and "conv3_finish" in k):
+                v += float(val)
+        tot[counter] = v
+        shutil.rmtree(d, ignore_errors=True)
+    # the sub-run executes `passes` timed passes + 1 warm pass of the conv stack and nothing else
+    n = passes + 1
+    rd = tot["FETCH_SIZE"] * 1024.0 * 2.0 / n
+    wr = tot["WRITE_SIZE"] * 1024.0 / n
+    return rd + wr, {"read_bytes": rd, "write_bytes": wr, "passes_profiled": n,
+                     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), conv kernels only, FETCH_SIZE x2 (gfx950), KiB units"}
+
+
+def sub_convpasses(args):
+    """Body profiled by measure_traffic: K passes of the conv stack, nothing else."""
+    from livetalking_amd import synth
+    from livetalking_amd.engine import Engine
+    nf = min(args.sessions * args.batch, 256)
+    eng = Engine(0)
+    eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=nf)
+    eng.time_convs(nf, args.steps)
+    eng.close()
+
+
+def run_sub(name, extra, timeout=600):
+    cmd = [sys.executable, os.path.abspath(__file__), "--sub", name] + extra
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"{name}: timed out after {timeout} s"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{") or line.startswith("["):
+            try:
+                return json.loads(line)
+            except Exception:  # noqa: BLE001
+                pass
+    return {"error": f"{name}: rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+
+
+def dry_rank(args, ranks: Ranks):
+    """The launcher / barrier / max-over-ranks protocol without a GPU: rank r 'works' 10 ms x (r + 1) per step."""
+    ranks.barrier(sync_gpu=False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (ranks.rank + 1))
+    own = time.perf_counter() - t0
+    ranks.barrier(sync_gpu=False)
+    elapsed = time.perf_counter() - t0
+    mx, _ = ranks.gather_max(elapsed)
+    _, per_rank = ranks.gather_max(own)
+    if ranks.rank == 0:
+        return {"metric": "dry-ranks", "n_gpus": ranks.world, "steps": args.steps, "ms_per_step": round(mx / args.steps * 1e3, 3),
+                "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank], "ranks_seen": len(per_rank)}
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sessions", type=int, default=1, help="sessions per GPU, each with its own inference thread")
+    ap.add_argument("--batch", type=int, default=16, help="frames per session per step (opt.batch_size)")
+    ap.add_argument("--model", choices=("wav2lip", "musetalk"), default="wav2lip",
+                    help="wav2lip = BASELINE.json configs[1] (default, the driver's line); musetalk = configs[2]")
+    ap.add_argument("--fp8", action="store_true", help="musetalk: BASELINE configs[4] fp8 conv path")
+    ap.add_argument("--paced", type=int, default=0, help="after the timed run: N periods of B/25 s with every session paced at 25 fps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
+    ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.sub == "convpasses":
+        return sub_convpasses(args)
+    if args.sub == "paced-capacity":
+        print(json.dumps(paced_capacity(args)), flush=True)
+        return
+    if args.sub == "musetalk-both":        # configs[2] then configs[4]'s share in one process: the synthetic weights are made once
+        ranks = Ranks()
+        shared = {}
+        a2 = argparse.Namespace(**vars(args)); a2.sessions, a2.fp8, a2.steps, a2.warmup = 1, False, 4, 2
+        o2 = run_musetalk(a2, ranks, shared)
+        a4 = argparse.Namespace(**vars(args)); a4.sessions, a4.fp8, a4.steps, a4.warmup = 4, True, 3, 1
+        o4 = run_musetalk(a4, ranks, shared)
+        print(json.dumps([o2, o4]), flush=True)
+        return
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    ranks = Ranks()
+    if ranks.world != args.gpus and ranks.rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ranks.world}: using WORLD_SIZE", file=sys.stderr)
+    if args.dry_ranks:
+        out = dry_rank(args, ranks)
+    elif args.model == "musetalk":
+        out = run_musetalk(args, ranks)
+    else:
+        out = run_wav2lip(args, ranks)
+    ranks.close()
+    if ranks.rank != 0 or out is None:
+        return
+    primary = not args.sub and not args.dry_ranks
+    if primary and ranks.world == 1 and args.model == "wav2lip":
+        if not args.no_traffic:
+            traffic, info = measure_traffic(args)
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_unit"] = "HBM bytes per conv-stack pass"
+            out["roofline"]["traffic_info"] = info
+        if not args.no_also:
+            mt = run_sub("musetalk-both", ["--batch", str(args.batch)])
+            also = [run_sub("also-w2l16", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "3", "--paced", "4"])]
+            also += mt if isinstance(mt, list) else [mt]
+            tags = ["configs[3] per-GPU share: 16 wav2lip256 sessions on one GPU (16 session threads, continuous batching)",
+                    "configs[2]: MuseTalk, 1 session", "configs[4] per-GPU share: 4 MuseTalk sessions, fp8 conv path"]
+            for a, t in zip(also, tags):
+                if isinstance(a, dict):
+                    a["baseline_config"] = t
+            out["also"] = also
+            out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
+            w16 = also[0] if isinstance(also[0], dict) else {}
+            out["sessions_25fps"] = {"per_gpu_sustained": out["paced"].get("max_sessions_25fps"),
+                                     "at_16_sessions_per_gpu": w16.get("paced"),
+                                     "note": "per_gpu_sustained: paced bisection (engine level); at_16_sessions_per_gpu: 16 paced session threads through LipReal.inference_batch"}
+    if primary and ranks.world == 1 and not args.no_cpu_baseline:         # the CPU baseline is timed at N=1 only
+        out["cpu_baseline"] = cpu_baseline(args.batch) if args.model == "wav2lip" else cpu_baseline_musetalk()
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline_musetalk(budget_s: float = 25.0):
@@ -77,257 +677,6 @@ def cpu_baseline_musetalk(budget_s: float = 25.0):
                 break
     return {"value": round(n / t_total, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} x inference_batch(B=1) fp32 torch-CPU oracle (U-Net + VAE decoder), seeded synthetic weights"}
-
-
-def main_musetalk(args):
-    """BASELINE.json configs[2]: MuseTalk (Whisper audio feat + U-Net + VAE decoder), 1 session, 1 GPU.  A step =
-    one MuseReal.inference_batch-equivalent pass (latent gather + PE + U-Net + VAE decode + uint8 BGR) over
-    sessions x batch frames with latents, weights and whisper chunks resident in HBM; the Whisper step
-    (run_step's work, outside inferfps in the reference too) is timed separately."""
-    import numpy as np
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    from livetalking_amd import synth
-    from livetalking_amd.engine import Engine
-
-    S, B = args.sessions, args.batch
-    fps_step = S * B
-    eng = Engine(local_rank)
-    eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=min(fps_step, 64), fp8=args.fp8)
-    macs_all, macs_fp8 = eng.musetalk_info()
-    n = 8
-    lats = synth.musetalk_latents(n)
-    frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(720, 1280), box=320, seed=0)
-    coords = [(480, 200, 800, 520)] * n
-    crops = [(400, 120, 880, 600)] * n
-    masks = [np.full((480, 480, 3), 128, np.uint8)] * n
-    aid = eng.register_musetalk_avatar(lats, frames, coords, masks, crops)
-    d_feat = torch.from_numpy(synth.musetalk_whisper_feats(fps_step)).cuda().reshape(S, B, 50, 384)
-    d_pred = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
-
-    def step(i):
-        eng.musetalk_infer([(aid, i * B + 3 * s, B, d_feat[s].data_ptr(), d_pred[s].data_ptr()) for s in range(S)])
-
-    for i in range(args.warmup):
-        step(i)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * args.steps * fps_step / elapsed
-    nt = min(fps_step, 64)
-    ms, macs = eng.musetalk_time(nt, 3)
-    achieved = 2.0 * macs / (ms * 1e-3) / 1e12
-    # WhisperASR.run_step's feature work (log-mel + whisper-tiny encoder + chunk slicing) for one session's 0.64-s step: the
-    # reference runs it on the render thread, outside inferfps (base_avatar.py:364-373 times inference_batch only); reported
-    # beside it because BASELINE configs[2] names it
-    eng.load_whisper(synth.whisper_encoder_state_dict())
-    pcm = synth.synthetic_audio(2.0)[: (20 + 2 * B) * 320]
-    d_chunks = torch.zeros(B, 50, 384, dtype=torch.float32, device="cuda")
-    for _ in range(2):
-        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
-    torch.cuda.synchronize()
-    tw = time.perf_counter()
-    for _ in range(5):
-        eng.whisper_step(pcm, B, first_row=10, d_out_ptr=d_chunks.data_ptr())
-    torch.cuda.synchronize()
-    whisper_ms = (time.perf_counter() - tw) / 5 * 1e3
-    if rank == 0:
-        out = {"metric": "inferfps", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "fp8(e4m3)+f16" if args.fp8 else "f16", "data": "synthetic",
-               "config": {"workload": f"musetalk (U-Net + VAE decoder), {S} session(s)/GPU, {B}-frame batch, " +
-                                      (f"fp8 e4m3 operands on the resnet 3x3 convs ({macs_fp8 / macs_all:.0%} of the MACs), fp16 elsewhere, fp32 accumulate"
-                                       if args.fp8 else "fp16 activations / fp32 accumulate"),
-                          "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": fps_step,
-                          "parallelism": f"session-sharded x{world} (no collective)"},
-               "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
-                            "kernel": "conv3_kernel / conv_mfma_kernel (U-Net + VAE conv and linear layers; attention excluded from the flop count)",
-                            "pass_ms": round(ms, 4), "flops_per_frame": 2.0 * macs / nt}}
-        out["whisper"] = {"ms_per_session_step": round(whisper_ms, 3), "frames_per_step": B,
-                          "note": "log-mel + whisper-tiny encoder (1500 tokens) + chunk slicing, host PCM in, device features out; not in `value`",
-                          "fps_incl_whisper": round(fps_step / (elapsed / args.steps + S * whisper_ms * 1e-3), 2)}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_musetalk()
-        print(json.dumps(out), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sessions", type=int, default=1, help="sessions coalesced per launch on each GPU")
-    ap.add_argument("--batch", type=int, default=16, help="frames per session per step (opt.batch_size)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--paced", type=int, default=0, help="wav2lip: after the timed run, N periods of B/25 s with all sessions paced at 25 fps")
-    ap.add_argument("--fp8", action="store_true", help="musetalk: BASELINE configs[4] fp8 conv path (non-scaled fp8 MFMA = the fp16 MFMA rate, so the roofline peak stays 2.5 PF)")
-    ap.add_argument("--model", choices=("wav2lip", "musetalk"), default="wav2lip",
-                    help="wav2lip = BASELINE.json configs[1] (default, the driver's line); musetalk = configs[2]")
-    args = ap.parse_args()
-    if args.model == "musetalk":
-        return main_musetalk(args)
-
-    import numpy as np
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-
-    from livetalking_amd.engine import Engine
-    from livetalking_amd import synth  # seeded synthetic input generators (product-side; nothing from oracle/)
-
-    S, B = args.sessions, args.batch
-    frames_per_step = S * B
-    if frames_per_step > 256:
-        os.environ.setdefault("LTK_MICROBATCH", "256")     # activation arena for 256 frames; larger steps run as micro-batches
-    eng = Engine(local_rank)
-    call_sessions = max(1, min(S, 4096 // B))              # ltk_wav2lip_infer takes up to 4096 frames per call
-    eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=call_sessions * B)
-    frames, faces, coords = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
-    aid = eng.register_avatar(faces, frames, coords)
-    # mel windows resident in HBM: one (B,80,16) block per session, made by the HIP mel kernel
-    audio = synth.synthetic_audio(4.0)
-    n_chunks = 20 + 2 * B
-    starts = [int(16 + i * 3.2) for i in range(B)]
-    d_mel = torch.zeros(S, B, 80, 16, dtype=torch.float32, device="cuda")
-    for s in range(S):
-        off = (s * 977) % (len(audio) - n_chunks * 320)
-        eng.mel_step(audio[off: off + n_chunks * 320], starts, d_mel[s].data_ptr())
-    d_pred = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
-
-    def step(i):
-        reqs = [(aid, i * B + 7 * s, B, d_mel[s].data_ptr(), d_pred[s].data_ptr()) for s in range(S)]
-        for j in range(0, S, call_sessions):
-            eng.wav2lip_infer(reqs[j:j + call_sessions])
-
-    for i in range(args.warmup):
-        step(i)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total_frames = world * args.steps * frames_per_step
-    value = total_frames / elapsed
-
-    # --paced: SURVEY.md 8(d)'s second accounting.  Every session asks for its next B frames once per B/25 s (what a
-    # 25 fps render loop does); all S requests of a period go down as one coalesced call.  A period's latency is the
-    # time from its due time to the last frame being ready: the session count is sustainable if it stays below the
-    # period.  Not part of the timed region above.
-    paced = None
-    if args.paced > 0:
-        period = B / 25.0
-        lat = []
-        tp0 = time.perf_counter() + 0.05
-        for i in range(args.paced):
-            due = tp0 + i * period
-            while time.perf_counter() < due:
-                time.sleep(0.0005)
-            step(args.warmup + args.steps + i)          # returns when the frames are ready (ltk_wav2lip_infer is synchronous)
-            lat.append(time.perf_counter() - due)
-        paced = {"sessions": S, "fps_per_session": 25, "periods": args.paced, "period_ms": period * 1e3,
-                 "latency_ms_mean": round(1e3 * sum(lat) / len(lat), 2), "latency_ms_max": round(1e3 * max(lat), 2),
-                 "sustained": bool(max(lat) < period)}
-
-    # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass): HIP events on
-    # the engine's own stream around the conv stack only (no gather/pack, no head), averaged over 10 passes
-    # of the same workload.  One "launch" below = one pass of the conv stack over frames_per_step frames.
-    conv_ms, conv_macs = eng.time_convs(min(frames_per_step, call_sessions * B), 10)
-    achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
-    # HBM bytes per pass from the committed rocprofv3 PMC summary of this same command
-    # (scripts/gpu_profile.sh -> scripts/make_profile_summary.py): separate --pmc passes, FETCH_SIZE doubled
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            pm = json.load(f)
-        if int(pm.get("frames_per_pass", -1)) == frames_per_step:
-            traffic = float(pm["hbm_bytes_per_pass"])
-    except Exception:  # noqa: BLE001 - the summary is optional
-        traffic = None
-
-    if rank == 0:
-        out = {
-            "metric": "inferfps",
-            "value": round(value, 2),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16",
-            "data": "synthetic",
-            "config": {"workload": f"wav2lip256, {S} session(s)/GPU, {B}-frame batch, fp16 activations / fp32 accumulate",
-                       "sessions_per_gpu": S, "batch": B, "frames_per_step_per_gpu": frames_per_step,
-                       "parallelism": f"session-sharded x{world} (no collective)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc.json)",
-                         "kernel": "conv3_kernel + conv_mfma_kernel (the 54 conv/convT layers = one pass)",
-                         "conv_stack_ms": round(conv_ms, 4), "flops_per_frame": 2 * (MACS_PER_FRAME - HEAD_MACS)},
-        }
-        # BASELINE.json's second figure: sessions a GPU sustains at 25 fps each.  A step of S coalesced sessions must finish
-        # within the 0.64 s its 16 frames last (base_avatar.py:364-373 accounting), so the bound is throughput / 25 as long
-        # as the step latency stays below that.
-        step_ms = elapsed / args.steps * 1e3
-        out["sessions_25fps"] = {"per_gpu": int(value / world // 25), "step_latency_ms": round(step_ms, 3),
-                                 "latency_budget_ms": 1000.0 * B / 25, "note": "unpaced saturating rate / 25 fps"}
-        if paced is not None:
-            out["paced"] = paced
-        if not args.no_cpu_baseline and world == 1:         # the CPU baseline is timed at N=1 only
-            out["cpu_baseline"] = cpu_baseline(B)
-        print(json.dumps(out), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -243,6 +243,15 @@ int ltk_debug_set_knob(const char* name, int value);
  * MACs one pass executes (27,788,599,296 x frames for wav2lip256). */
 int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
 
+/* Per-layer view of the same pass (tuning / profiling): layer names in execution order (state_dict prefixes), the time
+ * of every layer inside a whole pass on one stream (HIP events between consecutive launches, so a layer sees the cache
+ * state its predecessor left, not the hot loop of an isolated microbenchmark), and the engine's per-layer tile table:
+ * bucket 0..4 = launches of <= 16 / 32 / 64 / 128 / more frames; pxw in {0,1,2,4}, nbt in {0,1,2}, ksplit >= 0; 0 = rule. */
+int ltk_wav2lip_layer_count(ltk_engine* e);
+int ltk_wav2lip_layer_name(ltk_engine* e, int layer, char* buf, int buf_len);
+int ltk_wav2lip_set_layer_tile(ltk_engine* e, int layer, int bucket, int pxw, int nbt, int ksplit);
+int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_layer, int n_layers);
+
 /* Generic standalone fp16 conv used by kernel unit tests and per-layer timing.  Activations are in the engine's
  * channel-blocked layout: x device fp16 [N][Cin/16][H][W][16] ([N][H][W][8] when Cin <= 8), res / y device fp16
  * [N][Cout/16][Ho][Wo][16]; weight host fp32 torch layout ([Cout][Cin][kh][kw], or [Cin][Cout][kh][kw] when

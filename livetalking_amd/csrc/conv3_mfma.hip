@@ -748,9 +748,11 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     // tile selection (does not change any output element's summation order)
     int NBT = (G == 4) ? 1 : ((p.lCout >= 64) ? 2 : 1);
     int PXW = (G == 1 && T == 9 && NC8 == 2 && S == 1) ? 4 : 2;
-    const int kn_pxw = knob(K_CONV_PXW), kn_nbt = knob(K_CONV3_NBT);      // tuning sweeps only (0 = heuristic)
-    if (kn_pxw == 2 || (kn_pxw == 1 && G == 1 && T == 9 && S == 1)) PXW = kn_pxw;
+    // a caller's per-layer choice wins over the sweep knobs; 0 = the rule below
+    const int kn_pxw = io.force_pxw ? io.force_pxw : knob(K_CONV_PXW), kn_nbt = io.force_nbt ? io.force_nbt : knob(K_CONV3_NBT);
+    if (kn_pxw == 2 || (kn_pxw == 1 && G == 1 && T == 9 && S == 1) || (kn_pxw == 4 && PXW == 4)) PXW = kn_pxw;
     if (kn_nbt == 1) NBT = 1;
+    const bool forced_tile = io.force_pxw != 0 && io.force_nbt != 0;
     int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0;
     long long blocks = 0;
     auto geom = [&](int pxw) -> bool {
@@ -772,7 +774,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S, T) * 256 && npix < 32768;
     };
     bool fit;
-    if (G == 1 && T == 9 && S == 1 && kn_pxw == 0 && kn_nbt == 0) {
+    if (G == 1 && T == 9 && S == 1 && kn_pxw == 0 && kn_nbt == 0 && knob(K_TILE_RULE)) {
         // 3x3 stride 1: the largest tile that still gives the chip ~1.5 items per CU.  Measured per layer and frame count
         // (scripts/conv_sweep2.py, profiles/r02_conv_sweep.txt): with fewer items a launch runs one wave per SIMD and
         // cannot hide its own DMA latency -- at 16 frames 128 ch @32^2 takes 22.8 us as 128 items of 256 px x 64 ch and
@@ -791,19 +793,20 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
         fit = geom(PXW);
         if (PXW == 4) {
             const long long nt = (p.lCout + 32 * NBT - 1) / (32 * NBT);
-            if (!fit || blocks * nt < knob(K_CONV_PXW4_MIN)) { PXW = 2; fit = geom(PXW); }
+            if (!fit || (!forced_tile && blocks * nt < knob(K_CONV_PXW4_MIN))) { PXW = 2; fit = geom(PXW); }
         }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
     if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && (kn_nbt == 0 || kn_nbt == 4)) NBT = 4;
-    if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128 && !(G == 1 && T == 9 && S == 1)) NBT = 1;
+    if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < 128 && !(G == 1 && T == 9 && S == 1 && knob(K_TILE_RULE)) && !forced_tile) NBT = 1;
     const int BN = NBT * 32;
     a.n_ntiles = (p.lCout + BN - 1) / BN;
     a.ablate = LTK_ABLATE_BUILD ? knob(K_ABLATE) : 0;
     // LTK_SPLITK=0: never split (batch-size independent summation order); LTK_KSPLIT=n forces a factor (sweeps)
-    int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks, T == 1 ? 0 : (G == 4 ? 8 : 4)) : 1;
-    if (knob(K_KSPLIT) > 0) ksplit = std::max(1, std::min(std::min(knob(K_KSPLIT), kMaxKSplit), a.nchunks));
+    int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks, (T == 1 || !knob(K_TILE_RULE)) ? 0 : (G == 4 ? 8 : 4)) : 1;
+    const int fks = io.force_ksplit ? io.force_ksplit : knob(K_KSPLIT);
+    if (fks > 0 && knob(K_SPLITK)) ksplit = std::max(1, std::min(std::min(fks, kMaxKSplit), a.nchunks));
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
     }

@@ -110,6 +110,7 @@ struct ConvIO {
     int act = 0;                   // epilogue activation when relu == 0: 0 none, 2 GELU (erf), 3 SiLU
     int ups = 0;                   // conv3 only: the input map is H/2 x W/2 and is read through a nearest-neighbour
                                    // 2x upsample (diffusers Upsample2D: F.interpolate(scale_factor=2) then conv)
+    int force_pxw = 0, force_nbt = 0, force_ksplit = 0;   // conv3: per-layer tile / split choice of the caller's table (0 = rule)
     const float* head_w = nullptr;     // conv3, 3x3 stride-1 layers of 32 output channels only: fuse the Wav2Lip output head
     const void* head_outs = nullptr;   // (1x1 conv 32->3 + sigmoid + uint8 truncation; wav2lip_v2.py:90-91): device [3][32]+[3]
                                        // weights and an OutPtrs (misc_kernels.h) of per-frame uint8 [256][256][3] outputs; `y` unused

@@ -570,8 +570,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
             // 16-channel chunks everywhere: measured (profiles/r02_conv_sweep.txt) equal or better than 32-channel chunks on
             // every 3x3 layer at 16 frames and 25-28 % better on the 256/512-channel 8^2..16^2 maps at 256 frames (the
             // smaller stage leaves room for two resident blocks and allows 512-pixel tiles)
-            NC8 = 2;
-            (void)hint_hw;
+            NC8 = knob(K_TILE_RULE) ? 2 : ((Cin % 32 != 0 || hint_hw >= 1024 || hint_hw == 0) ? 2 : 4);     // 0: round-1 rule (A/B)
             if (knob(K_CONV3_NC8) == 2 || (knob(K_CONV3_NC8) == 4 && Cin % 32 == 0)) NC8 = knob(K_CONV3_NC8);
         }
         if (p->v3_S == 2) NC8 = 2;

@@ -129,7 +129,39 @@ struct Layer {
     bool res_folded = false;   // the identity branch lives in the centre tap of the packed weights
     bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
     double macs = 0;  // per frame
+    // measured tile / split choice per frame-count bucket (<= 16, 32, 64, 128, 256+ frames per launch); 0 = conv3's rule
+    struct Tile { signed char pxw = 0, nbt = 0, ks = 0; } tile[5];
 };
+
+int frame_bucket(int nf) { return nf <= 16 ? 0 : nf <= 32 ? 1 : nf <= 64 ? 2 : nf <= 128 ? 3 : 4; }
+
+// Per-layer tile / split choices that beat conv3's rule inside a whole pass (scripts/tile_tune.py on MI355X,
+// profiles/r02_tile_tune.txt: every layer timed between its neighbours, so with the cache state they leave).  Tiles never
+// change an output element's summation order; the few split entries replace the split the rule would have chosen.
+struct TileEntry { const char* layer; int bucket, pxw, nbt, ks; };
+const TileEntry kTileTable[] = {
+    // <= 16 frames per launch
+    {"face_encoder_blocks.5.1", 0, 2, 1, 0},     // 512 ch @ 8^2: 27.7 -> 22.6 us (half the weight-slab re-reads of 128-px tiles)
+    {"face_decoder_blocks.2.1", 0, 2, 1, 0},     // 512 ch @ 8^2: 28.1 -> 22.9 us
+    {"face_encoder_blocks.6.0", 0, 0, 0, 8},     // 512 -> 512 stride 2 @ 8^2: 20.7 -> 18.1 us
+    {"face_decoder_blocks.1.0", 0, 0, 0, 4},     // convT 4x4 on the 1x1 map: 20.9 -> 18.0 us
+    {"audio_encoder.7", 0, 0, 0, 1},             // 128 ch @ 9x6: 14.1 -> 12.0 us unsplit
+    {"audio_encoder.8", 0, 0, 0, 1},
+    // <= 64 frames per launch
+    {"face_decoder_blocks.4.1", 2, 2, 2, 0},     // 384 ch @ 32^2: 182 -> 150 us
+    {"face_decoder_blocks.4.2", 2, 2, 2, 0},
+    {"face_encoder_blocks.5.0", 2, 2, 1, 0},     // 256 -> 512 stride 2: 33.6 -> 26.5 us
+    {"face_encoder_blocks.6.1", 2, 1, 2, 0},     // 512 ch @ 4^2: 29.0 -> 24.3 us
+    {"face_decoder_blocks.1.1", 2, 1, 2, 0},     // 512 ch @ 4^2: 29.4 -> 23.2 us
+    {"face_decoder_blocks.1.0", 2, 0, 0, 4},
+};
+
+void apply_tile_table_impl(std::vector<Layer>& layers) {
+    for (const TileEntry& t : kTileTable)
+        for (Layer& L : layers)
+            if (L.name == t.layer) { L.tile[t.bucket].pxw = (signed char)t.pxw; L.tile[t.bucket].nbt = (signed char)t.nbt; L.tile[t.bucket].ks = (signed char)t.ks; }
+}
+
 
 struct Avatar {
     uint8_t* d_face = nullptr;
@@ -440,6 +472,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
     CHK(hipMemcpy(e->d_head, h.data(), 99 * sizeof(float), hipMemcpyHostToDevice));
     e->macs_per_frame = 32.0 * 3 * 65536;
     for (const Layer& L : e->layers) e->macs_per_frame += L.macs;
+    apply_tile_table_impl(e->layers);
     return 0;
 }
 
@@ -450,9 +483,12 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // the aux stream beside the face encoder instead of in front of it.
 // `head_outs` != nullptr: the last layer (output_block.0) also applies the 1x1 head + sigmoid and writes the uint8 frames
 // (one launch and one 4 MB/frame round trip of the 32-channel map less); the caller then skips launch_head.
-int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr) {
+// `evs` != nullptr (measurement): everything on `s`, one event in front of every layer and one behind the last.
+int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr) {
     std::string err;
-    const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM);
+    const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM) && !evs;
+    const int bucket = frame_bucket(nf);
+    size_t evi = 0;
     bool joined = !fork;
     if (fork) {
         CHK(hipEventRecord(e->ev_fork, s));
@@ -488,6 +524,8 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         io.partial = on_aux ? e->d_partial_aux : e->d_partial;
         io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;
         if (head_outs && Lp == &e->layers.back()) { io.head_w = e->d_head; io.head_outs = head_outs; }
+        if (knob(K_TILE_TABLE)) { io.force_pxw = L.tile[bucket].pxw; io.force_nbt = L.tile[bucket].nbt; io.force_ksplit = L.tile[bucket].ks; }
+        if (evs) CHK(hipEventRecord((*evs)[evi++], s));
         int rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
         if (e->capture) {
@@ -507,6 +545,7 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         CHK(hipEventRecord(e->ev_join, e->aux));
         CHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
+    if (evs) CHK(hipEventRecord((*evs)[evi++], s));
     return 0;
 }
 
@@ -900,6 +939,61 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - (fused ? 0.0 : 32.0 * 3 * 65536)) * frames;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (d_frames) (void)hipFree(d_frames);
+    return LTK_OK;
+}
+
+int ltk_wav2lip_layer_count(ltk_engine* e) {
+    if (!e || !e->loaded) return 0;
+    return (int)e->layers.size();
+}
+
+int ltk_wav2lip_layer_name(ltk_engine* e, int layer, char* buf, int buf_len) {
+    if (!e || !e->loaded || layer < 0 || layer >= (int)e->layers.size() || !buf || buf_len <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    snprintf(buf, (size_t)buf_len, "%s", e->layers[layer].name.c_str());
+    return LTK_OK;
+}
+
+int ltk_wav2lip_set_layer_tile(ltk_engine* e, int layer, int bucket, int pxw, int nbt, int ksplit) {
+    if (!e || !e->loaded || layer < 0 || layer >= (int)e->layers.size() || bucket < 0 || bucket > 4) return fail(LTK_E_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> g(e->mu);
+    Layer::Tile& t = e->layers[layer].tile[bucket];
+    t.pxw = (signed char)pxw; t.nbt = (signed char)nbt; t.ks = (signed char)ksplit;
+    return LTK_OK;
+}
+
+int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_layer, int n_layers) {
+    if (!e || frames <= 0 || iters <= 0 || !ms_per_layer) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
+    if (frames > e->micro_batch || frames > kPackMaxFrames) return fail(LTK_E_INVALID, "frames exceeds one arena pass");
+    if (n_layers != (int)e->layers.size()) return fail(LTK_E_INVALID, "n_layers != ltk_wav2lip_layer_count");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
+    std::vector<hipEvent_t> evs(e->layers.size() + 1);
+    for (auto& ev : evs) CHK(hipEventCreate(&ev));
+    uint8_t* d_frames = nullptr;
+    OutPtrs op;
+    const bool fused = knob(K_HEAD_FUSED) != 0;
+    if (fused) {
+        CHK(hipMalloc((void**)&d_frames, (size_t)frames * 65536 * 3));
+        for (int i = 0; i < kPackMaxFrames; ++i) op.p[i] = i < frames ? d_frames + (size_t)i * 65536 * 3 : nullptr;
+    }
+    std::vector<double> acc(e->layers.size(), 0.0);
+    int rc = run_convs(e, frames, e->compute, fused ? &op : nullptr);     // warm
+    for (int it = 0; it < iters && !rc; ++it) {
+        rc = run_convs(e, frames, e->compute, fused ? &op : nullptr, &evs);
+        if (rc) break;
+        CHK(hipEventSynchronize(evs.back()));
+        for (size_t i = 0; i < e->layers.size(); ++i) {
+            float ms = 0.f;
+            CHK(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto& ev : evs) (void)hipEventDestroy(ev);
+    if (d_frames) (void)hipFree(d_frames);
+    if (rc) return rc;
+    for (size_t i = 0; i < e->layers.size(); ++i) ms_per_layer[i] = (float)(acc[i] / iters);
     return LTK_OK;
 }
 

@@ -27,6 +27,8 @@ enum Knob {
     K_SPLITK_FUSED,       // LTK_SPLITK_FUSED   1: the last-arriving block of a split-K group reduces the slabs (no finish launch)
     K_HEAD_FUSED,         // LTK_HEAD_FUSED     1: output_block conv 80->32 + 1x1 head + sigmoid in one launch
     K_CONV3_NC8,          // LTK_CONV3_NC8      conv3 3x3: channel planes per chunk (2 = 16 channels, 4 = 32); 0 = by map size
+    K_TILE_RULE,          // LTK_TILE_RULE      conv3 3x3 tile selection: 1 = items-per-CU rule (round 2), 0 = round-1 heuristic (A/B)
+    K_TILE_TABLE,         // LTK_TILE_TABLE     1: use the engine's per-layer measured tile table where it has an entry
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
     K_COUNT
 };

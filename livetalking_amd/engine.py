@@ -295,6 +295,24 @@ class Engine:
         _lib.check(self._lib.ltk_debug_get(self._h, layer.encode(), out.ctypes.data, out.size))
         return out
 
+    def layer_names(self):
+        n = self._lib.ltk_wav2lip_layer_count(self._h)
+        out = []
+        for i in range(n):
+            buf = C.create_string_buffer(96)
+            _lib.check(self._lib.ltk_wav2lip_layer_name(self._h, i, buf, 96))
+            out.append(buf.value.decode())
+        return out
+
+    def set_layer_tile(self, layer: int, bucket: int, pxw: int = 0, nbt: int = 0, ksplit: int = 0):
+        _lib.check(self._lib.ltk_wav2lip_set_layer_tile(self._h, int(layer), int(bucket), int(pxw), int(nbt), int(ksplit)))
+
+    def time_layers(self, frames: int, iters: int) -> np.ndarray:
+        n = self._lib.ltk_wav2lip_layer_count(self._h)
+        ms = (C.c_float * n)()
+        _lib.check(self._lib.ltk_wav2lip_time_layers(self._h, int(frames), int(iters), ms, n))
+        return np.array(ms[:], dtype=np.float64)
+
     def time_convs(self, frames: int, iters: int):
         ms = C.c_float()
         macs = C.c_double()

@@ -4,6 +4,7 @@ PCM chunks in -> composited uint8 frames out, compared with the oracle chain
 reference's render/inference/process_frames loops (avatars/base_avatar.py:337-376,
 :433, :487-494)."""
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -62,3 +63,101 @@ def test_lipreal_headless_render_loop():
         index += B
         pcm_hist = pcm_hist[-20:]
     model.engine.close()
+
+
+def _psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    m = float((d * d).mean())
+    return 99.0 if m == 0 else 10 * np.log10(255.0 ** 2 / m)
+
+
+@pytest.mark.gpu
+def test_file_format_legs_checkpoint_and_avatar_dir(tmp_path, monkeypatch):
+    """W9 / 8(f)-1 end to end on the GPU path: load_model(path) on a checkpoint FILE in the reference's format
+    ({"state_dict": {"module.<name>": tensor}}, wav2lip_avatar.py:51-70) and load_avatar(id) on a directory in genavatar's
+    layout (full_imgs/%08d.png, face_imgs/%08d.png, coords.pkl; wav2lip/genavatar.py:124-138) packed to bank.ltkbank,
+    then a render step; frames must equal the ones from the in-memory state dict / in-memory bank bit for bit."""
+    import pickle
+    from PIL import Image
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd import bank
+
+    sd_np = synth.wav2lip_state_dict(1234)
+    ckpt = {"state_dict": {"module." + k: torch.from_numpy(v) for k, v in sd_np.items()}}
+    # BatchNorm's num_batches_tracked entries exist in a real checkpoint (SURVEY 8a-W5: 380 tensors): they must be ignored
+    for k in list(ckpt["state_dict"]):
+        if k.endswith("running_var"):
+            ckpt["state_dict"][k.replace("running_var", "num_batches_tracked")] = torch.tensor(1000)
+    os.makedirs(tmp_path / "models")
+    path = str(tmp_path / "models" / "wav2lip.pth")
+    torch.save(ckpt, path)
+
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=4, full_hw=(180, 320), box=96, seed=5)
+    adir = tmp_path / "data" / "avatars" / "avt1"
+    os.makedirs(adir / "full_imgs"); os.makedirs(adir / "face_imgs")
+    for i in range(4):
+        Image.fromarray(np.ascontiguousarray(frames[i][..., ::-1])).save(adir / "full_imgs" / f"{i:08d}.png")     # cv2.imwrite stores BGR arrays as RGB files
+        Image.fromarray(np.ascontiguousarray(faces[i][..., ::-1])).save(adir / "face_imgs" / f"{i:08d}.png")
+    with open(adir / "coords.pkl", "wb") as f:
+        pickle.dump(coords, f)
+    bank.pack_avatar_dir(str(adir))
+    monkeypatch.chdir(tmp_path)                                     # load_avatar reads ./data/avatars/<id>
+    monkeypatch.setenv("LTK_DEVICES", "0")
+
+    model = plugin.load_model(path, max_frames=8)                   # the torch.load(path)["state_dict"] leg
+    avatar = plugin.load_avatar("avt1")                             # the .ltkbank leg
+    assert len(avatar[0]) == 4 and all(np.array_equal(a, b) for a, b in zip(avatar[1], faces))
+    B = 4
+    opt = argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=0)
+    sess = plugin.LipReal(opt, model, avatar)
+    feat = torch.from_numpy(np.random.default_rng(0).standard_normal((B, 80, 16)).astype(np.float32)).cuda()
+    got = torch.stack(sess.inference_batch(2, feat)).cpu().numpy()
+    outs = [sess.paste_back_frame(sess.inference_batch(2, feat)[i], plugin.mirror_index(4, 2 + i)) for i in range(B)]
+
+    model2 = plugin.load_model(None, state_dict=sd_np, max_frames=8)
+    sess2 = plugin.LipReal(opt, model2, (frames, faces, coords))
+    ref = torch.stack(sess2.inference_batch(2, feat)).cpu().numpy()
+    assert np.array_equal(got, ref)
+    for i in range(B):
+        idx = plugin.mirror_index(4, 2 + i)
+        assert np.array_equal(outs[i], sess2.paste_back_frame(sess2.inference_batch(2, feat)[i], idx))
+    for m in (model, model2):
+        for e in m.engines:
+            e.close()
+
+
+@pytest.mark.gpu
+def test_two_engines_two_sessions_render_concurrently(monkeypatch):
+    """8(e) inside one process: LTK_DEVICES=0,0 builds two engines (here on the same GPU); two sessions land on different
+    engines and render the same request concurrently from two threads: identical frames, each engine touched once."""
+    import threading
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    monkeypatch.setenv("LTK_DEVICES", "0,0")
+    sd_np = synth.wav2lip_state_dict(1234)
+    model = plugin.load_model(None, state_dict=sd_np, max_frames=8)
+    assert len(model.engines) == 2 and model.engines[0] is not model.engines[1]
+    plugin.warm_up(4, model, 256)
+    avatar = synth.wav2lip_avatar(n_frames=5, full_hw=(360, 640), box=160, seed=0)
+    B = 4
+    opt = argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=0)
+    s0, s1 = plugin.LipReal(opt, model, avatar), plugin.LipReal(opt, model, avatar)
+    assert (s0._slot, s1._slot) == (0, 1) and s0.engine is not s1.engine
+    feat = torch.from_numpy(np.random.default_rng(1).standard_normal((B, 80, 16)).astype(np.float32)).cuda()
+    res = {}
+
+    def run(name, s):
+        frames = []
+        for step in range(3):
+            pred = s.inference_batch(step * B, feat)
+            frames += [s.paste_back_frame(pred[i], plugin.mirror_index(5, step * B + i)) for i in range(B)]
+        res[name] = np.stack(frames)
+
+    ts = [threading.Thread(target=run, args=("a", s0)), threading.Thread(target=run, args=("b", s1))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert "a" in res and "b" in res and np.array_equal(res["a"], res["b"])
+    assert s0._sched.stats["calls"] == 3 and s1._sched.stats["calls"] == 3 and s0._sched is not s1._sched
+    for e in model.engines:
+        e.close()

@@ -1,58 +1,92 @@
-"""CPU, world_size 2 over gloo: the multi-GPU path is "independent replicas + a
-barrier + max-over-ranks" (bench.py); sessions are partitioned with no data-path
-collective."""
-import os
-import socket
+"""Multi-GPU path on the CPU: sessions are independent, so N GPUs = N engine replicas and the only
+cross-rank traffic is the bench's barrier + max-over-ranks bookkeeping.
 
+* bench.py's own launcher and the driver's torch.distributed.run launch, world size 2/3 over gloo, through the REAL
+  bench code path (`--dry-ranks`: the rank protocol of bench.py with a sleep in place of the GPU step);
+* `bench.py --gpus 2` on a box without 2 GPUs fails loudly;
+* one process, several engines: the plugin's EnginePool places sessions least-loaded, every session keeps its engine,
+  avatar replicas are registered once per (avatar, engine), released sessions free their slot (fake engines)."""
+import argparse
+import gc
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
 import pytest
 
-torch = pytest.importorskip("torch")
-import torch.distributed as dist  # noqa: E402
-import torch.multiprocessing as mp  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in: " + text[-500:])
 
 
-def _worker(rank, world, port, n_sessions, q):
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from livetalking_amd.sharding import shard_for_rank
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = shard_for_rank(n_sessions, world, rank)
-    # every rank "renders" its own sessions; only bookkeeping crosses ranks
-    frames = torch.tensor([len(mine) * 16], dtype=torch.int64)
-    elapsed = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)
-    dist.barrier()
-    dist.all_reduce(frames, op=dist.ReduceOp.SUM)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
-    if rank == 0:
-        q.put((int(frames.item()), float(elapsed.item()), gathered))
-    dist.destroy_process_group()
+def test_bench_spawns_its_own_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "4", "--dry-ranks"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3
+    own = d["per_rank_ms_per_step"]                       # rank r sleeps 10 ms x (r + 1) per step
+    assert own[0] < own[1] < own[2] and 9.0 < own[0] < 20.0 and 29.0 < own[2] < 45.0
+    assert d["ms_per_step"] >= own[2] - 0.5               # the reported time is the MAX over ranks (barrier on both sides)
 
 
-def test_two_rank_session_sharding():
-    world, n_sessions = 2, 7
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_sessions, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    frames, elapsed, gathered = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert frames == n_sessions * 16
-    assert elapsed == pytest.approx(0.75)
-    assert sorted(sum(gathered, [])) == list(range(n_sessions))
-    assert abs(len(gathered[0]) - len(gathered[1])) <= 1
+def test_bench_under_torch_distributed_run():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--dry-ranks"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["ms_per_step"] >= 19.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    torch = pytest.importorskip("torch")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(max(have + 1, 2)), "--steps", "1", "--no-also"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "visible GPUs" in r.stderr
+
+
+def test_engine_pool_places_sessions_across_engines():
+    pytest.importorskip("torch")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_engine import FakeEngine
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd.sharding import EnginePool
+    from oracle import synth
+
+    pool = EnginePool([0, 1, 1], lambda d: FakeEngine(net="tiny", device=d), capacity_per_gpu=2)
+    model = plugin.Wav2LipModel(pool)
+    avatar = synth.wav2lip_avatar(n_frames=3, full_hw=(120, 160), box=64, seed=0)
+    opt = argparse.Namespace(fps=25, batch_size=2, l=10, r=10, sessionid=0)
+    sess = [plugin.LipReal(opt, model, avatar) for _ in range(5)]
+    assert [s._slot for s in sess] == [0, 1, 2, 0, 1] and pool.load() == [2, 2, 1]
+    assert all(s.engine is pool.engines[s._slot] and s.asr.engine is s.engine for s in sess)
+    # one bank replica per (avatar, engine), shared by the sessions of that engine
+    assert sess[0]._aid == sess[3]._aid and len(pool.engines[0]._avatars) == 1 and len(pool.engines[2]._avatars) == 1
+    plugin.LipReal(opt, model, avatar)                     # the 6th fills the pool (capacity 2 per engine)
+    gc.collect()                                           # ... and is dropped again at once: its slot is free
+    assert pool.load() == [2, 2, 1]
+    keep = plugin.LipReal(opt, model, avatar)
+    with pytest.raises(RuntimeError):
+        plugin.LipReal(opt, model, avatar)
+    # a session renders on its own engine only
+    feats = np.zeros((2, 80, 16), np.float32)
+    import torch
+    before = [e.calls["wav2lip_infer"] for e in pool.engines]
+    sess[2].inference_batch(0, torch.from_numpy(feats))
+    after = [e.calls["wav2lip_infer"] for e in pool.engines]
+    assert [a - b for a, b in zip(after, before)] == [0, 0, 1]
+    del sess[0]
+    gc.collect()
+    assert pool.load()[0] == 1 and keep._slot == 2         # removed sessions free their slot (weakref.finalize)
