@@ -1,0 +1,189 @@
+// conv7: the generator's first layer, Conv2d(6, 16, 7, stride 1, pad 3) + BN + ReLU on the 256x256 face crop
+// (avatars/wav2lip/models/wav2lip_v2.py:13, conv.py:5-19), fused with the input pack of LipReal.inference_batch
+// (avatars/wav2lip_avatar.py:119-134: bank gather, lower-half mask, 6-channel concat, /255).
+//
+// Why its own kernel: K = 6 channels x 49 taps.  The generic kernels pad it to 8 x 49 rows of a 32-cout MFMA tile whose
+// upper 16 rows are zero and stage 7x7-halo patches through registers; in a pass it ran at 0.2 PFLOP/s (52 us for 16
+// frames, 716 us for 256, against 6 / 130 us of HBM time) and the separate pack launch wrote and re-read 1 MB per frame.
+// Here:
+//   * v_mfma_f32_16x16x32_f16 with the WEIGHTS as the row operand (16 couts = the whole layer) and 16 pixels as columns;
+//     k = 4 taps x 8 channels, so a lane's 8-half B fragment is ONE pixel's 8 packed channels: a single 16-byte LDS read
+//     at (x + tap) with no shuffling, conflict-free (a 16-lane group reads 16 consecutive 16-byte slots).  A 7-tap kernel
+//     row is two MFMAs (taps 0-3, taps 4-6 + a zero tap): 14 MFMAs per 16 pixels, 66 % of them useful work;
+//   * the 14 weight fragments (56 VGPRs) stay in registers for the life of the block (persistent over tiles);
+//   * BANK mode reads the uint8 bank crop directly (3 B per pixel instead of the 16-B packed item), builds the
+//     {masked b,g,r, b,g,r, 0, 0} / 255 item in registers and writes it to LDS: the pack kernel and its 1 MB per frame
+//     round trip disappear; PACKED mode (test hooks, the float face6 input) reads the packed fp16 item;
+//   * the epilogue stores a lane's 4 consecutive output channels (8 B); the 4 lanes of a pixel cover its 32-byte CB16 cell.
+#include <hip/hip_fp16.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "conv_mfma.h"
+#include "misc_kernels.h"
+
+namespace ltk {
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C7_TW = 64, C7_TH = 16;                 // output pixels per tile
+constexpr int C7_PW = C7_TW + 6, C7_PH = C7_TH + 6;   // input patch (pad 3 each side)
+constexpr int C7_PWP = 72;                            // patch row pitch in pixels (16-byte slots)
+constexpr int C7_LDS = C7_PH * C7_PWP * 16;           // 25 344 B
+
+struct C7Args {
+    const f16* x;                 // PACKED mode: fp16 [N][256][256][8]; BANK mode: unused
+    const f16x8* w;               // [14][64] A fragments: (ky*2 + h) x lane
+    const float* scale;           // [16]
+    const float* shift;           // [16]
+    f16* y;                       // CB16 output buffer
+    int N, y_cbt, y_cb0;
+    int ntiles;                   // N * 64 tiles
+};
+
+template <bool BANK>
+__global__ __launch_bounds__(256, 2) void conv7_kernel(const C7Args a, const FacePtrs faces) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, g = lane >> 4;
+
+    f16x8 wf[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) wf[i] = a.w[i * 64 + lane];
+    f32x4 sc, sf;                                      // this lane's 4 couts: 4g .. 4g+3
+    sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * g);
+    sf = *reinterpret_cast<const f32x4*>(a.shift + 4 * g);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int n = tile >> 6, t = tile & 63;
+        const int ty0 = (t >> 2) * C7_TH, tx0 = (t & 3) * C7_TW;
+        if (tile != (int)blockIdx.x) __syncthreads();           // everyone is out of the previous patch
+        // ---- stage the (TH+6) x (TW+6) input patch, zero outside the image
+        const uint8_t* __restrict__ bank = BANK ? faces.p[n] : nullptr;
+        for (int i = tid; i < C7_PH * C7_PW; i += 256) {
+            const int py = i / C7_PW, px = i - py * C7_PW;
+            const int iy = ty0 - 3 + py, ix = tx0 - 3 + px;
+            f16x8 v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (f16)0.f;
+            if ((unsigned)iy < 256u && (unsigned)ix < 256u) {
+                if constexpr (BANK) {
+                    const uint8_t* s = bank + (iy * 256 + ix) * 3;
+                    const float k = 1.0f / 255.0f;                 // wav2lip_avatar.py:129 (/255.), same rounding as pack_faces_kernel
+                    const float b = s[0] * k, gg = s[1] * k, r = s[2] * k;
+                    const bool keep = iy < 128;                     // img_masked[:, 128:] = 0 (rows), wav2lip_avatar.py:127-128
+                    v[0] = (f16)(keep ? b : 0.f); v[1] = (f16)(keep ? gg : 0.f); v[2] = (f16)(keep ? r : 0.f);
+                    v[3] = (f16)b; v[4] = (f16)gg; v[5] = (f16)r;
+                } else {
+                    v = *reinterpret_cast<const f16x8*>(a.x + ((size_t)n * 65536 + iy * 256 + ix) * 8);
+                }
+            }
+            *reinterpret_cast<f16x8*>(smem + (py * C7_PWP + px) * 16) = v;
+        }
+        __syncthreads();
+        // ---- wave w: output rows 4w .. 4w+3 of the tile, 4 column groups of 16 pixels each
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // input row (relative to the patch) py = 4w + r + ky serves output row r through kernel row ky: walk the 10 input
+        // rows once, each fragment read feeds every (r, ky) pair with r + ky = row
+#pragma unroll
+        for (int row = 0; row < 10; ++row) {
+            const unsigned char* rowp = smem + ((wave * 4 + row) * C7_PWP + n16 + g) * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = *reinterpret_cast<const f16x8*>(rowp + (c * 16 + 4 * h) * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ky = row - r;
+                    if (ky < 0 || ky > 6) continue;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ky * 2 + h], xb[c], acc[r][c], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: BN + ReLU, lane holds couts 4g..4g+3 of pixel (row 4w+r, column 16c + n16)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = ty0 + wave * 4 + r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ox = tx0 + c * 16 + n16;
+                f16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (f16)__builtin_amdgcn_fmed3f(acc[r][c][q] * sc[q] + sf[q], 0.f, 65504.f);
+                *reinterpret_cast<f16x4*>(a.y + (((size_t)n * a.y_cbt + a.y_cb0) * 65536 + oy * 256 + ox) * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct Conv7Plan {
+    f16x8* d_w = nullptr;
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+};
+
+int conv7_plan_create(Conv7Plan** out, const float* weight /*[16][6][7][7]*/, const float* scale, const float* shift, std::string* err) {
+    std::vector<f16> w((size_t)14 * 64 * 8, (f16)0.f);
+    for (int ky = 0; ky < 7; ++ky)
+        for (int h = 0; h < 2; ++h)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = lane & 15, kx = 4 * h + (lane >> 4);
+                if (kx > 6) continue;
+                for (int ci = 0; ci < 6; ++ci)
+                    w[(((size_t)(ky * 2 + h)) * 64 + lane) * 8 + ci] = (f16)weight[(((size_t)co * 6 + ci) * 7 + ky) * 7 + kx];
+            }
+    Conv7Plan* p = new Conv7Plan();
+    auto fail = [&](const char* m) { if (err) *err = m; delete p; return -2; };
+    if (hipMalloc((void**)&p->d_w, w.size() * sizeof(f16)) != hipSuccess) return fail("conv7: weight allocation failed");
+    if (hipMalloc((void**)&p->d_scale, 16 * sizeof(float)) != hipSuccess) return fail("conv7: allocation failed");
+    if (hipMalloc((void**)&p->d_shift, 16 * sizeof(float)) != hipSuccess) return fail("conv7: allocation failed");
+    if (hipMemcpy(p->d_w, w.data(), w.size() * sizeof(f16), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_scale, scale, 16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_shift, shift, 16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail("conv7: upload failed");
+    *out = p;
+    return 0;
+}
+
+void conv7_plan_destroy(Conv7Plan* p) {
+    if (!p) return;
+    if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_scale) (void)hipFree(p->d_scale);
+    if (p->d_shift) (void)hipFree(p->d_shift);
+    delete p;
+}
+
+// faces != nullptr: BANK mode (uint8 crops); else PACKED mode from x0 (fp16 [N][256][256][8]).
+int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N, f16* y, int y_ld, int y_coff, hipStream_t stream,
+                 std::string* err) {
+    if (!p || N <= 0 || N > kPackMaxFrames || ((y_ld | y_coff) & 15)) { if (err) *err = "conv7: bad arguments"; return -1; }
+    C7Args a;
+    a.x = x0; a.w = p->d_w; a.scale = p->d_scale; a.shift = p->d_shift; a.y = y;
+    a.N = N; a.y_cbt = y_ld >> 4; a.y_cb0 = y_coff >> 4; a.ntiles = N * 64;
+    const int grid = std::min(a.ntiles, 512);            // 2 resident blocks per CU (180 VGPRs) walk the tile list
+    if (faces) {
+        hipLaunchKernelGGL(conv7_kernel<true>, dim3(grid), dim3(256), C7_LDS, stream, a, *faces);
+    } else {
+        FacePtrs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(conv7_kernel<false>, dim3(grid), dim3(256), C7_LDS, stream, a, none);
+    }
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "conv7: launch failed"; return -2; }
+    return 0;
+}
+
+}  // namespace ltk

@@ -126,4 +126,13 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
 // upper bound of the split-K scratch a launch of `N` images of H x W may use
 size_t conv3_partial_bytes(const ConvPlan& p, int N, int H, int W);
 
+// conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
+struct Conv7Plan;
+struct FacePtrs;
+int conv7_plan_create(Conv7Plan** out, const float* weight /*[16][6][7][7]*/, const float* scale, const float* shift, std::string* err);
+void conv7_plan_destroy(Conv7Plan* p);
+// faces != nullptr: read the uint8 bank crops (pack fused); else read the packed fp16 input x0 [N][256][256][8]
+int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N, f16* y, int y_ld, int y_coff, hipStream_t stream,
+                 std::string* err);
+
 }  // namespace ltk

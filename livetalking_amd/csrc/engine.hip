@@ -205,6 +205,7 @@ struct ltk_engine {
     f16* buf[B_COUNT] = {nullptr};
     size_t buf_halfs[B_COUNT] = {0};  // per frame
     float* d_head = nullptr;          // 96 weights + 3 bias
+    Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
     double macs_per_frame = 0;
     // debug capture
     bool capture = false;
@@ -355,6 +356,10 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
                               sc.data(), sf.data(), &err, hint_hw);
     }
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+    if (!d.transposed && d.k == 7 && d.cin == 6 && d.cout == 16 && d.sh == 1 && d.pad == 3 && knob(K_CONV7) && !e->c7) {
+        rc = conv7_plan_create(&e->c7, w, sc.data(), sf.data(), &err);
+        if (rc) return fail(LTK_E_HIP, p + ": " + err);
+    }
     L->name = p;
     L->cin_real = d.cin;
     L->residual = d.residual;
@@ -484,7 +489,9 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // `head_outs` != nullptr: the last layer (output_block.0) also applies the 1x1 head + sigmoid and writes the uint8 frames
 // (one launch and one 4 MB/frame round trip of the 32-channel map less); the caller then skips launch_head.
 // `evs` != nullptr (measurement): everything on `s`, one event in front of every layer and one behind the last.
-int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr) {
+// `faces` != nullptr: the first layer reads the uint8 bank crops itself (the caller then skips launch_pack_faces).
+int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr,
+              const FacePtrs* faces = nullptr) {
     std::string err;
     const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM) && !evs;
     const int bucket = frame_bucket(nf);
@@ -526,7 +533,11 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         if (head_outs && Lp == &e->layers.back()) { io.head_w = e->d_head; io.head_outs = head_outs; }
         if (knob(K_TILE_TABLE)) { io.force_pxw = L.tile[bucket].pxw; io.force_nbt = L.tile[bucket].nbt; io.force_ksplit = L.tile[bucket].ks; }
         if (evs) CHK(hipEventRecord((*evs)[evi++], s));
-        int rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
+        int rc;
+        if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
+            rc = conv7_launch(e->c7, faces, e->buf[B_X0], nf, e->buf[L.out_buf], L.out_ld, L.out_coff, s, &err);
+        else
+            rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
         if (e->capture) {
             const int C = L.plan.Cout;
@@ -632,6 +643,7 @@ void ltk_engine_destroy(ltk_engine* e) {
     for (Layer& L : e->layers) conv_plan_destroy(&L.plan);
     for (int i = 0; i < B_COUNT; ++i) if (e->buf[i]) (void)hipFree(e->buf[i]);
     if (e->d_head) (void)hipFree(e->d_head);
+    conv7_plan_destroy(e->c7);
     if (e->d_basis) (void)hipFree(e->d_basis);
     if (e->d_lohi) (void)hipFree(e->d_lohi);
     for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
@@ -751,12 +763,13 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
 static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mels, const float* d_face6, int nf,
                         const OutPtrs* outs, float* d_pred_f32) {
     hipStream_t s = e->compute;
-    if (faces) launch_pack_faces(*faces, nf, e->buf[B_X0], s);
+    const bool pack_fused = faces && e->c7 && knob(K_CONV7);     // the first layer reads the bank crops itself
+    if (faces) { if (!pack_fused) launch_pack_faces(*faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
     launch_pack_mel(*mels, nf, e->buf[B_MEL], s);
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
     const bool fused = outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
-    int rc = run_convs(e, nf, s, fused ? outs : nullptr);
+    int rc = run_convs(e, nf, s, fused ? outs : nullptr, nullptr, pack_fused ? faces : nullptr);
     if (rc) return rc;
     if (!fused) {
         launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, outs, d_pred_f32, s);
