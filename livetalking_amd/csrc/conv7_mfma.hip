@@ -67,9 +67,10 @@ __global__ __launch_bounds__(256, 2) void conv7_kernel(const C7Args a, const Fac
         if (tile != (int)blockIdx.x) __syncthreads();           // everyone is out of the previous patch
         // ---- stage the (TH+6) x (TW+6) input patch, zero outside the image
         const uint8_t* __restrict__ bank = BANK ? faces.p[n] : nullptr;
-        for (int i = tid; i < C7_PH * C7_PW; i += 256) {
-            const int py = i / C7_PW, px = i - py * C7_PW;
-            const int iy = ty0 - 3 + py, ix = tx0 - 3 + px;
+        // (all C7_PWP columns: the zero eighth tap of the second MFMA reads up to column 71; 0 x garbage could be NaN)
+        for (int i = tid; i < C7_PH * C7_PWP; i += 256) {
+            const int py = i / C7_PWP, px = i - py * C7_PWP;
+            const int iy = ty0 - 3 + py, ix = px < C7_PW ? tx0 - 3 + px : -1;
             f16x8 v;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = (f16)0.f;
