@@ -149,6 +149,31 @@ UNET_CTX = 384
 VAE_CH = (128, 256, 512, 512)
 
 
+class _Shape:
+    """Stand-in array for `shapes_only=True`: carries a shape through the generators' arithmetic without allocating."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+
+    def __mul__(self, other):
+        return self
+
+    def astype(self, dtype):
+        return self
+
+
+class _ShapeRng:
+    def standard_normal(self, shape, dtype=None):
+        return _Shape(shape)
+
+    def uniform(self, lo, hi, shape):
+        return _Shape(shape)
+
+
+def _finish(sd, shapes_only):
+    return {k: tuple(v.shape) for k, v in sd.items()} if shapes_only else sd
+
+
 def _w(rng, shape, fan_in, gain=1.0):
     return (rng.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))).astype(np.float32)
 
@@ -196,8 +221,8 @@ def _transformer(rng, sd, p, c, ctx):
     _conv(rng, sd, p + ".proj_out", c, c, 1, gain=0.5)
 
 
-def musetalk_unet_state_dict(seed: int = 4321) -> Dict[str, np.ndarray]:
-    rng = np.random.default_rng(seed)
+def musetalk_unet_state_dict(seed: int = 4321, shapes_only: bool = False) -> Dict[str, np.ndarray]:
+    rng = _ShapeRng() if shapes_only else np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     ch = UNET_CH
     _conv(rng, sd, "conv_in", 8, ch[0], 3)
@@ -230,11 +255,11 @@ def musetalk_unet_state_dict(seed: int = 4321) -> Dict[str, np.ndarray]:
             _conv(rng, sd, f"up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
     _norm(rng, sd, "conv_norm_out", cin)
     _conv(rng, sd, "conv_out", cin, 4, 3, gain=0.5)
-    return sd
+    return _finish(sd, shapes_only)
 
 
-def vae_decoder_state_dict(seed: int = 987) -> Dict[str, np.ndarray]:
-    rng = np.random.default_rng(seed)
+def vae_decoder_state_dict(seed: int = 987, shapes_only: bool = False) -> Dict[str, np.ndarray]:
+    rng = _ShapeRng() if shapes_only else np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     _conv(rng, sd, "post_quant_conv", 4, 4, 1)
     top = VAE_CH[-1]
@@ -255,12 +280,12 @@ def vae_decoder_state_dict(seed: int = 987) -> Dict[str, np.ndarray]:
             _conv(rng, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
     _norm(rng, sd, "decoder.conv_norm_out", cin)
     _conv(rng, sd, "decoder.conv_out", cin, 3, 3, gain=0.7)
-    return sd
+    return _finish(sd, shapes_only)
 
 
-def vae_encoder_state_dict(seed: int = 654) -> Dict[str, np.ndarray]:
+def vae_encoder_state_dict(seed: int = 654, shapes_only: bool = False) -> Dict[str, np.ndarray]:
     """AutoencoderKL (sd-vae) encoder + quant_conv under diffusers' key names."""
-    rng = np.random.default_rng(seed)
+    rng = _ShapeRng() if shapes_only else np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     _conv(rng, sd, "encoder.conv_in", 3, VAE_CH[0], 3)
     cin = VAE_CH[0]
@@ -280,7 +305,7 @@ def vae_encoder_state_dict(seed: int = 654) -> Dict[str, np.ndarray]:
     _norm(rng, sd, "encoder.conv_norm_out", cin)
     _conv(rng, sd, "encoder.conv_out", cin, 8, 3, gain=0.7)
     _conv(rng, sd, "quant_conv", 8, 8, 1)
-    return sd
+    return _finish(sd, shapes_only)
 
 
 def musetalk_latents(n_frames: int = 4, seed: int = 5) -> List[np.ndarray]:

@@ -29,7 +29,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 sys.path.insert(0, REPO)
 
-from oracle import gen_golden, musetalk_oracle, whisper_oracle  # noqa: E402
+from oracle import musetalk_oracle, whisper_oracle  # noqa: E402
+from oracle import ref_loop as gen_golden  # noqa: E402  (install_stubs / _stub)
 
 
 def main():
@@ -132,6 +133,67 @@ def main():
         out.update({"mha_xq": xq.numpy(), "mha_xc": xc.numpy(), "mha_y_self": y_self.numpy(), "mha_y_cross": y_cross.numpy()})
         for k, v in asd.items():
             out["mha_sd." + k] = v.detach().numpy()
+    # ---- Transformer2D composition: the reference's in-tree AttentionBlock2D (syncnet.py:142-181) = GroupNorm(eps 1e-6) -> 1x1
+    # conv_in -> LayerNorm -> self-attention + x -> LayerNorm -> GEGLU feed-forward + x -> 1x1 conv_out -> + input, i.e. diffusers'
+    # Transformer2DModel / BasicTransformerBlock without the cross-attention sub-block.  Its two diffusers leaf classes are
+    # replaced by (a) the reference's own MultiHeadAttention pinned above and (b) a literal GEGLU feed-forward; what is pinned
+    # is the COMPOSITION that musetalk_oracle.transformer2d(cross=False) restates.
+    import sys as _sys
+    att_mod = _sys.modules["diffusers.models.attention"]
+
+    class _Attn(torch.nn.Module):
+        def __init__(self, query_dim, heads=8, dim_head=None, dropout=0.0, bias=True):
+            super().__init__()
+            self.mha = MultiHeadAttention(query_dim, heads)
+
+        def forward(self, x, attention_mask=None):
+            out = self.mha(x)
+            return out[0] if isinstance(out, tuple) else out
+
+    class _FF(torch.nn.Module):
+        def __init__(self, dim, dropout=0.0, activation_fn="geglu"):
+            super().__init__()
+            assert activation_fn == "geglu"
+            self.proj = torch.nn.Linear(dim, dim * 8)
+            self.out = torch.nn.Linear(dim * 4, dim)
+
+        def forward(self, x):
+            a, gate = self.proj(x).chunk(2, dim=-1)
+            return self.out(a * torch.nn.functional.gelu(gate))
+
+    att_mod.Attention, att_mod.FeedForward = _Attn, _FF
+    _sys.modules["diffusers.utils.import_utils"].is_xformers_available = lambda: True
+    import importlib
+    import avatars.musetalk.models.syncnet as syncnet
+    importlib.reload(syncnet)
+    torch.manual_seed(13)
+    blk = syncnet.AttentionBlock2D(128).eval()
+    with torch.no_grad():
+        for nm, prm in blk.named_parameters():
+            prm.copy_(torch.randn_like(prm) * (0.2 if prm.dim() == 1 else (1.0 / prm[0].numel()) ** 0.5))
+            if "norm" in nm and nm.endswith("weight"):
+                prm.add_(1.0)
+        xa = torch.randn(2, 128, 6, 5)
+        ya = blk(xa)
+        m = blk.attn.mha
+        tsd = {"t.norm.weight": blk.norm1.weight, "t.norm.bias": blk.norm1.bias,
+               "t.proj_in.weight": blk.conv_in.weight, "t.proj_in.bias": blk.conv_in.bias,
+               "t.proj_out.weight": blk.conv_out.weight, "t.proj_out.bias": blk.conv_out.bias,
+               "t.transformer_blocks.0.norm1.weight": blk.norm2.weight, "t.transformer_blocks.0.norm1.bias": blk.norm2.bias,
+               "t.transformer_blocks.0.norm3.weight": blk.norm3.weight, "t.transformer_blocks.0.norm3.bias": blk.norm3.bias,
+               "t.transformer_blocks.0.attn1.to_q.weight": m.query.weight, "t.transformer_blocks.0.attn1.to_q.bias": m.query.bias,
+               "t.transformer_blocks.0.attn1.to_k.weight": m.key.weight,
+               "t.transformer_blocks.0.attn1.to_v.weight": m.value.weight, "t.transformer_blocks.0.attn1.to_v.bias": m.value.bias,
+               "t.transformer_blocks.0.attn1.to_out.0.weight": m.out.weight, "t.transformer_blocks.0.attn1.to_out.0.bias": m.out.bias,
+               "t.transformer_blocks.0.ff.net.0.proj.weight": blk.ff.proj.weight, "t.transformer_blocks.0.ff.net.0.proj.bias": blk.ff.proj.bias,
+               "t.transformer_blocks.0.ff.net.2.weight": blk.ff.out.weight, "t.transformer_blocks.0.ff.net.2.bias": blk.ff.out.bias}
+        mine = musetalk_oracle.transformer2d(tsd, "t", xa, None, cross=False, heads=8, groups=32, gn_eps=1e-6)
+        e3 = float((mine - ya).abs().max())
+        assert mine.shape == ya.shape and e3 < 5e-5, f"Transformer2D composition drifted ({e3})"
+        print(f"AttentionBlock2D (Transformer2D composition): max|restatement - reference| = {e3:.2e}")
+        out.update({"t2d_x": xa.numpy(), "t2d_y": ya.numpy()})
+        for k, v in tsd.items():
+            out["t2d_sd." + k] = v.detach().numpy()
     np.savez_compressed(os.path.join(args.out, "musetalk_blocks_golden.npz"), **out)
     print("wrote musetalk_blocks_golden.npz")
 

@@ -30,9 +30,13 @@ the ResnetBlock2D building block (GN -> SiLU -> conv -> GN -> SiLU -> conv + 1x1
 asymmetric-pad stride-2 downsample, against the reference's own in-tree implementation
 (avatars/musetalk/models/syncnet.py:71-139, imported with `diffusers` stubbed; golden tensors in
 tests/golden/musetalk_blocks_golden.npz), the positional encoding (unet.py:12-27) and the Whisper side
-(oracle/whisper_oracle.py calls the installed transformers).  Compared by reading only: syncnet.py:142-181
-(AttentionBlock2D: GN, 1x1 in, LN, attention, LN, GEGLU feed-forward, 1x1 out), whose attention and
-feed-forward are diffusers classes.  The HIP path is required to match THIS statement within the fp16 tolerance
+(oracle/whisper_oracle.py calls the installed transformers); the Transformer2D composition (GN, 1x1 in, LN, attention +
+residual, LN, GEGLU feed-forward + residual, 1x1 out + residual) against the reference's in-tree AttentionBlock2D
+(syncnet.py:142-181, its two diffusers leaf classes replaced by the pinned multi-head attention and a literal GEGLU);
+and the WHOLE VAE decoder / encoder graph against an independent implementation of the same network that is installed
+here (transformers' Janus VQ-VAE = the taming / latent-diffusion autoencoder AutoencoderKL ports; tests/test_vae_pin.py,
+2.7e-6).  Still unpinned: the U-Net's block wiring (down / mid / up order, skip concatenation, timestep embedding) and
+diffusers' key names / config values.  The HIP path is required to match THIS statement within the fp16 tolerance
 written in tests/test_musetalk_gpu.py.
 """
 from __future__ import annotations
@@ -178,8 +182,13 @@ def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, taps=None) -> 
     return _linear(sd, p + ".to_out.0", o)
 
 
-def transformer2d(sd: SD, p: str, x: Tensor, ctx: Tensor, taps=None) -> Tensor:
-    """diffusers Transformer2DModel (use_linear_projection False) with one BasicTransformerBlock.
+def transformer2d(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], taps=None, cross: bool = True, heads: int = UNET_HEADS,
+                  groups: int = UNET_GROUPS, gn_eps: float = ATTN_GN_EPS) -> Tensor:
+    """diffusers Transformer2DModel (use_linear_projection False) with one BasicTransformerBlock: GroupNorm -> 1x1 proj_in ->
+    [LN -> self-attention + x; LN -> cross-attention + x; LN -> GEGLU feed-forward + x] -> 1x1 proj_out -> + input.
+    `cross=False` drops the cross-attention sub-block: that is the reference's in-tree AttentionBlock2D
+    (avatars/musetalk/models/syncnet.py:142-181), against which this function is pinned
+    (oracle/gen_golden_musetalk.py, tests/golden/musetalk_blocks_golden.npz: same code path, one sub-block fewer).
     Token-major taps (B, T, C) are stored as (B, C, H, W) so they compare directly with the device tensors."""
     B, C, H, W = x.shape
 
@@ -189,15 +198,16 @@ def transformer2d(sd: SD, p: str, x: Tensor, ctx: Tensor, taps=None) -> Tensor:
         return t
 
     res = x
-    h = _tap(taps, p + ".norm", _gn(sd, p + ".norm", x, UNET_GROUPS, ATTN_GN_EPS))
+    h = _tap(taps, p + ".norm", _gn(sd, p + ".norm", x, groups, gn_eps))
     h = _tap(taps, p + ".proj_in", _conv(sd, p + ".proj_in", h, pad=0))
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = p + ".transformer_blocks.0"
     n = tk(b + ".norm1", _ln(sd, b + ".norm1", h))
     at = {} if taps is not None else None
-    h = tk(b + ".attn1.to_out.0", attention(sd, b + ".attn1", n, n, UNET_HEADS, at) + h)
-    n = tk(b + ".norm2", _ln(sd, b + ".norm2", h))
-    h = tk(b + ".attn2.to_out.0", attention(sd, b + ".attn2", n, ctx, UNET_HEADS, at) + h)
+    h = tk(b + ".attn1.to_out.0", attention(sd, b + ".attn1", n, n, heads, at) + h)
+    if cross:
+        n = tk(b + ".norm2", _ln(sd, b + ".norm2", h))
+        h = tk(b + ".attn2.to_out.0", attention(sd, b + ".attn2", n, ctx, heads, at) + h)
     if at:
         for k, v in at.items():
             tk(k, v)

@@ -99,3 +99,26 @@ def test_resize_properties():
 def test_mirror_index_ping_pong():
     assert [paste_oracle.mirror_index(3, i) for i in range(9)] == [0, 1, 2, 2, 1, 0, 0, 1, 2]
     assert [paste_oracle.mirror_index(1, i) for i in range(4)] == [0, 0, 0, 0]
+
+
+def test_resize_restatement_vs_independent_bilinear():
+    """paste_oracle.resize_linear_u8 restates cv2.resize(uint8, INTER_LINEAR) (no OpenCV in this image: the leaf is unpinned
+    against OpenCV itself).  Its GEOMETRY (half-pixel centres, no antialiasing when shrinking, edge clamping, the exact-2x
+    area path) is cross-checked here against an independent implementation of the same sampling,
+    torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=False): OpenCV's 8-bit path quantises the
+    coefficients to 11 bits and rounds once at the end, so the two may differ by 1 LSB, never more."""
+    import torch
+    from oracle import paste_oracle
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    smooth = synth.wav2lip_avatar(n_frames=1, full_hw=(64, 64), box=32, seed=1)[1][0]          # a 256x256 smooth crop
+    for img in (src, smooth):
+        for (w, h) in ((320, 320), (317, 325), (200, 200), (163, 171), (128, 128), (256, 300), (96, 64)):
+            mine = paste_oracle.resize_linear_u8(np.ascontiguousarray(img), (w, h)).astype(np.int32)
+            t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None].float()
+            ref = torch.nn.functional.interpolate(t, size=(h, w), mode="bilinear", align_corners=False, antialias=False)
+            ref = ref[0].permute(1, 2, 0).numpy()
+            d = np.abs(mine - np.rint(ref).astype(np.int32))
+            # where the float result sits within 0.02 of a rounding boundary the 11-bit coefficients may tip it: allow 1 LSB
+            assert mine.shape == (h, w, 3) and d.max() <= 1, ((w, h), int(d.max()))
+            assert float((d != 0).mean()) < 0.25, ((w, h), float((d != 0).mean()))       # OpenCV truncates twice on the way (>> 4, >> 16)
