@@ -73,6 +73,9 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
  * (coords.pkl, avatars/wav2lip/genavatar.py:130).  Host pointers. */
 int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* full_bank,
                         const int32_t* coords, int n, int H, int W, int* avatar_id);
+/* Drops a bank registered by ltk_avatar_register or ltk_musetalk_avatar_register (ids of both kinds come from one counter).
+ * Safe while other threads render from it: every call holds a reference to its bank until it returns, the device buffers are
+ * freed when the last of them does. */
 int ltk_avatar_release(ltk_engine* e, int avatar_id);
 
 /* avatars/audio_features/mel.py:43-63 (MelASR.run_step feature part) +

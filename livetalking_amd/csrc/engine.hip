@@ -163,11 +163,24 @@ void apply_tile_table_impl(std::vector<Layer>& layers) {
 }
 
 
+// Avatar banks are shared_ptr-owned: an entry point keeps its avatar alive for the duration of the call, so a concurrent
+// ltk_avatar_release only drops the table's reference and the device buffers go when the last call using them returns
+// (every entry point synchronises its stream before it returns).  The destructor also frees a half-built bank when a
+// register call fails part-way.
 struct Avatar {
     uint8_t* d_face = nullptr;
     uint8_t* d_full = nullptr;
     std::vector<int32_t> coords;
     int n = 0, H = 0, W = 0;
+    int device = 0;
+    Avatar() = default;
+    Avatar(const Avatar&) = delete;
+    Avatar& operator=(const Avatar&) = delete;
+    ~Avatar() {
+        (void)hipSetDevice(device);
+        if (d_face) (void)hipFree(d_face);
+        if (d_full) (void)hipFree(d_full);
+    }
 };
 
 struct Scratch {
@@ -183,6 +196,23 @@ struct MtAvatar {
     std::vector<int64_t> mask_off;
     std::vector<int32_t> face_box, crop_box;
     int n = 0, H = 0, W = 0;
+    int device = 0;
+    MtAvatar() = default;
+    MtAvatar(const MtAvatar&) = delete;
+    MtAvatar& operator=(const MtAvatar&) = delete;
+    ~MtAvatar() {
+        (void)hipSetDevice(device);
+        if (d_latents) (void)hipFree(d_latents);
+        if (d_full) (void)hipFree(d_full);
+        if (d_masks) (void)hipFree(d_masks);
+    }
+};
+
+// RAII HIP event: error returns between create and destroy do not leak it
+struct Ev {
+    hipEvent_t e = nullptr;
+    hipError_t create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+    ~Ev() { if (e) (void)hipEventDestroy(e); }
 };
 
 }  // namespace
@@ -212,7 +242,7 @@ struct ltk_engine {
     std::map<std::string, std::vector<float>> taps;
     std::map<std::string, std::vector<int>> tap_shape;
     // avatars
-    std::map<int, Avatar> avatars;
+    std::map<int, std::shared_ptr<Avatar>> avatars;
     int next_avatar = 1;
     // mel
     float* d_basis = nullptr;
@@ -232,7 +262,7 @@ struct ltk_engine {
     float* d_pe = nullptr;                // PositionalEncoding table [50][384]
     float* d_mt_feat = nullptr;           // staging: fp32 [max_frames][50][384]
     float* d_mt_lat = nullptr;            // staging for the host-input hook: fp32 [max_frames][8][32][32]
-    std::map<int, MtAvatar> mt_avatars;
+    std::map<int, std::shared_ptr<MtAvatar>> mt_avatars;
     // pools
     std::vector<Scratch> scratch_free;
     std::vector<hipStream_t> stream_free;
@@ -646,8 +676,8 @@ void ltk_engine_destroy(ltk_engine* e) {
     conv7_plan_destroy(e->c7);
     if (e->d_basis) (void)hipFree(e->d_basis);
     if (e->d_lohi) (void)hipFree(e->d_lohi);
-    for (auto& kv : e->avatars) { (void)hipFree(kv.second.d_face); (void)hipFree(kv.second.d_full); }
-    for (auto& kv : e->mt_avatars) { (void)hipFree(kv.second.d_latents); (void)hipFree(kv.second.d_full); (void)hipFree(kv.second.d_masks); }
+    e->avatars.clear();
+    e->mt_avatars.clear();
     if (e->mt) mt_graph_delete(e->mt);
     if (e->whisper) mt_graph_delete(e->whisper);
     if (e->vae_enc) mt_graph_delete(e->vae_enc);
@@ -708,7 +738,9 @@ int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* 
             return fail(LTK_E_INVALID, "coords box outside the frame");
     }
     CHK(hipSetDevice(e->device));
-    Avatar a;
+    auto ap = std::make_shared<Avatar>();
+    Avatar& a = *ap;
+    a.device = e->device;
     a.n = n; a.H = H; a.W = W;
     a.coords.assign(coords, coords + 4 * (size_t)n);
     const size_t fb = (size_t)n * 256 * 256 * 3, ub = (size_t)n * H * W * 3;
@@ -718,7 +750,7 @@ int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* 
     CHK(hipMemcpy(a.d_full, full_bank, ub, hipMemcpyHostToDevice));
     std::lock_guard<std::mutex> g(e->pool_mu);
     const int id = e->next_avatar++;
-    e->avatars[id] = a;
+    e->avatars[id] = ap;
     *avatar_id = id;
     return LTK_OK;
 }
@@ -727,11 +759,10 @@ int ltk_avatar_release(ltk_engine* e, int avatar_id) {
     if (!e) return fail(LTK_E_INVALID, "engine is null");
     std::lock_guard<std::mutex> g(e->pool_mu);
     auto it = e->avatars.find(avatar_id);
-    if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
-    (void)hipFree(it->second.d_face);
-    (void)hipFree(it->second.d_full);
-    e->avatars.erase(it);
-    return LTK_OK;
+    if (it != e->avatars.end()) { e->avatars.erase(it); return LTK_OK; }      // buffers go with the last call that still uses them
+    auto mt = e->mt_avatars.find(avatar_id);                                       // ids of both kinds come from one counter
+    if (mt != e->mt_avatars.end()) { e->mt_avatars.erase(mt); return LTK_OK; }
+    return fail(LTK_E_STATE, "unknown avatar id");
 }
 
 int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* win_start, int n_win,
@@ -786,13 +817,15 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
     std::vector<const uint8_t*> fptr;
     std::vector<const float*> mptr;
     std::vector<uint8_t*> optr;
+    std::vector<std::shared_ptr<Avatar>> hold;        // the banks stay alive until this call has synchronised
     {
         std::lock_guard<std::mutex> g(e->pool_mu);
         for (int r = 0; r < nreq; ++r) {
             auto it = e->avatars.find(reqs[r].avatar);
             if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
             if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_mel || !reqs[r].d_pred) return fail(LTK_E_INVALID, "bad request");
-            const Avatar& a = it->second;
+            hold.push_back(it->second);
+            const Avatar& a = *it->second;
             for (int i = 0; i < reqs[r].batch; ++i) {
                 const int idx = mirror_index(a.n, reqs[r].index + i);  // wav2lip_avatar.py:121-124
                 fptr.push_back(a.d_face + (size_t)idx * 256 * 256 * 3);
@@ -803,17 +836,17 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
     }
     const int total = (int)fptr.size();
     if (total > e->max_frames) return fail(LTK_E_INVALID, "more frames than max_frames given to ltk_wav2lip_load");
-    hipEvent_t done;
-    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    Ev done_ev;
+    CHK(done_ev.create());
+    const hipEvent_t done = done_ev.e;
     int rc = 0;
     {
         std::lock_guard<std::mutex> g(e->mu);
         if (stream) {  // inputs were produced on the caller's stream
-            hipEvent_t ready;
-            CHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-            CHK(hipEventRecord(ready, (hipStream_t)stream));
-            CHK(hipStreamWaitEvent(e->compute, ready, 0));
-            CHK(hipEventDestroy(ready));
+            Ev ready;
+            CHK(ready.create());
+            CHK(hipEventRecord(ready.e, (hipStream_t)stream));
+            CHK(hipStreamWaitEvent(e->compute, ready.e, 0));
         }
         const int mbs = std::min(e->micro_batch, kPackMaxFrames);
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
@@ -830,19 +863,19 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
     }
-    (void)hipEventDestroy(done);
     return rc;
 }
 
 int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out, int out_is_device, void* stream) {
     if (!e || !d_pred || !out) return fail(LTK_E_INVALID, "bad arguments");
-    Avatar a;
+    std::shared_ptr<Avatar> ap;
     {
         std::lock_guard<std::mutex> g(e->pool_mu);
         auto it = e->avatars.find(avatar_id);
         if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
-        a = it->second;
+        ap = it->second;
     }
+    const Avatar& a = *ap;
     if (idx < 0 || idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
     CHK(hipSetDevice(e->device));
     const int32_t* c = a.coords.data() + 4 * (size_t)idx;
@@ -1157,7 +1190,9 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
             return fail(LTK_E_INVALID, "mask size does not match its crop box");
     }
     CHK(hipSetDevice(e->device));
-    MtAvatar a;
+    auto ap = std::make_shared<MtAvatar>();
+    MtAvatar& a = *ap;
+    a.device = e->device;
     a.n = n; a.H = H; a.W = W;
     a.face_box.assign(face_boxes, face_boxes + 4 * (size_t)n);
     a.crop_box.assign(crop_boxes, crop_boxes + 4 * (size_t)n);
@@ -1171,7 +1206,7 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
     CHK(hipMemcpy(a.d_masks, masks, mb, hipMemcpyHostToDevice));
     std::lock_guard<std::mutex> g(e->pool_mu);
     const int id = e->next_avatar++;
-    e->mt_avatars[id] = a;
+    e->mt_avatars[id] = ap;
     *avatar_id = id;
     return LTK_OK;
 }
@@ -1202,13 +1237,15 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
     CHK(hipSetDevice(e->device));
     std::vector<const float*> lptr, fptr;
     std::vector<uint8_t*> optr;
+    std::vector<std::shared_ptr<MtAvatar>> hold;      // the banks stay alive until this call has synchronised
     {
         std::lock_guard<std::mutex> g(e->pool_mu);
         for (int r = 0; r < nreq; ++r) {
             auto it = e->mt_avatars.find(reqs[r].avatar);
             if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
             if (reqs[r].batch <= 0 || reqs[r].index < 0 || !reqs[r].d_feat || !reqs[r].d_pred) return fail(LTK_E_INVALID, "bad request");
-            const MtAvatar& a = it->second;
+            hold.push_back(it->second);
+            const MtAvatar& a = *it->second;
             for (int i = 0; i < reqs[r].batch; ++i) {
                 const int idx = mirror_index(a.n, reqs[r].index + i);   // musetalk_avatar.py:137-139
                 lptr.push_back(a.d_latents + (size_t)idx * 8 * 1024);
@@ -1218,17 +1255,17 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
         }
     }
     const int total = (int)lptr.size();
-    hipEvent_t done;
-    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    Ev done_ev;
+    CHK(done_ev.create());
+    const hipEvent_t done = done_ev.e;
     int rc = 0;
     {
         std::lock_guard<std::mutex> g(e->mu);
         if (stream) {
-            hipEvent_t ready;
-            CHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-            CHK(hipEventRecord(ready, (hipStream_t)stream));
-            CHK(hipStreamWaitEvent(e->compute, ready, 0));
-            CHK(hipEventDestroy(ready));
+            Ev ready;
+            CHK(ready.create());
+            CHK(hipEventRecord(ready.e, (hipStream_t)stream));
+            CHK(hipStreamWaitEvent(e->compute, ready.e, 0));
         }
         for (int f0 = 0; f0 < total && !rc; f0 += e->mt_max_frames) {
             const int nf = std::min(e->mt_max_frames, total - f0);
@@ -1247,7 +1284,6 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
     }
-    (void)hipEventDestroy(done);
     return rc;
 }
 
@@ -1256,11 +1292,13 @@ int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, v
     const uint8_t *full, *mask;
     int H, W;
     int32_t fb[4], cb[4];
+    std::shared_ptr<MtAvatar> hold;
     {
         std::lock_guard<std::mutex> g(e->pool_mu);
         auto it = e->mt_avatars.find(avatar_id);
         if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
-        const MtAvatar& a = it->second;
+        hold = it->second;
+        const MtAvatar& a = *hold;
         if (idx < 0 || idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
         H = a.H; W = a.W;
         full = a.d_full + (size_t)idx * H * W * 3;
@@ -1349,18 +1387,20 @@ int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* q, uint
     std::lock_guard<std::mutex> gs(s->mu);
     StreamLease sl(e, stream);
     const uint8_t* src = nullptr;
+    std::shared_ptr<Avatar> hold_w;           // keep the bank alive until the stream has been synchronised below
+    std::shared_ptr<MtAvatar> hold_m;
     if (q->source == LTK_SRC_HOST) {
         if (!q->h_frame) return fail(LTK_E_INVALID, "LTK_SRC_HOST without h_frame");
         CHK(hipMemcpyAsync(s->d_frame, q->h_frame, bytes, hipMemcpyHostToDevice, sl.s));
         src = s->d_frame;
     } else if (q->source == LTK_SRC_WAV2LIP) {
-        Avatar a;
         {
             std::lock_guard<std::mutex> g(e->pool_mu);
             auto it = e->avatars.find(q->avatar);
             if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
-            a = it->second;
+            hold_w = it->second;
         }
+        const Avatar& a = *hold_w;
         if (q->idx < 0 || q->idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
         if (a.H != H || a.W != W) return fail(LTK_E_INVALID, "avatar frame size differs from the egress session");
         const uint8_t* full = a.d_full + (size_t)q->idx * bytes;
@@ -1378,7 +1418,8 @@ int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* q, uint
             std::lock_guard<std::mutex> g(e->pool_mu);
             auto it = e->mt_avatars.find(q->avatar);
             if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
-            const MtAvatar& a = it->second;
+            hold_m = it->second;
+            const MtAvatar& a = *hold_m;
             if (q->idx < 0 || q->idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
             if (a.H != H || a.W != W) return fail(LTK_E_INVALID, "avatar frame size differs from the egress session");
             full = a.d_full + (size_t)q->idx * bytes;
@@ -1521,8 +1562,9 @@ int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, 
         return fail(LTK_E_INVALID, "bad arguments");
     if (!e->whisper) return fail(LTK_E_STATE, "ltk_whisper_load has not been called");
     CHK(hipSetDevice(e->device));
-    hipEvent_t done;
-    CHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    Ev done_ev;
+    CHK(done_ev.create());
+    const hipEvent_t done = done_ev.e;
     int rc = 0;
     {
         std::lock_guard<std::mutex> g(e->mu);
@@ -1545,7 +1587,6 @@ int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, 
         if (stream && hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed");
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
     }
-    (void)hipEventDestroy(done);
     return rc;
 }
 
