@@ -223,6 +223,12 @@ int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* 
 int ltk_musetalk_debug_get(ltk_engine* e, const char* name, int frames, float* out, size_t n_floats);
 /* average milliseconds of one U-Net + VAE pass over `frames` frames, and its conv/linear MACs */
 int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
+/* Per-op view of the MuseTalk launch program (profiling): op names in execution order (diffusers module paths), type 0 conv /
+ * linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos; time of every op inside a whole pass (HIP events between
+ * consecutive ops on the compute stream). */
+int ltk_musetalk_op_count(ltk_engine* e);
+int ltk_musetalk_op_name(ltk_engine* e, int op, char* buf, int buf_len, int* type);
+int ltk_musetalk_time_ops(ltk_engine* e, int frames, int iters, float* ms_per_op, int n_ops);
 
 
 /* Run Wav2Lip.forward on explicit inputs: mel host float32 [B][80][16], face6

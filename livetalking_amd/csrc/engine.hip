@@ -1508,6 +1508,43 @@ int ltk_musetalk_debug_get(ltk_engine* e, const char* name, int frames, float* o
     return LTK_OK;
 }
 
+int ltk_musetalk_op_count(ltk_engine* e) { return (e && e->mt) ? mt_op_count(e->mt) : 0; }
+
+int ltk_musetalk_op_name(ltk_engine* e, int op, char* buf, int buf_len, int* type) {
+    if (!e || !e->mt || !buf || buf_len <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    const char* n = mt_op_name(e->mt, op, type);
+    if (!n) return fail(LTK_E_INVALID, "no such op");
+    snprintf(buf, (size_t)buf_len, "%s", n);
+    return LTK_OK;
+}
+
+int ltk_musetalk_time_ops(ltk_engine* e, int frames, int iters, float* ms_per_op, int n_ops) {
+    if (!e || frames <= 0 || iters <= 0 || !ms_per_op) return fail(LTK_E_INVALID, "bad arguments");
+    if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
+    if (frames > e->mt_max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
+    if (n_ops != mt_op_count(e->mt)) return fail(LTK_E_INVALID, "n_ops != ltk_musetalk_op_count");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    std::vector<hipEvent_t> evs((size_t)n_ops + 1);
+    for (auto& ev : evs) CHK(hipEventCreate(&ev));
+    std::vector<double> acc((size_t)n_ops, 0.0);
+    int rc = mt_run(e->mt, frames, e->d_partial, e->partial_cap, e->compute);
+    for (int it = 0; it < iters && !rc; ++it) {
+        rc = mt_run_timed(e->mt, frames, e->d_partial, e->partial_cap, e->compute, &evs);
+        if (rc) break;
+        CHK(hipEventSynchronize(evs.back()));
+        for (int i = 0; i < n_ops; ++i) {
+            float ms = 0.f;
+            CHK(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto& ev : evs) (void)hipEventDestroy(ev);
+    if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    for (int i = 0; i < n_ops; ++i) ms_per_op[i] = (float)(acc[i] / iters);
+    return LTK_OK;
+}
+
 int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass) {
     if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");

@@ -1,5 +1,6 @@
 // MuseTalk device program (musetalk.hip): graph construction from diffusers-named state dicts and execution.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -27,6 +28,10 @@ f16* mt_ctx_in(MtGraph* g, int* cbt);          // [N][24][50][16]
 f16* mt_unet_out(MtGraph* g, int* cbt);        // [N][1][1024][16] (4 real channels)
 f16* mt_vae_out(MtGraph* g, int* cbt);         // [N][1][65536][16] (3 real channels, RGB)
 int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s);
+// per-op view (profiling): ops in execution order; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos
+int mt_op_count(MtGraph* g);
+const char* mt_op_name(MtGraph* g, int i, int* type);
+int mt_run_timed(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, std::vector<hipEvent_t>* evs);
 // named intermediate (debug / parity): returns device pointer + geometry, or null
 f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, int* W);
 double mt_macs_per_frame(const MtGraph* g);

@@ -748,11 +748,14 @@ void mt_graph_free(MtGraph& g) {
 
 f16* mt_ptr(const MtGraph& g, const MtTensor& t) { return g.bufs[t.buf]; }
 
-int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStream_t s, int op_begin, int op_end) {
+// `evs` (measurement): one event in front of every op and one behind the last
+int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStream_t s, int op_begin, int op_end,
+                 std::vector<hipEvent_t>* evs = nullptr) {
     if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
     if (op_end < 0) op_end = (int)g.ops.size();
     for (int oi = op_begin; oi < op_end; ++oi) {
         const MtOp& op = g.ops[oi];
+        if (evs) (void)hipEventRecord((*evs)[oi - op_begin], s);
         switch (op.type) {
             case OP_CONV: {
                 ConvIO io;
@@ -801,11 +804,21 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                 break;
         }
     }
+    if (evs) (void)hipEventRecord((*evs)[op_end - op_begin], s);
     if (hipGetLastError() != hipSuccess) { g.err = "a MuseTalk kernel launch failed"; return -2; }
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------ public wrappers
+int mt_op_count(MtGraph* g) { return (int)g->ops.size(); }
+const char* mt_op_name(MtGraph* g, int i, int* type) {
+    if (i < 0 || i >= (int)g->ops.size()) return nullptr;
+    if (type) *type = (int)g->ops[i].type;
+    return g->ops[i].name.c_str();
+}
+int mt_run_timed(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, std::vector<hipEvent_t>* evs) {
+    return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1, evs);
+}
 MtGraph* mt_graph_new() { return new MtGraph(); }
 void mt_graph_delete(MtGraph* g) {
     if (!g) return;

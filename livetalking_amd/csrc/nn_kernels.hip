@@ -8,6 +8,7 @@
 //   GEGLU              FeedForward.net[0]
 // In-tree statements of the same blocks: avatars/musetalk/models/syncnet.py:71-181.
 #include "nn_kernels.h"
+#include "tune.h"
 
 #include <hip/hip_fp16.h>
 
@@ -379,6 +380,131 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     }
 }
 
+// Wide single head (VAE mid-block attention: 1 head of 512 channels, 1024 tokens; vae.py:96-108 -> AutoencoderKL mid block).
+// The 4 waves of a block take the SAME 32 queries and split BOTH contractions:
+//   S^T = K Q^T over the channel dimension: wave w contracts channel blocks [8w, 8w+8) (8 MFMAs per 32-key tile instead of
+//         32), the four partial S^T tiles meet in LDS (one 16-byte-strided exchange area per key-tile parity, one barrier
+//         per key tile) and every wave then holds the complete tile in the usual register layout;
+//   O^T += V^T P^T over the value channels: wave w owns value channels [128w, 128w+128) as before.
+// Per key tile a wave issues 16 MFMAs (attn_kernel<32,4,true> issued 40: every wave recomputed the whole S^T), its 8 Q
+// fragments stay in registers for the whole kernel (they were re-read from memory for every key tile), and the K / V^T
+// fragments of tile t+1 are loaded while tile t is computed.
+__global__ __launch_bounds__(256, 2) void attn_wide_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float xch[2][4][4][64][4];        // [parity][wave][register quad][lane][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = blockIdx.x * 32;
+    const int Tq = a.Tq, Tk = a.Tk, Tkp = a.Tkp;
+    constexpr int DTW = 8, DVT = 4;                      // channel blocks / value tiles per wave (512 channels over 4 waves)
+    const int j0 = wave * DTW;
+    const f16* qb = a.q + ((size_t)(n * a.q_cbt + a.q_cb0 + h * 32 + j0) * Tq) * 16 + hh * 8;
+    const f16* kb = a.k + ((size_t)(n * a.k_cbt + a.k_cb0 + h * 32 + j0) * Tk) * 16 + hh * 8;
+    const f16* vtb = a.vt + ((size_t)(n * a.heads + h) * a.dv32 + wave * DVT * 32 + l31) * Tkp + hh * 8;
+    const int qrow = min(q0 + l31, Tq - 1);
+
+    f16x8 qf[DTW];
+#pragma unroll
+    for (int j = 0; j < DTW; ++j) qf[j] = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
+    f32x16 acc[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    f16x8 kf[DTW];
+    auto load_k = [&](int key0) {
+        const int krow = min(key0 + l31, Tk - 1);
+#pragma unroll
+        for (int j = 0; j < DTW; ++j) kf[j] = *reinterpret_cast<const f16x8*>(kb + ((size_t)j * Tk + krow) * 16);
+    };
+    load_k(0);
+    int par = 0;
+    for (int key0 = 0; key0 < Tk; key0 += 32, par ^= 1) {
+        // this tile's V^T fragments: needed only after the softmax, their latency hides behind the S^T work
+        f16x8 vcur[2][DVT];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) vcur[s2][t] = *reinterpret_cast<const f16x8*>(vtb + (size_t)t * 32 * Tkp + key0 + s2 * 16);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DTW; ++j) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[j], qf[j], st, 0, 0, 0);
+        if (key0 + 32 < Tk) load_k(key0 + 32);            // next tile's K fragments fly while this one is reduced and applied
+        // partial S^T tiles of the four waves -> LDS -> full tile in every wave
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<f32x4*>(&xch[par][wave][q4][lane][0]) = (f32x4){st[4 * q4], st[4 * q4 + 1], st[4 * q4 + 2], st[4 * q4 + 3]};
+        __syncthreads();
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const int ow = (wave + w) & 3;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(&xch[par][ow][q4][lane][0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[4 * q4 + r] += o[r];
+            }
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+            if (key >= Tk) st[r] = -1e30f;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);
+        float ls = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+        l = l * alpha + ls;
+        m = m_new;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pf[r] = (f16)p[8 * s2 + r]; pf[4 + r] = (f16)p[8 * s2 + 4 + r]; }
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vcur[s2][t], pf, acc[t], 0, 0, 0);
+        }
+    }
+    const float inv = 1.f / (l + __shfl_xor(l, 32));
+    const bool qok = (q0 + l31) < Tq;
+    f16* ob = a.o + ((size_t)(n * a.o_cbt + a.o_cb0 + h * 32) * Tq + q0 + l31) * 16 + hh * 8;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int cbl = (wave * DVT + t) * 2 + pr;       // channel block of the head
+            unsigned pk[2][2];
+#pragma unroll
+            for (int eo = 0; eo < 2; ++eo) {
+                const int g = 2 * pr + eo;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[t][4 * g + r] * inv);
+                const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                pk[eo][0] = u.x; pk[eo][1] = u.y;
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (qok) *reinterpret_cast<uint4*>(ob + (size_t)cbl * Tq * 16) = out;
+        }
+    }
+}
+
 int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, int k_cbt, int k_cb0, int Tk, const f16* vt,
                      f16* o, int o_cbt, int o_cb0, int N, int heads, int d16, hipStream_t s) {
     AttnArgs a;
@@ -392,7 +518,10 @@ int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, i
         case 64: hipLaunchKernelGGL((attn_kernel<4, 2, false>), grid4, dim3(256), 0, s, a); break;
         case 80: hipLaunchKernelGGL((attn_kernel<5, 3, false>), grid4, dim3(256), 0, s, a); break;
         case 160: hipLaunchKernelGGL((attn_kernel<10, 5, false>), grid4, dim3(256), 0, s, a); break;
-        case 512: hipLaunchKernelGGL((attn_kernel<32, 4, true>), grid1, dim3(256), 0, s, a); break;
+        case 512:
+            if (knob(K_ATTN_WIDE)) hipLaunchKernelGGL(attn_wide_kernel, grid1, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_kernel<32, 4, true>), grid1, dim3(256), 0, s, a);
+            break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

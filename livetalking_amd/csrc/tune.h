@@ -30,6 +30,7 @@ enum Knob {
     K_TILE_RULE,          // LTK_TILE_RULE      conv3 3x3 tile selection: 1 = items-per-CU rule (round 2), 0 = round-1 heuristic (A/B)
     K_TILE_TABLE,         // LTK_TILE_TABLE     1: use the engine's per-layer measured tile table where it has an entry
     K_CONV7,              // LTK_CONV7          1: dedicated first-layer kernel (7x7, 6 -> 16) with the input pack fused
+    K_ATTN_WIDE,          // LTK_ATTN_WIDE      1: cooperative kernel for the 512-channel single-head attention of the VAE mid block
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
     K_COUNT
 };

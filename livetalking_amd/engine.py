@@ -230,6 +230,21 @@ class Engine:
         _lib.check(self._lib.ltk_musetalk_info(self._h, C.byref(macs), C.byref(macs8)))
         return macs.value, macs8.value
 
+    def musetalk_ops(self):
+        """[(name, type)] of the MuseTalk launch program; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos."""
+        out = []
+        for i in range(self._lib.ltk_musetalk_op_count(self._h)):
+            buf, t = C.create_string_buffer(160), C.c_int()
+            _lib.check(self._lib.ltk_musetalk_op_name(self._h, i, buf, 160, C.byref(t)))
+            out.append((buf.value.decode(), t.value))
+        return out
+
+    def musetalk_time_ops(self, frames: int, iters: int) -> np.ndarray:
+        n = self._lib.ltk_musetalk_op_count(self._h)
+        ms = (C.c_float * n)()
+        _lib.check(self._lib.ltk_musetalk_time_ops(self._h, int(frames), int(iters), ms, n))
+        return np.array(ms[:], dtype=np.float64)
+
     def musetalk_time(self, frames: int, iters: int):
         ms = C.c_float()
         macs = C.c_double()
