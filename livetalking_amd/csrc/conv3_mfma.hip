@@ -114,7 +114,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     constexpr int BN = NBT * 32;
     constexpr int MAXA = k3_maxa(PXW, NC8, S, T);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
-    static_assert(G == 1 || (G == 4 && T == 9 && NBT == 1), "merged convT: 9 taps, 32 couts per block");
+    static_assert(G == 1 || (G == 4 && (T == 9 || T == 16) && NBT == 1), "merged convT (9 taps) / upsample-conv (16): 32 couts per block");
     static_assert(NBT <= 2 || T == 1, "128-cout blocks: 1x1 convolutions only (accumulator budget)");
     static_assert(Q == 0 || G == 1, "fp8 operands: plain convolutions only");
     constexpr int MPP = Q ? 2 : 1;         // MFMAs per (cout subtile, pixel subtile) pair and k16 plane pair
@@ -220,7 +220,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // offset dy * PW * 32 is wave-uniform.  The half swap follows the patch column only, so a tap costs ONE v_add per
     // fragment (uniform stage/row offset + aj[j][dx]); with the swap on the pixel index every tap re-derived it: 6 VALU per
     // fragment, 218 of the 385 non-MFMA instructions of a 72-MFMA chunk, which made the loop issue-bound.
-    constexpr int DXN = (T == 9 && G == 1) ? 3 : (G == 4 ? 2 : 1);
+    constexpr int DXN = ((T == 9 && G == 1) || (G == 4 && T == 16)) ? 3 : (G == 4 ? 2 : 1);
     int aj[PXW][DXN];
 #pragma unroll
     for (int j = 0; j < PXW; ++j) {
@@ -298,6 +298,32 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                         __builtin_amdgcn_sched_group_barrier(0x008, NBT * PXW * MPP, 0);   // then the MFMAs of tap t
                     }
                 }
+            } else if constexpr (T == 16) {
+                // nearest-2x upsample + 3x3 conv as four 2x2-tap phases (ConvPlan::ups4): the nine source offsets (dy,dx) of
+                // the (TH+2)x(TW+2) patch, each feeding the phases g = (py<<1)|px with dy in {py, py+1}, dx in {px, px+1};
+                // weight matrix t follows that walk (conv_plan_create)
+                auto wfrag = [&](int t) {
+                    return *reinterpret_cast<const f16x8*>(Bb + (((t * NC8 + plane) * 32) + l31) * 16);
+                };
+                int t = 0;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        f16x8 xa[PXW];
+#pragma unroll
+                        for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + dy * rowB + aj[j][dx]);
+#pragma unroll
+                        for (int py = 0; py < 2; ++py)
+#pragma unroll
+                            for (int px = 0; px < 2; ++px) {
+                                if ((dy != py && dy != py + 1) || (dx != px && dx != px + 1)) continue;
+                                const f16x8 wf = wfrag(t++);
+#pragma unroll
+                                for (int j = 0; j < PXW; ++j)
+                                    acc[py * 2 + px][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[j], acc[py * 2 + px][0][j], 0, 0, 0);
+                            }
+                    }
             } else {
                 auto wfrag = [&](int t) {
                     return *reinterpret_cast<const f16x8*>(Bb + (((t * NC8 + plane) * 32) + l31) * 16);
@@ -651,6 +677,7 @@ static k3_kernel_t k3_pick(int G, int NBT, int PXW, int NC8, int T) {
     K3CASE(1, 2, 2, 8, 1); K3CASE(1, 1, 2, 8, 1); K3CASE(1, 2, 2, 2, 1); K3CASE(1, 1, 2, 2, 1);
     K3CASE(1, 4, 2, 4, 1); K3CASE(1, 2, 2, 4, 1); K3CASE(1, 1, 2, 4, 1);
     K3CASE(4, 1, 2, 2, 9); K3CASE(4, 1, 2, 4, 9);
+    K3CASE(4, 1, 2, 2, 16);                             // upsample + conv as four phases (ConvPlan::ups4)
 #undef K3CASE
     return nullptr;
 }
@@ -710,7 +737,14 @@ size_t conv3_partial_bytes(const ConvPlan& p, int N, int H, int W) {
     return (size_t)kMaxKSplit * N * Ho * Wo * p.CoutPad * sizeof(float);
 }
 
-int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::string* err) {
+int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std::string* err) {
+    // four-phase upsample-conv: the caller describes the conv on the UPSAMPLED map (io.H x io.W, ups = 1); the kernel works on
+    // the source map and writes the four phases of every source pixel, exactly like the merged transposed conv
+    ConvIO io = io_in;
+    if (p.ups4) {
+        if (!io.ups || ((io.H | io.W) & 1)) { if (err) *err = "conv3: a four-phase upsample-conv plan needs ups = 1 and even H, W"; return -1; }
+        io.H /= 2; io.W /= 2; io.ups = 0;
+    }
     K3Args a;
     memset(&a, 0, sizeof(a));
     const int G = p.v3_G, T = p.v3_T, NC8 = p.NC8;
@@ -725,7 +759,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
     int ext;
     const int S = p.v3_S;
     a.Ho = io.H; a.Wo = io.W;
-    if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = 0; ext = 1; }
+    if (G == 4) { a.HoA = 2 * io.H; a.WoA = 2 * io.W; a.pad = p.ups4 ? 1 : 0; ext = p.ups4 ? 2 : 1; }
     else if (S == 2) {   // pad 1, or pad 0 + one zero row/column at the bottom/right (p.out_pad)
         a.Ho = (io.H + 2 * p.ph + p.out_pad - 3) / 2 + 1; a.Wo = (io.W + 2 * p.pw + p.out_pad - 3) / 2 + 1;
         a.HoA = a.Ho; a.WoA = a.Wo; a.pad = p.ph; ext = 2;

@@ -70,6 +70,10 @@ struct ConvPlan {
     int v3_G = 1;                         // 1 = conv, 4 = merged transposed conv (4 sub-pixel phases per block)
     int v3_T = 9;                         // taps: 9 (3x3 / merged convT) or 1 (1x1)
     int v3_S = 1;                         // stride (3x3 pad 1 only): 1 or 2
+    // nearest-2x upsample + 3x3 conv (diffusers Upsample2D) as FOUR sub-pixel phases of 2x2 taps each on the source map:
+    // v3_G = 4, v3_T = 16 (operand, phase) pairs with the 3x3 weights pre-summed per phase -- 16 MACs per source pixel and
+    // channel pair instead of 36; `io.H, io.W` stay the upsampled size
+    bool ups4 = false;
     // fp8 operands (conv3, 3x3 stride 1): the input is [N][CinReal/32][H][W][32] e4m3 bytes holding x * act_scale; Cin
     // above then counts 16-bit units (= CinReal / 2) so that every byte offset of the fp16 path carries over
     bool q8 = false;
@@ -93,7 +97,8 @@ struct ConvPlan {
 int conv_plan_create(ConvPlan* p, const float* weight, int Cin, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
                      const float* scale, const float* shift, std::string* err, int hint_hw = 0,
-                     int quant = 0, float act_scale = 1.f);
+                     int quant = 0, float act_scale = 1.f, int ups4 = 0);
+// `ups4` = 1: the conv always runs on a nearest-2x upsampled input (ConvIO::ups): build the four-phase form (ConvPlan::ups4).
 // `quant` = 1: e4m3 weights with one scale per output channel (224 / max|w|), folded together with `act_scale`
 // (what the producer of the fp8 input multiplied by) into the epilogue scale.  3x3 stride-1 pad-1 convs, Cin % 32 == 0.
 

@@ -462,7 +462,7 @@ unsigned char f32_to_e4m3(float v) {
 
 int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int kh, int kw,
                      int sh, int sw, int ph, int pw, bool transposed, int out_pad,
-                     const float* scale, const float* shift, std::string* err, int hint_hw, int quant, float act_scale) {
+                     const float* scale, const float* shift, std::string* err, int hint_hw, int quant, float act_scale, int ups4) {
     *p = ConvPlan();
     if (quant) {
         if (transposed || kh != 3 || kw != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || CinArg % 32 != 0) {
@@ -488,7 +488,46 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     std::vector<std::pair<int, int>> phase_off;
     const bool v3_on = knob(K_CONV_V3) != 0;
     const bool is_convT_s2 = transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && out_pad == 1;
-    if (v3_on && is_convT_s2 && Cin % 16 == 0) {
+    // Upsample2D = F.interpolate(scale_factor=2, nearest) + Conv2d(3x3, pad 1).  Output pixel (2y+py, 2x+px) reads upsampled rows
+    // 2y+py+ky-1, i.e. source rows y + floor((py+ky-1)/2): phase py=0 sees rows {y-1 <- ky 0, y <- ky 1,2}, phase py=1 rows
+    // {y <- ky 0,1, y+1 <- ky 2} (columns alike).  So every phase is a 2x2 conv on the SOURCE map whose weights are sums of the
+    // 3x3 taps: 16 (operand, phase) products per source pixel instead of 36.  Operands (dy,dx) in 0..2 address the 3x3 source
+    // neighbourhood (patch origin y-1, x-1); the kernel walks them row-major and feeds phases g = (py<<1)|px in ascending order.
+    std::vector<float> weff;
+    const float* wsrc = weight;
+    int wkh = kh, wkw = kw;
+    if (ups4 && v3_on && knob(K_UPS4) && !transposed && !quant && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
+        out_pad == 0 && Cin % 16 == 0) {
+        p->v3 = true; p->v3_G = 4; p->v3_T = 16; p->ups4 = true;
+        lsh = lsw = 1;
+        std::vector<Tap> taps;
+        weff.assign((size_t)Cout * CinReal * 16, 0.f);
+        int t = 0;
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx)
+                for (int py = 0; py < 2; ++py)
+                    for (int px = 0; px < 2; ++px) {
+                        if (dy != py && dy != py + 1) continue;
+                        if (dx != px && dx != px + 1) continue;
+                        // 3x3 taps of this phase that land on source offset (dy, dx)
+                        int kys[2], nky = 0, kxs[2], nkx = 0;
+                        for (int ky = 0; ky < 3; ++ky) if (1 + ((py + ky - 1) >> 1) == dy) kys[nky++] = ky;     // floor((py+ky-1)/2) + 1
+                        for (int kx = 0; kx < 3; ++kx) if (1 + ((px + kx - 1) >> 1) == dx) kxs[nkx++] = kx;
+                        for (int co = 0; co < Cout; ++co)
+                            for (int ci = 0; ci < CinReal; ++ci) {
+                                float acc = 0.f;
+                                for (int a = 0; a < nky; ++a)
+                                    for (int b = 0; b < nkx; ++b) acc += weight[(((size_t)co * CinReal + ci) * 3 + kys[a]) * 3 + kxs[b]];
+                                weff[((size_t)co * CinReal + ci) * 16 + t] = acc;
+                            }
+                        taps.push_back({t >> 2, t & 3, dy, dx});
+                        ++t;
+                    }
+        if (t != 16) { if (err) *err = "ups4 tap table"; return -1; }
+        phases.push_back(taps);
+        phase_off.push_back({0, 0});
+        wsrc = weff.data(); wkh = 4; wkw = 4;
+    } else if (v3_on && is_convT_s2 && Cin % 16 == 0) {
         // conv3 merged transposed conv: ONE phase of 9 taps over a 2x2 input neighbourhood, in the tap order the
         // kernel's static table expects (offset (0,0): phases 0..3, (0,1): 1,3, (1,0): 2,3, (1,1): 3)
         p->v3 = true; p->v3_G = 4; p->v3_T = 9;
@@ -565,6 +604,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
         // 1x1: 64-channel chunks; wide outputs take 32-channel chunks so that a 128-cout block (conv3_launch) still fits two
         // resident blocks per CU
         if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && knob(K_GEMM_NC8) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
+        else if (p->ups4) NC8 = 2;          // 16 weight matrices per chunk: 16-channel chunks keep two blocks per CU
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
         else {
             // 16-channel chunks everywhere: measured (profiles/r02_conv_sweep.txt) equal or better than 32-channel chunks on
@@ -598,8 +638,8 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
 
     auto wval = [&](int co, int ci, int ky, int kx) -> float {
         if (ci >= CinReal) return 0.f;
-        if (!transposed) return weight[(((size_t)co * CinReal + ci) * kh + ky) * kw + kx];
-        return weight[(((size_t)ci * Cout + co) * kh + ky) * kw + kx];
+        if (!transposed) return wsrc[(((size_t)co * CinReal + ci) * wkh + ky) * wkw + kx];
+        return wsrc[(((size_t)ci * Cout + co) * wkh + ky) * wkw + kx];
     };
     // fp8: per-output-channel scale, and the 16-bit unit (two consecutive input channels, low byte first)
     std::vector<float> wq_scale;
