@@ -49,12 +49,14 @@ def main():
         s[0] += 1; s[1] += d; s[2] = min(s[2], d); s[3] = max(s[3], d)
     tot = sum(s[1] for s in stats.values())
     with open(a.dst_prefix + "_kernel_stats.csv", "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline  (wav2lip256, 1 session, 16-frame batch)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic  (wav2lip256, 1 session, 16-frame batch)\n")
         f.write("kernel,calls,total_us,avg_us,min_us,max_us,pct,vgpr,sgpr\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1]):
             f.write(f"\"{k}\",{s[0]},{s[1]:.1f},{s[1]/s[0]:.2f},{s[2]:.2f},{s[3]:.2f},{100*s[1]/tot:.2f},{s[4]},{s[5]}\n")
     # one inference pass
-    idx = [i for i, r in enumerate(rows) if "pack_faces" in r[0]]
+    # a pass starts with the mel pack (the face pack is fused into the first conv since round 2) and ends with the output conv
+    # that carries the fused head (or the separate head kernel of the unfused path)
+    idx = [i for i, r in enumerate(rows) if "pack_mel" in r[0]]
     conv_us = 0.0
     with open(a.dst_prefix + "_pass_timeline.txt", "w") as f:
         f.write("# last inference pass of the profiled run: start_us dur_us stream grid lds_bytes kernel\n")
@@ -68,6 +70,7 @@ def main():
                 if "head_kernel" in n:
                     f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us\n")
                     break
+            f.write(f"# launches in the pass: {sum(1 for r in rows[idx[-1]:] if True)} (to the end of the trace)\n")
     fetch = counters(os.path.join(a.src, "pmc_fetch", "r_results.db"))
     write = counters(os.path.join(a.src, "pmc_write", "r_results.db"))
     sq = counters(os.path.join(a.src, "pmc_sq", "r_results.db"))
@@ -80,7 +83,7 @@ def main():
     hit = sum(l2.get(k, {}).get("TCC_HIT_sum", (0, 0))[0] for k in conv)
     miss = sum(l2.get(k, {}).get("TCC_MISS_sum", (0, 0))[0] for k in conv)
     summary = {
-        "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline",
+        "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic",
         "conv_passes_in_run": a.passes,
         "frames_per_pass": a.frames,
         "hbm_read_bytes_per_pass": rd / a.passes,
