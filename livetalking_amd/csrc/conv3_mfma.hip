@@ -72,9 +72,7 @@ struct K3Args {
     int relu;                        // activation: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU
     int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
     int nitems;                      // work items (ksplit x pixel tiles x cout tiles); gridDim.x <= nitems
-    float* gn_stats;                 // [N][gn_ld][2] sum / sum of squares per output channel, or nullptr (see ConvIO::gn_stats)
-    int gn_ld;
-    int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages; [2][BN] GroupNorm sums follow
+    int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
     int ablate;                      // measurement builds only (make ABLATE=1, knob LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA,
                                      // 8 no residual read, 16 no output store, 32 no LDS zero fill, 64 no epilogue, 128 epilogue math only
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
@@ -147,9 +145,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     const int iy0 = ty0 * S - a.pad, ix0 = tx0 * S - a.pad;
     const int PHW = a.PH * a.PW;
 
-    // GroupNorm partial sums of this item's output channels (ConvIO::gn_stats): [2][BN] floats behind the scale/shift image
-    float* const lds_gn = reinterpret_cast<float*>(smem + a.lds_scale_off) + 2 * BN;
-    if (a.gn_stats && tid < 2 * BN) lds_gn[tid] = 0.f;
     // ---- zero both A stages once: halo slots outside the image are never written by the DMA
     if (!ABL(a, 32)) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -543,11 +538,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                             sf[eo] = *reinterpret_cast<const f32x4*>(sbase + BN + cl);
                         }
                     }
-                    float gs[2][4], gq[2][4];           // GroupNorm sums of this lane's 8 channels over its PXW pixels
-#pragma unroll
-                    for (int eo = 0; eo < 2; ++eo)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { gs[eo][r] = 0.f; gq[eo][r] = 0.f; }
                     f16x4 rr[PXW][2];
                     if (has_res) {
 #pragma unroll
@@ -582,10 +572,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                                 }
                                 o[r] = (f16)t;
                             }
-                            if (a.gn_stats && okj[j]) {      // statistics of the values the consumer will read (fp16-rounded)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; gs[eo][r] += f; gq[eo][r] += f * f; }
-                            }
                             const uint2 u = *reinterpret_cast<const uint2*>(&o);
                             pk[eo][0] = u.x; pk[eo][1] = u.y;
                         }
@@ -596,23 +582,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                         const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         if (okj[j] && do_store) *reinterpret_cast<uint4*>(a.y + obase[j] + (2 * i + pr) * HWo16) = out;
                     }
-                    if (a.gn_stats) {
-                        // the 32 lanes of a half hold the same 8 channels for 32 different pixels: butterfly over them, lane 0 of
-                        // each half adds the wave's sums to the block's LDS table
-#pragma unroll
-                        for (int eo = 0; eo < 2; ++eo)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float sv = gs[eo][r], qv = gq[eo][r];
-#pragma unroll
-                                for (int m = 1; m < 32; m <<= 1) { sv += __shfl_xor(sv, m); qv += __shfl_xor(qv, m); }
-                                if (l31 == 0) {
-                                    const int cl = i * 32 + 8 * (2 * pr + eo) + 4 * hh + r;
-                                    atomicAdd(&lds_gn[cl], sv);
-                                    atomicAdd(&lds_gn[BN + cl], qv);
-                                }
-                            }
-                    }
                 }
             }
         }
@@ -621,14 +590,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     else if (a.relu == 2) epilogue(std::integral_constant<int, 2>{});
     else if (a.relu == 3) epilogue(std::integral_constant<int, 3>{});
     else epilogue(std::integral_constant<int, 0>{});
-    if (a.gn_stats) {      // one global atomic per channel and statistic for the whole block (the launch guarantees NB == 1: one image)
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int k = tid / BN, c = tid - k * BN;
-            if (cout0 + c < a.Cout)
-                atomicAdd(a.gn_stats + ((size_t)n0 * a.gn_ld + (size_t)a.y_cb0 * 16 + cout0 + c) * 2 + k, lds_gn[k * BN + c]);
-        }
-    }
 }
 
 // Persistent launch: the grid is at most `2 x CUs` blocks (what is resident at once) and every block walks the item
@@ -899,11 +860,6 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     lds = (lds + 255) / 256 * 256;
     a.lds_scale_off = (int)lds;
     if (T != 1) lds += 2 * BN * sizeof(float);
-    // GroupNorm statistics in the epilogue: needs the LDS table (not on the 1x1 kernels, whose stages fill the CU's LDS), one
-    // image per tile, no split-K (the finish kernel would have to do it) and no fused head
-    const bool gn = io.gn_stats != nullptr && T != 1 && ksplit == 1 && NB == 1 && !(io.head_w && io.head_outs) && knob(K_GN_FUSED);
-    if (gn) { a.gn_stats = io.gn_stats; a.gn_ld = io.gn_ld; lds += 2 * BN * sizeof(float); }
-    if (io.gn_fused) *io.gn_fused = gn ? 1 : 0;
     if (lds > 160 * 1024) { if (err) *err = "conv3: LDS budget exceeded"; return -1; }
     if (p.q8 && !(G == 1 && T == 9 && S == 1)) { if (err) *err = "conv3: fp8 operands are implemented for 3x3 stride-1 convs"; return -1; }
     const bool head = io.head_w != nullptr && io.head_outs != nullptr;

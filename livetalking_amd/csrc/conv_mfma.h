@@ -115,12 +115,6 @@ struct ConvIO {
     int act = 0;                   // epilogue activation when relu == 0: 0 none, 2 GELU (erf), 3 SiLU
     int ups = 0;                   // conv3 only: the input map is H/2 x W/2 and is read through a nearest-neighbour
                                    // 2x upsample (diffusers Upsample2D: F.interpolate(scale_factor=2) then conv)
-    // GroupNorm statistics of the OUTPUT accumulated by the epilogue (conv3, where the launch allows it): table
-    // gn_stats[n][gn_ld][2] (sum, sum of squares per channel of the output buffer; channel index = y_coff + cout);
-    // *gn_fused tells the caller whether this launch did it (else it runs launch_gn_stats_atomic itself)
-    float* gn_stats = nullptr;
-    int gn_ld = 0;
-    int* gn_fused = nullptr;
     int force_pxw = 0, force_nbt = 0, force_ksplit = 0;   // conv3: per-layer tile / split choice of the caller's table (0 = rule)
     const float* head_w = nullptr;     // conv3, 3x3 stride-1 layers of 32 output channels only: fuse the Wav2Lip output head
     const void* head_outs = nullptr;   // (1x1 conv 32->3 + sigmoid + uint8 truncation; wav2lip_v2.py:90-91): device [3][32]+[3]

@@ -81,8 +81,6 @@ struct MtOp {
     float eps = 1e-5f;
     int heads = 1, d16 = 0;
     int Tk = 0;
-    bool feeds_gn = false;      // OP_CONV: the output is (part of) a GroupNorm input -> its statistics go to the per-tensor table
-    bool stats2 = false;        // OP_GN: statistics come from that table (every producer of the input range is a conv)
 };
 
 struct MtGraph {
@@ -94,11 +92,6 @@ struct MtGraph {
     std::map<std::string, MtTensor> named;
     float* gn_partial = nullptr;
     size_t gn_partial_floats = 0;
-    // per-tensor GroupNorm statistics (sum, sum of squares per channel): one [frames][ld][2] region per buffer that a GroupNorm
-    // reads, filled by the producing convs' epilogues (ConvIO::gn_stats) or launch_gn_stats_atomic, zeroed at the start of a pass
-    float* gn_stats = nullptr;
-    size_t gn_stats_floats = 0;
-    std::vector<long long> stats_off;      // per buffer: offset of its region in floats, -1 = none
     f16* vt = nullptr;                        // transposed values scratch
     size_t vt_halfs = 0;                      // per frame
     int frames = 0;
@@ -738,29 +731,6 @@ int mt_graph_alloc(MtGraph& g, int frames) {
         if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 256 * 32);
     g.gn_partial_floats = need;
     if (hipMalloc((void**)&g.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
-    // which GroupNorms can take their statistics from the producers: every channel of the input view must be written by a conv
-    g.stats_off.assign(g.buf_halfs.size(), -1);
-    size_t stats_floats = 0;
-    if (knob(K_GN_FUSED)) {
-        for (MtOp& op : g.ops) {
-            if (op.type != OP_GN) continue;
-            std::vector<char> covered((size_t)op.x.C, 0);
-            for (const MtOp& c : g.ops)
-                if (c.type == OP_CONV && c.y.buf == op.x.buf && !c.y.q8)
-                    for (int ch = std::max(c.y.coff, op.x.coff); ch < std::min(c.y.coff + c.y.C, op.x.coff + op.x.C); ++ch) covered[ch - op.x.coff] = 1;
-            bool all = true;
-            for (char v : covered) all = all && v;
-            op.stats2 = all;
-            if (all && g.stats_off[op.x.buf] < 0) {
-                g.stats_off[op.x.buf] = (long long)stats_floats;
-                stats_floats += (size_t)frames * op.x.ld * 2;
-            }
-        }
-        for (MtOp& c : g.ops)
-            if (c.type == OP_CONV && !c.y.q8 && g.stats_off[c.y.buf] >= 0) c.feeds_gn = true;
-    }
-    g.gn_stats_floats = stats_floats;
-    if (stats_floats && hipMalloc((void**)&g.gn_stats, stats_floats * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     if (g.vt_halfs) {
         if (hipMalloc((void**)&g.vt, g.vt_halfs * frames * sizeof(f16)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     }
@@ -772,7 +742,6 @@ void mt_graph_free(MtGraph& g) {
     for (ConvPlan& p : g.plans) conv_plan_destroy(&p);
     for (float* v : g.vecs) if (v) (void)hipFree(v);
     if (g.gn_partial) (void)hipFree(g.gn_partial);
-    if (g.gn_stats) (void)hipFree(g.gn_stats);
     if (g.vt) (void)hipFree(g.vt);
     g.bufs.clear(); g.plans.clear(); g.vecs.clear();
 }
@@ -784,7 +753,6 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                  std::vector<hipEvent_t>* evs = nullptr) {
     if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
     if (op_end < 0) op_end = (int)g.ops.size();
-    if (g.gn_stats) (void)hipMemsetAsync(g.gn_stats, 0, g.gn_stats_floats * sizeof(float), s);
     for (int oi = op_begin; oi < op_end; ++oi) {
         const MtOp& op = g.ops[oi];
         if (evs) (void)hipEventRecord((*evs)[oi - op_begin], s);
@@ -797,27 +765,22 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                 io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
                 io.relu = 0; io.act = op.act; io.ups = op.ups;
                 io.partial = partial; io.partial_cap = partial_cap;
-                int fused = 0;
-                if (op.feeds_gn) { io.gn_stats = g.gn_stats + g.stats_off[op.y.buf]; io.gn_ld = op.y.ld; io.gn_fused = &fused; }
                 std::string e;
                 const int rc = conv_launch(g.plans[op.plan], io, s, &e);
                 if (rc) { g.err = op.name + ": " + e; return rc; }
-                if (op.feeds_gn && !fused)      // this launch could not accumulate (1x1 / split-K / several images per tile): one read pass
-                    launch_gn_stats_atomic(g.bufs[op.y.buf], nf, op.y.ld / 16, op.y.coff / 16, op.y.C, op.y.P(), g.gn_stats + g.stats_off[op.y.buf], s);
                 break;
             }
             case OP_GN: {
                 const int P = op.x.P();
                 const int segs = gn_segments(nf, op.x.C, P);
-                const float* st2 = op.stats2 ? g.gn_stats + g.stats_off[op.x.buf] : nullptr;
-                if (!st2) launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
+                launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
                 if (op.y.q8)
                     launch_gn_apply_fp8(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
                                         g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)g.bufs[op.y.buf],
-                                        op.y.ld / 32, op.y.coff / 32, s, st2);
+                                        op.y.ld / 32, op.y.coff / 32, s);
                 else
                     launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
-                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s, st2);
+                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
                 break;
             }
             case OP_LN:

@@ -14,19 +14,14 @@ namespace ltk {
 int gn_segments(int N, int C, int P);
 void launch_gn_stats(const f16* x, int N, int cbt, int cb0, int C, int P, int segs, float* partial, hipStream_t s);
 // y = (x - mean_g) * rstd_g * gamma + beta, optional SiLU; groups of C/groups consecutive channels
-// `stats2` != nullptr: statistics come from the per-tensor table stats2[n][x_cbt*16][2] (sum, sum of squares per channel) that
-// the producing conv epilogues (or launch_gn_stats_atomic) filled, `partial` / `segs` are ignored
 void launch_gn_apply(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
-                     int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s,
-                     const float* stats2 = nullptr);
-// sum / sum of squares of every channel of x added into stats[n][cbt*16][2] (the table must have been zeroed for this pass)
-void launch_gn_stats_atomic(const f16* x, int N, int cbt, int cb0, int C, int P, float* stats, hipStream_t s);
+                     int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s);
 
 // same, writing e4m3 bytes min(max(y * out_scale, -448), 448) into a [N][C/32][P][32] tensor (y_cbt / y_cb0 in 32-channel
 // blocks): the operand format of the fp8 conv path (conv3_mfma.hip, Q = 1)
 void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
                          int segs, const float* gamma, const float* beta, int silu, float out_scale, unsigned char* y, int y_cbt,
-                         int y_cb0, hipStream_t s, const float* stats2 = nullptr);
+                         int y_cb0, hipStream_t s);
 
 // ---- LayerNorm over channels per token (BasicTransformerBlock.norm1/2/3, Whisper layer norms)
 void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float eps, const float* gamma, const float* beta,

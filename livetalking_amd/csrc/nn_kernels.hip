@@ -82,61 +82,6 @@ void launch_gn_stats(const f16* x, int N, int cbt, int cb0, int C, int P, int se
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * CB, segs), dim3(256), 0, s, x, cbt, cb0, CB, P, segs, partial);
 }
 
-// Same reduction, result added into the per-tensor statistics table stats[n][ldC][2] (sum, sum of squares per channel) that the
-// conv epilogues also feed (conv3_mfma.hip, K3Args::gn_stats): the fallback for producers that cannot accumulate themselves.
-__global__ __launch_bounds__(256) void gn_stats_atomic_kernel(const f16* __restrict__ x, int cbt, int cb0, int CB, int P, int segs,
-                                                               float* __restrict__ stats) {
-    __shared__ float red[4][2][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = tid & 1, pl = tid >> 1;
-    const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB, seg = blockIdx.y;
-    const int seglen = (P + segs - 1) / segs;
-    const int p0 = seg * seglen, p1 = min(P, p0 + seglen);
-    const f16* base = x + ((size_t)(n * cbt + cb0 + cb) * P) * 16 + half * 8;
-    float s[8], q[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { s[c] = 0.f; q[c] = 0.f; }
-    int p = p0 + pl;
-    for (; p + 384 < p1; p += 512) {
-        const f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (size_t)p * 16);
-        const f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 128) * 16);
-        const f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 256) * 16);
-        const f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (size_t)(p + 384) * 16);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float f0 = (float)v0[c], f1 = (float)v1[c], f2 = (float)v2[c], f3 = (float)v3[c];
-            s[c] += (f0 + f1) + (f2 + f3);
-            q[c] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
-        }
-    }
-    for (; p < p1; p += 128) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)p * 16);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s[c] += f; q[c] += f * f; }
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-        for (int m = 2; m < 64; m <<= 1) { s[c] += __shfl_xor(s[c], m); q[c] += __shfl_xor(q[c], m); }
-    }
-    if (lane < 2) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { red[wave][0][lane * 8 + c] = s[c]; red[wave][1][lane * 8 + c] = q[c]; }
-    }
-    __syncthreads();
-    if (tid < 32) {
-        const int which = tid >> 4, c = tid & 15;
-        const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-        atomicAdd(stats + ((size_t)n * cbt * 16 + (size_t)(cb0 + cb) * 16 + c) * 2 + which, v);
-    }
-}
-
-void launch_gn_stats_atomic(const f16* x, int N, int cbt, int cb0, int C, int P, float* stats, hipStream_t s) {
-    const int CB = C / 16;
-    const int segs = gn_segments(N, C, P);
-    hipLaunchKernelGGL(gn_stats_atomic_kernel, dim3(N * CB, segs), dim3(256), 0, s, x, cbt, cb0, CB, P, segs, stats);
-}
-
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
@@ -144,23 +89,12 @@ template <bool FP8>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int CB, int P, int cpg,
                                                         float eps, const float* __restrict__ partial, int segs,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                                        f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale,
-                                                        const float* __restrict__ stats2) {
+                                                        f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale) {
     __shared__ float ab[2][16];
     __shared__ float red[2][16][17];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / CB, cb = blockIdx.x - n * CB;
-    if (stats2) {   // per-tensor table stats2[n][x_cbt*16][2] filled by the producers' epilogues: 16 threads per channel sum its group
-        const int c = cb * 16 + (tid & 15), sl = tid >> 4;
-        const int g0 = (c / cpg) * cpg;
-        float S = 0.f, Q = 0.f;
-        for (int i = sl; i < cpg; i += 16) {
-            const float* pp = stats2 + ((size_t)n * x_cbt * 16 + (size_t)x_cb0 * 16 + g0 + i) * 2;
-            S += pp[0]; Q += pp[1];
-        }
-        red[0][tid & 15][sl] = S;
-        red[1][tid & 15][sl] = Q;
-    } else {   // group statistics of this block's 16 channels: 16 threads per channel share the cpg x segs partial sums
+    {   // group statistics of this block's 16 channels: 16 threads per channel share the cpg x segs partial sums
         const int c = cb * 16 + (tid & 15), sl = tid >> 4;
         const int g0 = (c / cpg) * cpg;           // first channel of this channel's group
         const int terms = cpg * segs;
@@ -232,19 +166,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 }
 
 void launch_gn_apply(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
-                     int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s,
-                     const float* stats2) {
+                     int segs, const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, hipStream_t s) {
     const int CB = C / 16;
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
-                       partial, segs, gamma, beta, silu, y, y_cbt, y_cb0, 1.f, stats2);
+                       partial, segs, gamma, beta, silu, y, y_cbt, y_cb0, 1.f);
 }
 
 void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* partial,
                          int segs, const float* gamma, const float* beta, int silu, float out_scale, unsigned char* y, int y_cbt,
-                         int y_cb0, hipStream_t s, const float* stats2) {
+                         int y_cb0, hipStream_t s) {
     const int CB = C / 16;
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(N * CB, (P + 1023) / 1024), dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, eps,
-                       partial, segs, gamma, beta, silu, reinterpret_cast<f16*>(y), y_cbt, y_cb0, out_scale, stats2);
+                       partial, segs, gamma, beta, silu, reinterpret_cast<f16*>(y), y_cbt, y_cb0, out_scale);
 }
 
 // =============================================================================================== LayerNorm
