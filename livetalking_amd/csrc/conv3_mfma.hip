@@ -54,6 +54,8 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef long i64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct K3Args {
     const f16* x; const f16* w; const float* scale; const float* shift; const f16* res; f16* y;
@@ -117,7 +119,8 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     static_assert(G == 1 || (G == 4 && (T == 9 || T == 16) && NBT == 1), "merged convT (9 taps) / upsample-conv (16): 32 couts per block");
     static_assert(NBT <= 2 || T == 1, "128-cout blocks: 1x1 convolutions only (accumulator budget)");
     static_assert(Q == 0 || G == 1, "fp8 operands: plain convolutions only");
-    constexpr int MPP = Q ? 2 : 1;         // MFMAs per (cout subtile, pixel subtile) pair and k16 plane pair
+    static_assert(Q != 2 || (NC8 == 4 && T == 9), "MX fp8: 64-channel chunks, 3x3");
+    constexpr int MPP = Q == 1 ? 2 : 1;    // MFMAs per (cout subtile, pixel subtile) pair and k16 plane pair
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int pcol = in ? tx * S : 0;
 #pragma unroll
         for (int dx = 0; dx < DXN; ++dx)
-            aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ hh) << 4);
+            aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ (Q == 2 ? 0 : hh)) << 4);     // Q = 2 reads both halves
     }
 
     f32x16 acc[G][NBT][PXW];
@@ -257,6 +260,46 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         for (int j = 0; j < PXW; ++j)
 #pragma unroll
             for (int dx = 0; dx < DXN; ++dx) asm volatile("" : "+v"(aj[j][dx]));
+        if constexpr (Q == 2) {
+            // MX-scaled fp8 (v_mfma_scale_f32_32x32x64_f8f6f4, E8M0 scale 127 = 1.0 on both operands): the chunk's 64 channels in
+            // ONE MFMA per tap and tile pair.  Lane half hh owns the 32-byte cell hh of the chunk: both 16-byte halves of its pixel
+            // (the second sits at the swizzle partner, address ^ 16) and weight planes 2hh, 2hh+1 of its cout row; byte j of
+            // both operands is the same input channel, which is all the contraction needs.
+            const unsigned char* Ap = Ab + hh * PS;
+            i32x8 xa[2][PXW], wf[2][NBT];
+            auto load_tap = [&](int t, int sl) {
+                const unsigned char* Ar = Ap + (t / 3) * rowB;
+#pragma unroll
+                for (int i = 0; i < NBT; ++i) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(Bb + ((((i * T + t) * NC8 + 2 * hh) * 32) + l31) * 16);
+                    const i32x4 hi = *reinterpret_cast<const i32x4*>(Bb + ((((i * T + t) * NC8 + 2 * hh + 1) * 32) + l31) * 16);
+                    wf[sl][i] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(Ar + aj[j][t % 3]);
+                    const i32x4 hi = *reinterpret_cast<const i32x4*>(Ar + (aj[j][t % 3] ^ 16));
+                    xa[sl][j] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            };
+            load_tap(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NBT + PXW), 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int sl = t & 1;
+                if (t + 1 < T) load_tap(t + 1, sl ^ 1);
+#pragma unroll
+                for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[sl][i], xa[sl][j], acc[0][i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                                       0x7f7f7f7f);
+                if (t + 1 < T) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NBT + PXW), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NBT * PXW, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < NCB; ++q) {
             const int plane = 2 * q + hh;
@@ -689,6 +732,13 @@ static k3_kernel_t k3_pick_q8(int NBT, int PXW, int NC8) {     // fp8 operands: 
     return nullptr;
 }
 
+static k3_kernel_t k3_pick_mx(int NBT, int PXW) {     // MX-scaled fp8 operands: 3x3 stride 1, 64-channel chunks
+#define K3M(n, p) if (NBT == n && PXW == p) return (k3_kernel_t)conv3_kernel<1, n, p, 4, 9, 1, 2>
+    K3M(2, 2); K3M(1, 2); K3M(2, 1); K3M(1, 1);
+#undef K3M
+    return nullptr;
+}
+
 static k3_kernel_t k3_pick_s2(int NBT, int NC8) {     // 3x3 stride 2 pad 1 (face-encoder / U-Net downsamples): PXW = 2
     if (NC8 == 2) return NBT == 2 ? (k3_kernel_t)conv3_kernel<1, 2, 2, 2, 9, 2> : (k3_kernel_t)conv3_kernel<1, 1, 2, 2, 9, 2>;
     return nullptr;
@@ -867,7 +917,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         if (err) *err = "conv3: fused head needs the 3x3 stride-1 32-cout configuration";
         return -1;
     }
-    k3_kernel_t k = p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
+    k3_kernel_t k = p.mx ? k3_pick_mx(NBT, PXW) : p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }

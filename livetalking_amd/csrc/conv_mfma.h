@@ -78,6 +78,10 @@ struct ConvPlan {
     // above then counts 16-bit units (= CinReal / 2) so that every byte offset of the fp16 path carries over
     bool q8 = false;
     int CinReal = 0;
+    // q8 on the MX-scaled instruction (v_mfma_scale_f32_32x32x64_f8f6f4, unit E8M0 scales: 2x the MAC rate of every other fp8 /
+    // fp16 MFMA on gfx950): 64 e4m3 channels per chunk (NC8 = 4) = ONE MFMA per tap and tile pair; lane half hh contracts the
+    // 32-byte cell 2*chunk + hh.  Same tensors, weight bytes and scales as q8.
+    bool mx = false;
     ConvPhase phase[kMaxPhases];
     // device data
     f16* d_w = nullptr;
@@ -99,6 +103,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int Cin, int Cout, int kh
                      const float* scale, const float* shift, std::string* err, int hint_hw = 0,
                      int quant = 0, float act_scale = 1.f, int ups4 = 0);
 // `ups4` = 1: the conv always runs on a nearest-2x upsampled input (ConvIO::ups): build the four-phase form (ConvPlan::ups4).
+// `quant` = 2: the same on the MX-scaled fp8 MFMA (ConvPlan::mx; needs Cin % 64 == 0).
 // `quant` = 1: e4m3 weights with one scale per output channel (224 / max|w|), folded together with `act_scale`
 // (what the producer of the fp8 input multiplied by) into the epilogue scale.  3x3 stride-1 pad-1 convs, Cin % 32 == 0.
 

@@ -470,6 +470,10 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
             return -1;
         }
         p->q8 = true;
+        if (quant == 2) {
+            if (CinArg % 64 != 0) { if (err) *err = "MX fp8 operands: Cin % 64 == 0"; return -1; }
+            p->mx = true;
+        }
     }
     p->CinReal = CinArg;
     // fp8: two channels per 16-bit unit; everything below (chunking, pack order, launch geometry) sees CinArg / 2 "channels"
@@ -614,6 +618,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
             if (knob(K_CONV3_NC8) == 2 || (knob(K_CONV3_NC8) == 4 && Cin % 32 == 0)) NC8 = knob(K_CONV3_NC8);
         }
         if (p->v3_S == 2) NC8 = 2;
+        if (p->mx) NC8 = 4;                 // 4 planes of 16 e4m3 channels = the 64 channels one MX MFMA contracts
         NBT = 2;
     }
     p->NC8 = NC8; p->NBT = NBT;      // NBT here = the widest block the staging registers allow
