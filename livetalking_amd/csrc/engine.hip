@@ -1095,7 +1095,7 @@ int ltk_conv2d_fp8(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
     ConvPlan plan;
     std::string err;
     int rc = conv_plan_create(&plan, weight, Cin, Cout, 3, 3, 1, 1, 1, 1, false, 0, scale, shift, &err, H * W,
-                              (knob(K_FP8_MX) && Cin % 64 == 0) ? 2 : 1, act_scale);
+                              (Cin % 64 == 0 && (knob(K_FP8_MX) == 2 || (knob(K_FP8_MX) == 1 && Cin >= 512))) ? 2 : 1, act_scale);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, err);
     ConvIO io;
     io.partial = e->d_partial; io.partial_cap = e->partial_cap;

@@ -168,7 +168,7 @@ struct MtGraph {
         ConvPlan p;
         std::string e;
         int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, pad_br, sc.data(), sf.data(), &e, x.P(),
-                                  x.q8 ? ((knob(K_FP8_MX) && CinR % 64 == 0) ? 2 : 1) : 0, fp8_ascale, ups ? 1 : 0);
+                                  x.q8 ? ((CinR % 64 == 0 && (knob(K_FP8_MX) == 2 || (knob(K_FP8_MX) == 1 && CinR >= 512))) ? 2 : 1) : 0, fp8_ascale, ups ? 1 : 0);
         if (rc) { err = name + ": " + e; return -1; }
         plans.push_back(p);
         MtOp op;

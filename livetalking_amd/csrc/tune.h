@@ -32,7 +32,8 @@ enum Knob {
     K_CONV7,              // LTK_CONV7          1: dedicated first-layer kernel (7x7, 6 -> 16) with the input pack fused
     K_ATTN_WIDE,          // LTK_ATTN_WIDE      1: cooperative kernel for the 512-channel single-head attention of the VAE mid block
     K_UPS4,               // LTK_UPS4           1: nearest-2x upsample + 3x3 conv as four 2x2-tap phases (16 instead of 36 MACs per source pixel)
-    K_FP8_MX,             // LTK_FP8_MX         1: fp8 convs with Cin % 64 == 0 on the MX-scaled MFMA (32x32x64, 2x MAC rate)
+    K_FP8_MX,             // LTK_FP8_MX         fp8 convs on the MX-scaled MFMA (32x32x64, 2x MAC rate): 1 = where it wins (Cin >= 512:
+                          //                    its 64-channel chunks leave one block per CU, which only deep K loops repay), 2 = all, 0 = none
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
     K_COUNT
 };
