@@ -9,8 +9,10 @@ scheduler batches them instead (continuous batching):
 * while a call is in flight, new requests collect in a queue; when the call returns, everything queued (up to the
   engine's max_frames) goes down as ONE engine call with nreq > 1, which is how 16 sessions per GPU fill the chip
   (256 frames per launch sequence instead of 16);
-* LTK_COALESCE_MS > 0 additionally holds a batch open for that long after its first request (fixed window; useful when
-  sessions are paced by the same clock and arrive within a millisecond of each other).
+* while several sessions are active (a batch of more than one request formed within the last two seconds) a leader holds its
+  batch open for LTK_COALESCE_AUTO_US (default 500 us, 0.08 % of a 640-ms step) so that sessions woken by the same clock
+  tick ride one launch sequence instead of "one alone, then the rest"; a lone session never waits;
+* LTK_COALESCE_MS > 0 holds every batch open for that long after its first request (fixed window).
 
 A session's frames keep their order: a request is one contiguous (index .. index+batch) span, a session has at most
 one request in flight (its inference thread blocks in `infer()`), and every request's frames land in its own output
@@ -46,6 +48,8 @@ class BatchingScheduler:
         self._handoff = False
         self._closed = False
         self._worker = None
+        self._auto_window = max(0.0, float(os.environ.get("LTK_COALESCE_AUTO_US", "500"))) * 1e-6
+        self._last_multi = -1e9            # perf_counter() of the last batch that carried more than one request
         self.stats = {"calls": 0, "requests": 0, "frames": 0, "max_requests_per_call": 0}
 
     def _limit(self) -> int:
@@ -66,6 +70,8 @@ class BatchingScheduler:
             # idle engine: run the call in this thread (no hop); whatever queued up meanwhile goes to the worker
             if self.window > 0.0:
                 time.sleep(self.window)
+            elif self._auto_window > 0.0 and time.perf_counter() - self._last_multi < 2.0:
+                time.sleep(self._auto_window)          # other sessions are active: let the ones due now join this launch
             self._run_one_batch()
             with self._cv:
                 if self._pending:
@@ -104,6 +110,8 @@ class BatchingScheduler:
             self.stats["requests"] += len(group)
             self.stats["frames"] += frames
             self.stats["max_requests_per_call"] = max(self.stats["max_requests_per_call"], len(group))
+            if len(group) > 1:
+                self._last_multi = time.perf_counter()
         for q in group:
             q.err = err
             q.done.set()
