@@ -67,10 +67,11 @@ def main():
                 f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{r[8]} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
                 if "conv" in n:
                     conv_us += (r[2] - r[1]) / 1e3
+                nlaunch = nlaunch + 1 if "nlaunch" in dir() else 1
                 if "head_kernel" in n:
-                    f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us\n")
+                    f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us; {nlaunch} launches\n")
                     break
-            f.write(f"# launches in the pass: {sum(1 for r in rows[idx[-1]:] if True)} (to the end of the trace)\n")
+
     fetch = counters(os.path.join(a.src, "pmc_fetch", "r_results.db"))
     write = counters(os.path.join(a.src, "pmc_write", "r_results.db"))
     sq = counters(os.path.join(a.src, "pmc_sq", "r_results.db"))
