@@ -133,6 +133,7 @@ class SessionThreads:
         self.busy = [0.0] * self.S          # per session: seconds inside inference_batch (the reference's counttime)
         self.frames = [0] * self.S
         self._step = 0
+        self._nsteps = 1
         self._err = None
         if self.S > 1:
             self._go = threading.Barrier(self.S + 1)
@@ -159,16 +160,21 @@ class SessionThreads:
                 if self._due is not None:                      # paced: every session asks at its own due time
                     while time.perf_counter() < self._due:
                         time.sleep(0.0005)
-                self._one(i, self._step)
+                for st in range(self._nsteps):                 # free-running: no hand-shake with the other sessions between steps
+                    self._one(i, self._step + st)
             except Exception as ex:  # noqa: BLE001
                 self._err = ex
             self._done.wait()
 
-    def step(self, step, due=None):
+    def step(self, step, due=None, nsteps=1):
+        """`nsteps` consecutive inference_batch calls per session.  With several sessions every session's thread runs its
+        calls back to back on its own, as the reference's per-session inference threads do (base_avatar.py:326-381): the
+        threads meet only before the first and after the last call."""
         if self.S == 1:
-            self._one(0, step)
+            for st in range(nsteps):
+                self._one(0, step + st)
             return
-        self._step, self._due = step, due
+        self._step, self._due, self._nsteps = step, due, nsteps
         self._go.wait()
         self._done.wait()
         if self._err is not None:
@@ -245,8 +251,7 @@ def run_wav2lip(args, ranks: Ranks):
         drv.step(i)
     ranks.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        drv.step(args.warmup + i)
+    drv.step(args.warmup, nsteps=args.steps)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0                     # this rank's own time (reported per rank)
     ranks.barrier()
@@ -324,8 +329,7 @@ def run_musetalk(args, ranks: Ranks, shared=None):
         drv.step(i)
     ranks.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        drv.step(args.warmup + i)
+    drv.step(args.warmup, nsteps=args.steps)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0
     ranks.barrier()

@@ -10,7 +10,8 @@ scheduler batches them instead (continuous batching):
   engine's max_frames) goes down as ONE engine call with nreq > 1, which is how 16 sessions per GPU fill the chip
   (256 frames per launch sequence instead of 16);
 * while several sessions are active (a batch of more than one request formed within the last two seconds) a leader holds its
-  batch open for LTK_COALESCE_AUTO_US (default 500 us, 0.08 % of a 640-ms step) so that sessions woken by the same clock
+  batch open for LTK_COALESCE_AUTO_US (default 200 us, 0.03 % of a 640-ms step; 0 / 200 / 500 us measured with 16 free-running
+  session threads: 200 >= 0 > 500, profiles/r02_scheduler_window.txt) so that sessions woken by the same clock
   tick ride one launch sequence instead of "one alone, then the rest"; a lone session never waits;
 * LTK_COALESCE_MS > 0 holds every batch open for that long after its first request (fixed window).
 
@@ -48,7 +49,7 @@ class BatchingScheduler:
         self._handoff = False
         self._closed = False
         self._worker = None
-        self._auto_window = max(0.0, float(os.environ.get("LTK_COALESCE_AUTO_US", "500"))) * 1e-6
+        self._auto_window = max(0.0, float(os.environ.get("LTK_COALESCE_AUTO_US", "200"))) * 1e-6
         self._last_multi = -1e9            # perf_counter() of the last batch that carried more than one request
         self.stats = {"calls": 0, "requests": 0, "frames": 0, "max_requests_per_call": 0}
 
