@@ -219,7 +219,7 @@ def run_wav2lip(args, ranks: Ranks):
     torch.cuda.set_device(ranks.local_rank)
     os.environ["LTK_DEVICE"] = str(ranks.local_rank)
     import livetalking_amd.avatars.wav2lip_avatar as plugin
-    from livetalking_amd import synth  # seeded synthetic input generators (product-side; nothing from oracle/)
+    import synth_inputs as synth  # seeded synthetic input generators (repo root; nothing from oracle/)
 
     S, B = args.sessions, args.batch
     frames_per_step = S * B
@@ -305,7 +305,7 @@ def run_musetalk(args, ranks: Ranks, shared=None):
     os.environ["LTK_DEVICE"] = str(ranks.local_rank)
     os.environ["LTK_MT_FP8"] = "1" if args.fp8 else "0"
     import livetalking_amd.avatars.musetalk_avatar as plugin
-    from livetalking_amd import synth
+    import synth_inputs as synth
 
     S, B = args.sessions, args.batch
     fps_step = S * B
@@ -389,7 +389,7 @@ def paced_capacity(args):
     sustained when every period's last frame is ready before the next period starts.  Engine level (hundreds of Python
     session threads would measure the GIL, and those threads are the reference's own unchanged code)."""
     import torch
-    from livetalking_amd import synth
+    import synth_inputs as synth
     from livetalking_amd.engine import Engine
     B = args.batch
     os.environ.setdefault("LTK_MICROBATCH", "256")
@@ -450,7 +450,7 @@ def cpu_baseline(batch: int):
     torch CPU, all cores, seeded synthetic weights / bank / audio; median of 5 after one warm-up, B=batch and B=1."""
     import numpy as np
     import torch
-    from livetalking_amd import synth
+    import synth_inputs as synth
     from oracle import mel_oracle, plugin_oracle   # the checker, timed here as the CPU baseline only
     torch.set_num_threads(min(64, os.cpu_count() or 1))   # more threads only add contention on this model size
     sd_np = synth.wav2lip_state_dict(1234)
@@ -545,7 +545,7 @@ def measure_traffic(args):
 
 def sub_convpasses(args):
     """Body profiled by measure_traffic: K passes of the conv stack, nothing else."""
-    from livetalking_amd import synth
+    import synth_inputs as synth
     from livetalking_amd.engine import Engine
     nf = min(args.sessions * args.batch, 256)
     eng = Engine(0)
@@ -663,7 +663,7 @@ def main():
 def cpu_baseline_musetalk(budget_s: float = 25.0):
     """The oracle restatement of MuseReal.inference_batch (fp32, torch CPU) on the host cores, bounded sample."""
     import torch
-    from livetalking_amd import synth
+    import synth_inputs as synth
     from oracle import musetalk_oracle as M          # the checker, timed here as the CPU baseline only
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     usd = {k: torch.from_numpy(v) for k, v in synth.musetalk_unet_state_dict().items()}

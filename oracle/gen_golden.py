@@ -42,7 +42,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 sys.path.insert(0, REPO)
 
-from oracle import mel_oracle, paste_oracle, plugin_oracle, synth, wav2lip_oracle  # noqa: E402
+from oracle import mel_oracle, paste_oracle, plugin_oracle, wav2lip_oracle  # noqa: E402
+import synth_inputs as synth
 
 
 from oracle.ref_loop import install_stubs  # noqa: E402  (stub modules for the reference's third-party imports)

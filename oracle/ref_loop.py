@@ -263,7 +263,7 @@ def main():
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)        # enter_reference() moves to a scratch CWD
 
-    from oracle import synth
+    import synth_inputs as synth
     sd_np = synth.wav2lip_state_dict(1234) if args.net == "wav2lip" else None
     fr, fa, co = synth.wav2lip_avatar(n_frames=args.frames, full_hw=(360, 640), box=160, seed=0)
     avatar = ([np.ascontiguousarray(f) for f in fr], [np.ascontiguousarray(f) for f in fa], co)   # as cv2.imread returns them

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from livetalking_amd import synth  # noqa: E402
+import synth_inputs as synth  # noqa: E402
 from livetalking_amd.engine import Engine  # noqa: E402
 
 

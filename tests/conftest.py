@@ -21,7 +21,7 @@ def engine():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from livetalking_amd.engine import Engine
-    from oracle import synth
+    import synth_inputs as synth
     eng = Engine(0)
     eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=16)
     yield eng

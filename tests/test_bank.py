@@ -6,7 +6,8 @@ import pickle
 import numpy as np
 import pytest
 
-from livetalking_amd import bank, synth
+import synth_inputs as synth
+from livetalking_amd import bank
 
 
 def test_wav2lip_bank_roundtrip(tmp_path):

@@ -10,7 +10,8 @@ import pytest
 torch = pytest.importorskip("torch")
 
 from oracle import egress_oracle as eo  # noqa: E402
-from oracle import paste_oracle, synth  # noqa: E402
+from oracle import paste_oracle  # noqa: E402
+import synth_inputs as synth
 
 
 def _wm(seed=0):

@@ -15,7 +15,7 @@ import pytest
 torch = pytest.importorskip("torch")
 import torch.nn.functional as F  # noqa: E402
 
-from livetalking_amd import synth  # noqa: E402
+import synth_inputs as synth  # noqa: E402
 from livetalking_amd.layout import empty_cb16, from_cb16, to_cb16, to_cb32_fp8  # noqa: E402
 from oracle import musetalk_oracle as M  # noqa: E402
 

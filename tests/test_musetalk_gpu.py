@@ -13,7 +13,7 @@ import pytest
 
 torch = pytest.importorskip("torch")
 
-from livetalking_amd import synth  # noqa: E402
+import synth_inputs as synth  # noqa: E402
 from oracle import musetalk_oracle as M  # noqa: E402
 
 B = 2

@@ -10,7 +10,7 @@ import pytest
 torch = pytest.importorskip("torch")
 pytest.importorskip("transformers")
 
-from livetalking_amd import synth  # noqa: E402
+import synth_inputs as synth  # noqa: E402
 from oracle import musetalk_oracle as M  # noqa: E402
 from oracle import paste_oracle, whisper_oracle as WO  # noqa: E402
 

@@ -11,7 +11,8 @@ import pytest
 
 torch = pytest.importorskip("torch")
 
-from oracle import mel_oracle, paste_oracle, plugin_oracle, synth  # noqa: E402
+from oracle import mel_oracle, paste_oracle, plugin_oracle  # noqa: E402
+import synth_inputs as synth
 
 
 @pytest.mark.gpu

@@ -63,7 +63,7 @@ def test_engine_pool_places_sessions_across_engines():
     from fake_engine import FakeEngine
     import livetalking_amd.avatars.wav2lip_avatar as plugin
     from livetalking_amd.sharding import EnginePool
-    from oracle import synth
+    import synth_inputs as synth
 
     pool = EnginePool([0, 1, 1], lambda d: FakeEngine(net="tiny", device=d), capacity_per_gpu=2)
     model = plugin.Wav2LipModel(pool)

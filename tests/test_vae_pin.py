@@ -6,7 +6,7 @@ ResnetBlock), per level num_res_blocks(+1) ResnetBlocks (GroupNorm 32 eps 1e-6, 
 change), nearest-2x + 3x3 conv upsample / (0,1,0,1)-pad stride-2 downsample, norm_out, swish, conv_out.
 
 The same seeded weights are loaded into both: into the oracle under diffusers' AutoencoderKL key names (what a real
-sd-vae-ft-mse checkpoint uses, livetalking_amd.synth), into the Janus modules under their own names through the explicit
+sd-vae-ft-mse checkpoint uses, synth_inputs.py), into the Janus modules under their own names through the explicit
 name map below.  Equal outputs pin the oracle's WIRING (block order, channel plan, resnet / attention / resample
 composition, eps, activation) to code nobody here wrote.  What this cannot pin: diffusers' key names and config values
 themselves (sd-vae-ft-mse config: block_out_channels (128,256,512,512), layers_per_block 2, latent 4, no attention outside
@@ -19,7 +19,8 @@ import pytest
 torch = pytest.importorskip("torch")
 janus = pytest.importorskip("transformers.models.janus.modeling_janus")
 
-from oracle import musetalk_oracle as M, synth  # noqa: E402
+from oracle import musetalk_oracle as M  # noqa: E402
+import synth_inputs as synth
 
 
 def _cfg():

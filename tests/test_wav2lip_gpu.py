@@ -15,7 +15,8 @@ import pytest
 
 torch = pytest.importorskip("torch")
 
-from oracle import mel_oracle, plugin_oracle, synth, wav2lip_oracle  # noqa: E402
+from oracle import mel_oracle, plugin_oracle, wav2lip_oracle  # noqa: E402
+import synth_inputs as synth
 
 
 def _golden_inputs(golden_dir):

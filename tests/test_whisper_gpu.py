@@ -9,7 +9,7 @@ import pytest
 torch = pytest.importorskip("torch")
 pytest.importorskip("transformers")
 
-from livetalking_amd import synth  # noqa: E402
+import synth_inputs as synth  # noqa: E402
 from oracle import whisper_oracle as WO  # noqa: E402
 
 
