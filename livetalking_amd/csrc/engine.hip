@@ -399,9 +399,22 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
 
 void bump(size_t* cur, size_t v) { if (v > *cur) *cur = v; }
 
+// Everything ltk_wav2lip_load creates (layer plans, head weights, first-layer plan, activation arena): a failed load leaves
+// the engine as it found it, and can be retried.
+void wav2lip_unload(ltk_engine* e) {
+    for (Layer& L : e->layers) conv_plan_destroy(&L.plan);
+    e->layers.clear();
+    for (int i = 0; i < B_COUNT; ++i)
+        if (e->buf[i]) { (void)hipFree(e->buf[i]); e->buf[i] = nullptr; }
+    if (e->d_head) { (void)hipFree(e->d_head); e->d_head = nullptr; }
+    conv7_plan_destroy(e->c7);
+    e->c7 = nullptr;
+    e->loaded = false;
+}
+
 // Wire the layer program: buffers, channel offsets (torch.cat), spatial dims.
 int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
-    e->layers.clear();
+    wav2lip_unload(e);
     size_t* bh = e->buf_halfs;
     for (int i = 0; i < B_COUNT; ++i) bh[i] = 0;
     bh[B_MEL] = 80 * 16 * 8;
@@ -670,10 +683,7 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
-    for (Layer& L : e->layers) conv_plan_destroy(&L.plan);
-    for (int i = 0; i < B_COUNT; ++i) if (e->buf[i]) (void)hipFree(e->buf[i]);
-    if (e->d_head) (void)hipFree(e->d_head);
-    conv7_plan_destroy(e->c7);
+    wav2lip_unload(e);
     if (e->d_basis) (void)hipFree(e->d_basis);
     if (e->d_lohi) (void)hipFree(e->d_lohi);
     e->avatars.clear();
@@ -712,18 +722,22 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
     std::lock_guard<std::mutex> g(e->mu);
     if (e->loaded) return fail(LTK_E_STATE, "a model is already loaded in this engine");
     CHK(hipSetDevice(e->device));
-    int rc = build_program(e, sd, n);
-    if (rc) return rc;
-    e->micro_batch = knob(K_MICROBATCH);
-    if (e->micro_batch <= 0 || e->micro_batch > max_frames) e->micro_batch = max_frames;
-    e->max_frames = max_frames;
-    const int arena_frames = e->micro_batch;
-    for (int i = 0; i < B_COUNT; ++i) {
-        if (!e->buf_halfs[i]) continue;
-        const size_t bytes = e->buf_halfs[i] * arena_frames * sizeof(f16) + 4096;
-        if (hipMalloc((void**)&e->buf[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "activation arena allocation failed");
-        CHK(hipMemset(e->buf[i], 0, bytes));
-    }
+    const int rc = [&]() -> int {
+        const int brc = build_program(e, sd, n);
+        if (brc) return brc;
+        e->micro_batch = knob(K_MICROBATCH);
+        if (e->micro_batch <= 0 || e->micro_batch > max_frames) e->micro_batch = max_frames;
+        e->max_frames = max_frames;
+        const int arena_frames = e->micro_batch;
+        for (int i = 0; i < B_COUNT; ++i) {
+            if (!e->buf_halfs[i]) continue;
+            const size_t bytes = e->buf_halfs[i] * arena_frames * sizeof(f16) + 4096;
+            if (hipMalloc((void**)&e->buf[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "activation arena allocation failed");
+            CHK(hipMemset(e->buf[i], 0, bytes));
+        }
+        return LTK_OK;
+    }();
+    if (rc) { wav2lip_unload(e); return rc; }       // nothing half-built stays behind (the error text is already set)
     e->loaded = true;
     return LTK_OK;
 }
@@ -898,30 +912,41 @@ int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, vo
 }
 
 // ------------------------------------------------------------------ test / measurement hooks
+namespace {
+struct DevBuf {                     // device scratch of a host-side hook: freed on every return path
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+// B frames from host tensors (warm_up, tests).  Runs as passes of at most one arena (micro-batch) each, so a start-up
+// warm_up(batch_size) also works when LTK_MICROBATCH is smaller than the session batch.
 int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6, int B, float* pred) {
     if (!e || !mel || !face6 || !pred || B <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
-    if (B > e->micro_batch || B > kPackMaxFrames) return fail(LTK_E_INVALID, "B exceeds the arena (micro-batch) size");
+    if (B > e->max_frames) return fail(LTK_E_INVALID, "B exceeds max_frames");
     CHK(hipSetDevice(e->device));
-    const size_t melb = (size_t)B * 80 * 16 * sizeof(float), faceb = (size_t)B * 6 * 65536 * sizeof(float);
-    const size_t predb = (size_t)B * 3 * 65536 * sizeof(float);
-    float *d_mel = nullptr, *d_face = nullptr, *d_pred = nullptr;
-    CHK(hipMalloc((void**)&d_mel, melb));
-    CHK(hipMalloc((void**)&d_face, faceb));
-    CHK(hipMalloc((void**)&d_pred, predb));
-    CHK(hipMemcpy(d_mel, mel, melb, hipMemcpyHostToDevice));
-    CHK(hipMemcpy(d_face, face6, faceb, hipMemcpyHostToDevice));
-    MelPtrs mp;
-    for (int i = 0; i < B; ++i) mp.p[i] = d_mel + (size_t)i * 1280;
-    int rc;
-    {
-        std::lock_guard<std::mutex> g(e->mu);
-        rc = infer_locked(e, nullptr, &mp, d_face, B, nullptr, d_pred);
-        if (!rc && hipStreamSynchronize(e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "stream sync failed");
+    const int mb = std::min(e->micro_batch, kPackMaxFrames);
+    const int cap = std::min(B, mb);
+    DevBuf d_mel, d_face, d_pred;
+    CHK(hipMalloc(&d_mel.p, (size_t)cap * 80 * 16 * sizeof(float)));
+    CHK(hipMalloc(&d_face.p, (size_t)cap * 6 * 65536 * sizeof(float)));
+    CHK(hipMalloc(&d_pred.p, (size_t)cap * 3 * 65536 * sizeof(float)));
+    for (int f0 = 0; f0 < B; f0 += mb) {
+        const int nf = std::min(mb, B - f0);
+        CHK(hipMemcpy(d_mel.p, mel + (size_t)f0 * 1280, (size_t)nf * 1280 * sizeof(float), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d_face.p, face6 + (size_t)f0 * 6 * 65536, (size_t)nf * 6 * 65536 * sizeof(float), hipMemcpyHostToDevice));
+        MelPtrs mp;
+        for (int i = 0; i < nf; ++i) mp.p[i] = (float*)d_mel.p + (size_t)i * 1280;
+        {
+            std::lock_guard<std::mutex> g(e->mu);
+            const int rc = infer_locked(e, nullptr, &mp, (const float*)d_face.p, nf, nullptr, (float*)d_pred.p);
+            if (rc) return rc;
+            CHK(hipStreamSynchronize(e->compute));
+        }
+        CHK(hipMemcpy(pred + (size_t)f0 * 3 * 65536, d_pred.p, (size_t)nf * 3 * 65536 * sizeof(float), hipMemcpyDeviceToHost));
     }
-    if (!rc) CHK(hipMemcpy(pred, d_pred, predb, hipMemcpyDeviceToHost));
-    (void)hipFree(d_mel); (void)hipFree(d_face); (void)hipFree(d_pred);
-    return rc;
+    return LTK_OK;
 }
 
 int ltk_debug_capture(ltk_engine* e, int enable) {
@@ -1166,10 +1191,20 @@ int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet
             pe[pos * 384 + i] = sinf((float)pos * div);
             pe[pos * 384 + i + 1] = cosf((float)pos * div);
         }
-    CHK(hipMalloc((void**)&e->d_pe, pe.size() * sizeof(float)));
-    CHK(hipMemcpy(e->d_pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
-    CHK(hipMalloc((void**)&e->d_mt_feat, (size_t)max_frames * 50 * 384 * sizeof(float)));
-    CHK(hipMalloc((void**)&e->d_mt_lat, (size_t)max_frames * 8 * 1024 * sizeof(float)));
+    const int arc = [&]() -> int {
+        CHK(hipMalloc((void**)&e->d_pe, pe.size() * sizeof(float)));
+        CHK(hipMemcpy(e->d_pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+        CHK(hipMalloc((void**)&e->d_mt_feat, (size_t)max_frames * 50 * 384 * sizeof(float)));
+        CHK(hipMalloc((void**)&e->d_mt_lat, (size_t)max_frames * 8 * 1024 * sizeof(float)));
+        return LTK_OK;
+    }();
+    if (arc) {                                       // a failed load leaves nothing behind and can be retried
+        if (e->d_pe) { (void)hipFree(e->d_pe); e->d_pe = nullptr; }
+        if (e->d_mt_feat) { (void)hipFree(e->d_mt_feat); e->d_mt_feat = nullptr; }
+        if (e->d_mt_lat) { (void)hipFree(e->d_mt_lat); e->d_mt_lat = nullptr; }
+        mt_graph_delete(mg);
+        return arc;
+    }
     e->mt = mg;
     e->mt_max_frames = max_frames;
     return LTK_OK;

@@ -144,3 +144,33 @@ def test_fused_head_vs_separate_head(engine, golden_dir):
     ref = g["ref_pred_u8"]
     assert psnr_u8(out[1], ref) >= psnr_u8(out[0], ref) - 0.2      # and it is not further from the reference's frames
     engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
+def test_forward_host_runs_as_arena_passes(golden_dir):
+    """warm_up(batch_size) with an arena (LTK_MICROBATCH) smaller than the session batch: ltk_wav2lip_forward_host runs as
+    several passes and returns what one pass returns (frames are independent; split-K off so the summation order is too)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, feats)
+    mel, img = mel_t.numpy().reshape(B, 80, 16), img_t.numpy()
+    weights = synth.wav2lip_state_dict(int(g["weight_seed"]))
+    outs = []
+    Engine.set_knob("SPLITK", 0)
+    try:
+        for mb in (0, 3):
+            Engine.set_knob("MICROBATCH", mb)
+            eng = Engine(0)
+            try:
+                eng.load_wav2lip(weights, max_frames=B)
+                outs.append(eng.wav2lip_forward_host(mel, img))
+            finally:
+                eng.close()
+    finally:
+        Engine.set_knob("MICROBATCH", 0)
+        Engine.set_knob("SPLITK", 1)
+    assert outs[0].shape == outs[1].shape == (B, 3, 256, 256)
+    np.testing.assert_array_equal(outs[0], outs[1])
