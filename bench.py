@@ -262,6 +262,28 @@ def run_wav2lip(args, ranks: Ranks):
 
     paced = paced_sessions(drv, args.warmup + args.steps, args.paced, B) if args.paced > 0 else None
     sched = dict(sessions[0]._sched.stats)
+    # PCIe-inclusive rate of one session (outside the timed region): mel windows start on the HOST (the reference's ASR hands
+    # numpy arrays over, mel.py:34-67) and every frame comes back composited into its full frame as a host array, as
+    # LipReal.paste_back_frame returns it (wav2lip_avatar.py:141-147): 82 KB up and B x H x W x 3 bytes down per step.
+    pcie = None
+    if ranks.rank == 0 and S == 1:
+        import numpy as np
+        s0 = sessions[0]
+        host_mel = [np.ascontiguousarray(m) for m in d_mel[0].cpu().numpy()]
+        nloop = 10
+        for it in range(nloop + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+            pred = s0.inference_batch(it * B, host_mel)
+            for i in range(B):
+                s0.paste_back_frame(pred[i], (it * B + i) % 32)
+        dtp = time.perf_counter() - tp
+        h, w = avatar[0][0].shape[:2]
+        pcie = {"value": round(nloop * B / dtp, 1), "unit": "frames/s", "ms_per_step": round(dtp / nloop * 1e3, 3),
+                "bytes_down_per_frame": int(h * w * 3),
+                "note": "one session thread: host mel in, inference_batch, then paste_back_frame for each of the B frames "
+                        "(composited 720p BGR frame copied to the host per call); not `value`"}
     drv.close()
     # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass, the head fused into the last):
     # HIP events on the engine's own streams around the conv stack only (no gather/pack), averaged over 10 passes of the
@@ -287,6 +309,8 @@ def run_wav2lip(args, ranks: Ranks):
         }
         if paced is not None:
             out["paced"] = paced
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
     for eng_ in model.engines:
         eng_.close()
     return out
