@@ -90,3 +90,50 @@ def test_engine_pool_places_sessions_across_engines():
     del sess[0]
     gc.collect()
     assert pool.load()[0] == 1 and keep._slot == 2         # removed sessions free their slot (weakref.finalize)
+
+
+def test_bench_session_threads_run_free_between_steps():
+    """bench.py's SessionThreads: with several sessions every thread issues its `nsteps` calls back to back (no hand-shake
+    between steps - the reference's per-session inference threads, base_avatar.py:326-381); indices advance per step and
+    per session; an exception in one session surfaces in the caller."""
+    import threading
+    import time
+    import bench
+
+    class Sess:
+        batch_size = 4
+
+        def __init__(self, delay):
+            self.calls, self.delay = [], delay
+
+        def inference_batch(self, index, feats):
+            self.calls.append((index, time.perf_counter()))
+            time.sleep(self.delay)
+            return [None] * self.batch_size
+
+    slow, fast = Sess(0.02), Sess(0.001)
+    drv = bench.SessionThreads([slow, fast], [None, None], stride=7)
+    try:
+        drv.step(0)                                   # one lock-step call each (warm-up style)
+        t0 = time.perf_counter()
+        drv.step(1, nsteps=5)
+        dt = time.perf_counter() - t0
+    finally:
+        drv.close()
+    assert [c[0] for c in slow.calls] == [0 * 4 + 0, 4, 8, 12, 16, 20]
+    assert [c[0] for c in fast.calls] == [7, 11, 15, 19, 23, 27]
+    # the fast session finished its five calls while the slow one was still in its first or second: no per-step barrier
+    assert fast.calls[-1][1] < slow.calls[3][1]
+    assert dt < 5 * 0.02 + 0.08
+    assert drv.frames == [24, 24]
+
+    class Bad(Sess):
+        def inference_batch(self, index, feats):
+            raise RuntimeError("boom")
+
+    drv = bench.SessionThreads([Sess(0.0), Bad(0.0)], [None, None], stride=1)
+    try:
+        with pytest.raises(RuntimeError):
+            drv.step(0, nsteps=2)
+    finally:
+        drv.close()
