@@ -174,3 +174,48 @@ def test_forward_host_runs_as_arena_passes(golden_dir):
         Engine.set_knob("SPLITK", 1)
     assert outs[0].shape == outs[1].shape == (B, 3, 256, 256)
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_full_size_batching_properties(golden_dir):
+    """BASELINE.json configs[3]'s per-GPU share at full size - 16 sessions x 16 frames in ONE call (256 frames), and a
+    512-frame call that runs as two arena passes - checked through size-independent properties: a session's frames do
+    not depend on what it was batched with (bit-exact with LTK_SPLITK=0, <= 2 LSB with the default per-launch split-K), two
+    sessions asking for the same bank frames with the same audio get the same bytes, and the ping-pong index wraps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    n_bank = len(faces)
+    B, S = 16, 32
+    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    Engine.set_knob("MICROBATCH", 256)
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(int(g["weight_seed"])), max_frames=S * B)
+        aid = eng.register_avatar(faces, frames, coords)
+        index = [(5 * s) % (2 * n_bank) for s in range(S)]
+        index[7] = index[3]                                   # same bank frames, same audio -> same bytes
+        index[9] = index[3] + 2 * n_bank                      # one full ping-pong period later (mirror_index, utils/image.py:26-32)
+        single = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+        for mode in (1, 0):                                   # default split-K, then LTK_SPLITK=0
+            Engine.set_knob("SPLITK", mode)
+            for s in range(S):
+                eng.wav2lip_infer([(aid, index[s], B, mel.data_ptr(), single[s].data_ptr())])
+            assert torch.equal(single[7], single[3]) and torch.equal(single[9], single[3])
+            both = torch.zeros_like(single)
+            eng.wav2lip_infer([(aid, index[s], B, mel.data_ptr(), both[s].data_ptr()) for s in range(16)])        # 256 frames
+            whole = torch.zeros_like(single)
+            eng.wav2lip_infer([(aid, index[s], B, mel.data_ptr(), whole[s].data_ptr()) for s in range(S)])        # 512 = 2 passes
+            for name, got, n in (("256-frame call", both, 16), ("512-frame call", whole, S)):
+                d = (got[:n].to(torch.int16) - single[:n].to(torch.int16)).abs()
+                print(f"[full size] {name}, SPLITK={mode}: max diff {int(d.max())} LSB, differing bytes {float((d != 0).float().mean()):.2e}")
+                if mode == 0:
+                    assert int(d.max()) == 0
+                else:
+                    assert int(d.max()) <= 2
+            assert torch.equal(whole[:16], both[:16]) or mode == 1
+    finally:
+        Engine.set_knob("SPLITK", 1)
+        Engine.set_knob("MICROBATCH", 0)
+        eng.close()
