@@ -168,3 +168,44 @@ def test_vae_encoder_avatar_prep():
     print(f"[mt] vae encoder: mean rel_l2={r1:.3e}, sample rel_l2={r2:.3e}, |latent| max {np.abs(ref_mean).max():.3g}")
     assert got_mean.shape == (2, 8, 32, 32) and r1 <= 1e-2 and r2 <= 1e-2
     eng.close()
+
+
+@pytest.mark.gpu
+def test_full_size_batching_properties():
+    """BASELINE.json configs[4]'s per-GPU share at full size: 4 sessions x 16 frames in ONE call (64 frames) against the same
+    sessions one by one.  A session's frames do not depend on what it was batched with, up to the summation order of the
+    per-launch split-K slabs and GroupNorm segments (both follow the frame count): <= 2 LSB, PSNR >= 50 dB; two sessions with the
+    same latents and audio get the same bytes inside one call; a repeated call is bit-identical."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    S, Bf, n = 4, 16, 5
+    eng = Engine(0)
+    try:
+        eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=S * Bf)
+        lats = synth.musetalk_latents(n)
+        frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(360, 640), box=160, seed=2)
+        boxes = [(240, 100, 400, 280)] * n
+        crops = [(210, 60, 430, 315)] * n
+        masks = [np.full((255, 220, 3), 255, np.uint8)] * n
+        aid = eng.register_musetalk_avatar(lats, frames, boxes, masks, crops)
+        feats = [torch.from_numpy(synth.musetalk_whisper_feats(Bf, seed=30 + s)).cuda() for s in range(S)]
+        feats[3] = feats[1]
+        index = [0, 3, 7, 3]                                  # sessions 1 and 3: same latents, same audio
+        single = torch.zeros(S, Bf, 256, 256, 3, dtype=torch.uint8, device="cuda")
+        for s in range(S):
+            eng.musetalk_infer([(aid, index[s], Bf, feats[s].data_ptr(), single[s].data_ptr())])
+        assert torch.equal(single[1], single[3])
+        both = torch.zeros_like(single)
+        eng.musetalk_infer([(aid, index[s], Bf, feats[s].data_ptr(), both[s].data_ptr()) for s in range(S)])
+        again = torch.zeros_like(single)
+        eng.musetalk_infer([(aid, index[s], Bf, feats[s].data_ptr(), again[s].data_ptr()) for s in range(S)])
+        assert torch.equal(both, again), "a repeated call must be bit-identical"
+        assert torch.equal(both[1], both[3])
+        d = (both.to(torch.int16) - single.to(torch.int16)).abs()
+        mse = float((d.float() ** 2).mean())
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        print(f"[mt full size] 64-frame call vs 16-frame calls: max diff {int(d.max())} LSB, differing bytes {float((d != 0).float().mean()):.2e}, PSNR {psnr:.1f} dB")
+        assert int(d.max()) <= 2 and psnr >= 50.0
+    finally:
+        eng.close()
