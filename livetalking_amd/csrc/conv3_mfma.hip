@@ -763,8 +763,8 @@ constexpr int kMaxKSplit = 32;
 // differ by fp32 summation order only.  `cap` > 0 (3x3 / transposed / strided layers): split only below 128 items,
 // towards 256 items, at most `cap` ways -- measured (profiles/r02_conv_sweep.txt): a second split of a 192-item
 // transposed conv costs 55.7 us against 41.9 unsplit (the fp32 slabs + finish launch outweigh the fill), while 16..64
-// item launches on 4^2 / 8^2 maps are 15-25 % faster at 4 (conv) / 4-8 (transposed) splits.  cap == 0 (1x1 layers on
-// 1x1 maps, K up to 8192): fill the chip.
+// item launches on 4^2 / 8^2 maps are 15-25 % faster at 4 (conv) / 4-8 (transposed) splits.  cap == 0 (1x1 / linear layers,
+// K up to 8192): fill the chip.
 static int k3_ksplit(long long base, int nchunks, int cap) {
     if (nchunks < 4) return 1;
     int s;
@@ -772,7 +772,10 @@ static int k3_ksplit(long long base, int nchunks, int cap) {
         if (base >= 128) return 1;
         s = std::min(cap, (int)((256 + base - 1) / base));
     } else {
-        if (base >= 200) return 1;
+        // 1x1 / linear layers.  Between 128 and 200 items only a deep channel loop repays the fp32 slabs + finish launch:
+        // MuseTalk's 160-item projections with K = 384..640 (12-20 chunks) are 6-10 us faster unsplit, its K = 1920..5120
+        // layers (ff.net.2, the concatenated-input shortcuts) 12-33 us slower (profiles/r02_mt_linear_split_ab.txt)
+        if (base >= 200 || (base >= 128 && nchunks < 48)) return 1;
         s = (int)((256 + base - 1) / base);
     }
     s = std::min(s, std::min(nchunks / 2, kMaxKSplit));
