@@ -769,8 +769,15 @@ static int k3_ksplit(long long base, int nchunks, int cap) {
     if (nchunks < 4) return 1;
     int s;
     if (cap > 0) {
-        if (base >= 128) return 1;
-        s = std::min(cap, (int)((256 + base - 1) / base));
+        if (base >= 128) {
+            // ... except a very deep channel loop on a small map: the 3x3 convs on the 960..2560-channel concatenated inputs of
+            // MuseTalk's U-Net up blocks (60-160 chunks, 320-640 items of 128 px x 32 ch) are 10-20 % faster four ways
+            // (profiles/r02_mt_linear_split_ab.txt); plain convs only (a split 192-item transposed conv loses, see above)
+            if (!(cap == 4 && nchunks >= 60 && base <= 1024)) return 1;
+            s = 4;
+        } else {
+            s = std::min(cap, (int)((256 + base - 1) / base));
+        }
     } else {
         // 1x1 / linear layers.  Between 128 and 200 items only a deep channel loop repays the fp32 slabs + finish launch:
         // MuseTalk's 160-item projections with K = 384..640 (12-20 chunks) are 6-10 us faster unsplit, its K = 1920..5120
