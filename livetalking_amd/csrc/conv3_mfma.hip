@@ -881,7 +881,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
             if ((pxw == 4 && NC8 != 2) || (nbt == 2 && p.lCout < 64) || (pxw == 4 && nbt == 1 && p.lCout >= 64)) continue;
             if (!geom(pxw)) continue;
             fit = true; PXW = pxw; NBT = nbt;
-            if (blocks * ((p.lCout + 32 * nbt - 1) / (32 * nbt)) >= 384) break;
+            // (640 input channels and more: ~1 item per CU is enough - a 40-chunk item hides its own start-up, and the larger tile
+            // re-reads less: MuseTalk's 640-channel 16^2 convs 67 -> 48 us as 320 items of 128 px x 64 ch instead of 640 of 128 x 32)
+            if (blocks * ((p.lCout + 32 * nbt - 1) / (32 * nbt)) >= (a.nchunks >= 40 ? 256 : 384)) break;
         }
     } else {
         fit = geom(PXW);
