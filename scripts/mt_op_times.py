@@ -20,9 +20,9 @@ TYPES = ["conv/linear", "GroupNorm", "LayerNorm", "attention", "GEGLU", "add-pos
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     ab = None
-    if len(sys.argv) > 2:
-        k, vs = sys.argv[2].split("=")
-        ab = (k, [int(v) for v in vs.split(",")])
+    if len(sys.argv) > 2:          # KNOB=a,b or KNOB1=a,b+KNOB2=c,d (setting i = the i-th value of every knob)
+        ks = [kv.split("=") for kv in sys.argv[2].split("+")]
+        ab = ("+".join(k for k, _ in ks), list(zip(*[[int(v) for v in vs.split(",")] for _, vs in ks])), [k for k, _ in ks])
     t0 = time.time()
     eng = Engine(0)
     eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=frames, fp8=bool(int(os.environ.get("FP8", "0"))))
@@ -33,7 +33,8 @@ def main():
     for rnd in range(3):
         for si, v in enumerate(settings):
             if ab is not None:
-                Engine.set_knob(ab[0], v)
+                for kn, kv in zip(ab[2], v):
+                    Engine.set_knob(kn, kv)
             eng.musetalk_time_ops(frames, 1)
             t = eng.musetalk_time_ops(frames, 3) * 1e3
             if rnd == 0:
