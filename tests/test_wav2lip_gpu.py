@@ -188,7 +188,8 @@ def test_full_size_batching_properties(golden_dir):
     g, frames, faces, coords, feats = _golden_inputs(golden_dir)
     n_bank = len(faces)
     B, S = 16, 32
-    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    mel = torch.from_numpy(np.stack([feats[i % len(feats)] for i in range(B)]).astype(np.float32)).cuda()      # B windows (the golden step has 4)
+    assert mel.shape == (B, 80, 16)
     Engine.set_knob("MICROBATCH", 256)
     eng = Engine(0)
     try:
