@@ -5,7 +5,9 @@
 A "step" is one `inference_batch` call per session (avatars/base_avatar.py:366) - bank gather + mask + pack, the conv
 stack, head, uint8 frames - issued through the PLUGIN surface (`LipReal.inference_batch` / `MuseReal.inference_batch`:
 torch.empty of the outputs, scheduler, ctypes marshalling included), with the avatar bank, the weights and the audio
-features already resident in HBM.  inferfps = frames / wall time of those calls (base_avatar.py:364-373).
+features already resident in HBM.  inferfps = frames / wall time of those calls (base_avatar.py:364-373).  With several
+sessions every session has its own thread and issues its K calls back to back, like the reference's per-session inference
+threads; the threads meet only before the first and after the last call.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--sessions S] [--batch B] [--model wav2lip|musetalk] [--fp8]
 
@@ -17,6 +19,7 @@ adds, OUTSIDE the timed region (each in its own subprocess, so `ms_per_step x st
   cpu_baseline  the reference's LipReal.inference_batch on the host cores (kind "reference" when a LiveTalking checkout
                 is importable, else the oracle port), B=16 and B=1 (configs[0]), median of 5
   roofline.traffic  HBM bytes per pass from two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) of the conv stack
+  pcie_inclusive    the same single session with host mel in and every composited frame copied back (paste_back_frame)
 
 N>1: sessions are independent (app.py:62-63,99), so rank r owns its own engine, bank replica and sessions: no collective
 on the data path, xGMI unused.  Launched either by the driver (`python -m torch.distributed.run ... bench.py --gpus N`:
