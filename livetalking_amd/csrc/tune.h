@@ -24,7 +24,6 @@ enum Knob {
     K_NO_AUX_STREAM,      // LTK_NO_AUX_STREAM  1: audio encoder on the compute stream
     K_MICROBATCH,         // LTK_MICROBATCH     wav2lip frames per arena pass (0 = min(max_frames, 256))
     K_MT_NO_QKV_FUSE,     // LTK_MT_NO_QKV_FUSE 1: separate q / k / v projection launches
-    K_SPLITK_FUSED,       // LTK_SPLITK_FUSED   1: the last-arriving block of a split-K group reduces the slabs (no finish launch)
     K_HEAD_FUSED,         // LTK_HEAD_FUSED     1: output_block conv 80->32 + 1x1 head + sigmoid in one launch
     K_CONV3_NC8,          // LTK_CONV3_NC8      conv3 3x3: channel planes per chunk (2 = 16 channels, 4 = 32); 0 = by map size
     K_TILE_RULE,          // LTK_TILE_RULE      conv3 3x3 tile selection: 1 = items-per-CU rule (round 2), 0 = round-1 heuristic (A/B)

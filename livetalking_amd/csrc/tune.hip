@@ -15,7 +15,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_GEMM_NC8", 4},       {"LTK_CONV_MODE", 1},       {"LTK_CONV_MIN_BLOCKS", 512}, {"LTK_CONV_PXW", 0},
     {"LTK_CONV3_NBT", 0},      {"LTK_CONV_PXW4_MIN", 448}, {"LTK_SPLITK", 1},            {"LTK_KSPLIT", 0},
     {"LTK_CONV_PERSIST", 512}, {"LTK_NO_FOLD_RESIDUAL", 0}, {"LTK_NO_FLATTEN", 0},       {"LTK_NO_AUX_STREAM", 0},
-    {"LTK_MICROBATCH", 0},     {"LTK_MT_NO_QKV_FUSE", 0},  {"LTK_SPLITK_FUSED", 1},      {"LTK_HEAD_FUSED", 1},
+    {"LTK_MICROBATCH", 0},     {"LTK_MT_NO_QKV_FUSE", 0},  {"LTK_HEAD_FUSED", 1},
     {"LTK_CONV3_NC8", 0},      {"LTK_TILE_RULE", 1},       {"LTK_TILE_TABLE", 1},        {"LTK_CONV7", 1},           {"LTK_ATTN_WIDE", 1},       {"LTK_UPS4", 1},            {"LTK_FP8_MX", 1},
     {"LTK_ABLATE", 0},
 };
