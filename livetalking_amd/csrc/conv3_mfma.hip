@@ -879,6 +879,9 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
             const int pxw = cand[ci][0], nbt = cand[ci][1];
             // 512 px x 32 ch only for the layers that have no more than 32 output channels
             if ((pxw == 4 && NC8 != 2) || (nbt == 2 && p.lCout < 64) || (pxw == 4 && nbt == 1 && p.lCout >= 64)) continue;
+            // the fused output head exists for the 512- and 256-pixel tiles only: a one-frame launch (--batch_size 1, or the
+            // one-frame remainder of a micro-batched call) would otherwise settle on 128-pixel tiles and be rejected below
+            if (io.head_w != nullptr && io.head_outs != nullptr && pxw == 1) continue;
             if (!geom(pxw)) continue;
             fit = true; PXW = pxw; NBT = nbt;
             // (640 input channels and more: ~1 item per CU is enough - a 40-chunk item hides its own start-up, and the larger tile
@@ -905,6 +908,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     int ksplit = knob(K_SPLITK) ? k3_ksplit(blocks * a.n_ntiles, a.nchunks, (T == 1 || !knob(K_TILE_RULE)) ? 0 : (G == 4 ? 8 : 4)) : 1;
     const int fks = io.force_ksplit ? io.force_ksplit : knob(K_KSPLIT);
     if (fks > 0 && knob(K_SPLITK)) ksplit = std::max(1, std::min(std::min(fks, kMaxKSplit), a.nchunks));
+    if (io.head_w != nullptr && io.head_outs != nullptr) ksplit = 1;      // the fused head finishes in the epilogue: no partial slabs
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
     }

@@ -225,6 +225,51 @@ def main():
         shrink_crc=np.asarray(shrink_crc, dtype=np.uint32))
     print("paste: reference paste_back_frame == oracle on", B + 2, "frames (cv2.resize leaf restated, unpinned vs OpenCV)")
 
+    # ------------------------------------------- the BENCHMARKED configuration (BASELINE.json configs[1])
+    # B = 16 on the 250-frame 720p bank with ~320-px boxes (bench.py's bank), the index chosen so that the step walks over
+    # the ping-pong turn of the bank (243..249, 249..241), through the reference's own LipReal.inference_batch and
+    # paste_back_frame; plus the 200-px (shrinking) bank of SURVEY.md 8d for the composite.  Stored: CRCs + sub-samples.
+    Bb, index_b = 16, 243
+    frames_b, faces_b, coords_b = synth.wav2lip_bank(n_frames=250, full_hw=(720, 1280), box=320, seed=0)
+    feats_b = [ref_steps[1][i] for i in range(Bb)]
+    lip.batch_size = Bb
+    lip.frame_list_cycle, lip.face_list_cycle, lip.coord_list_cycle = frames_b, faces_b, coords_b
+    ref_pred_b = lip.inference_batch(index_b, feats_b)                      # float32 (16,256,256,3)
+    assert ref_pred_b.shape == (Bb, 256, 256, 3)
+    my_pred_b = plugin_oracle.inference_batch(sd, faces_b, index_b, Bb, feats_b)
+    err_b = float(np.abs(my_pred_b - ref_pred_b).max())
+    assert err_b < 1e-3, err_b
+    crc_b, sub_b, idx_b = [], [], []
+    for i in range(Bb):
+        idx = ref_mirror(len(frames_b), index_b + i)
+        ref_frame = lip.paste_back_frame(ref_pred_b[i], idx)
+        assert np.array_equal(ref_frame, paste_oracle.paste_back_frame(ref_pred_b[i], frames_b[idx], coords_b[idx]))
+        y1, y2, x1, x2 = coords_b[idx]
+        crc_b.append(zlib.crc32(ref_frame.tobytes())); idx_b.append(idx)
+        sub_b.append(ref_frame[y1:y2:8, x1:x2:8][:39, :39].copy())
+    frames_s, faces_s, coords_s = synth.wav2lip_bank(n_frames=8, full_hw=(720, 1280), box=200, seed=1)
+    lip.frame_list_cycle, lip.coord_list_cycle = frames_s, coords_s
+    crc_s, sub_s = [], []
+    for i in range(Bb):
+        ref_frame = lip.paste_back_frame(ref_pred_b[i], i % 8)
+        assert np.array_equal(ref_frame, paste_oracle.paste_back_frame(ref_pred_b[i], frames_s[i % 8], coords_s[i % 8]))
+        y1, y2, x1, x2 = coords_s[i % 8]
+        crc_s.append(zlib.crc32(ref_frame.tobytes()))
+        sub_s.append(ref_frame[y1:y2:8, x1:x2:8][:24, :24].copy())
+    np.savez_compressed(
+        os.path.join(args.out, "wav2lip_bench_golden.npz"),
+        weight_seed=1234, generator="synth_inputs.wav2lip_bank", bank_frames=250, bank_hw=np.asarray([720, 1280]), bank_box=320,
+        bank_seed=0, batch=Bb, index=index_b, mel_step=1, bank_idx=np.asarray(idx_b),
+        face_crc=zlib.crc32(b"".join(f.tobytes() for f in faces_b)),
+        ref_pred_u8_crc=zlib.crc32(ref_pred_b.astype(np.uint8).tobytes()),
+        ref_pred_sub=ref_pred_b[:, ::8, ::8, :].astype(np.float32),           # 16 x 32 x 32 x 3 fp32
+        ref_pred_u8_q=ref_pred_b[:, 3::4, 1::4, :].astype(np.uint8),          # every 16th pixel of the uint8 frames
+        frame_crc=np.asarray(crc_b, dtype=np.uint32), bbox_sub=np.stack(sub_b),
+        shrink_frames=8, shrink_box=200, shrink_seed=1,
+        shrink_crc=np.asarray(crc_s, dtype=np.uint32), shrink_sub=np.stack(sub_s),
+        oracle_vs_reference_maxerr=err_b)
+    print(f"bench config: B=16 @ index 243 on the 250-frame 720p / 320-px bank + 200-px bank; oracle-vs-reference {err_b:.2e} (of 255)")
+
 
 if __name__ == "__main__":
     main()

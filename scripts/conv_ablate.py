@@ -19,7 +19,21 @@ LAYERS = [
     ("out80>32@256", 256, 256, 80, 32, 3, 1, 1, False, 0, False),
     ("T160>64@128", 128, 128, 160, 64, 3, 2, 1, True, 1, False),
     ("T320>128@64", 64, 64, 320, 128, 3, 2, 1, True, 1, False),
+    # the small-map, deep-K layers (weights dominate; ABLATE_SET=small)
+    ("c512@16", 16, 16, 512, 512, 3, 1, 1, False, 0, True),
+    ("c512@8", 8, 8, 512, 512, 3, 1, 1, False, 0, True),
+    ("c512@4", 4, 4, 512, 512, 3, 1, 1, False, 0, True),
+    ("T1024>512@8", 8, 8, 1024, 512, 3, 2, 1, True, 1, False),
+    ("T1024>512@4", 4, 4, 1024, 512, 3, 2, 1, True, 1, False),
+    ("T768>384@16", 16, 16, 768, 384, 3, 2, 1, True, 1, False),
+    ("s2 256>512@16", 16, 16, 256, 512, 3, 2, 1, False, 0, False),
+    ("s2 512>512@8", 8, 8, 512, 512, 3, 2, 1, False, 0, False),
 ]
+_SET = os.environ.get("ABLATE_SET", "")
+if _SET == "small":
+    LAYERS = [l for l in LAYERS if l[0].endswith(("@16", "@8", "@4"))]
+elif _SET == "big":
+    LAYERS = [l for l in LAYERS if not l[0].endswith(("@16", "@8", "@4"))]
 MASKS = [int(m) for m in os.environ.get("ABLATE_MASKS", "0,3,4,24,27,31,63,95,127,64,128,132").split(",")]
 
 

@@ -139,6 +139,48 @@ def wav2lip_avatar(n_frames: int = 8, full_hw: Tuple[int, int] = (720, 1280),
     return frames, faces, coords
 
 
+def _lerp_axis(a: np.ndarray, n_out: int, axis: int) -> np.ndarray:
+    """Linear interpolation of fp32 `a` along `axis` at the sample positions `_smooth_image` uses: elementwise IEEE
+    products and sums only (no BLAS), so the bytes are the same on every host."""
+    n_in = a.shape[axis]
+    pos = np.linspace(0, n_in - 1.001, n_out)
+    i0 = pos.astype(np.int64)
+    shape = [1] * a.ndim
+    shape[axis] = n_out
+    f = (pos - i0).astype(np.float32).reshape(shape)
+    return np.take(a, i0, axis=axis) * (np.float32(1) - f) + np.take(a, i0 + 1, axis=axis) * f
+
+
+def _smooth_image_fast(rng: np.random.Generator, h: int, w: int, grain: np.ndarray, cells: int = 12) -> np.ndarray:
+    """`_smooth_image` for LARGE banks (the 250-frame 720p bench bank): the same coarse-grid bilinear
+    field in fp32, separable, plus a fixed fine-grain field rolled by a per-frame offset (~10x faster per 720p frame).  A
+    different pixel stream than `_smooth_image`: fixtures name the generator they used."""
+    gh, gw = cells + 1, cells * w // h + 2
+    coarse = rng.uniform(0, 255, (gh, gw, 3)).astype(np.float32)
+    img = _lerp_axis(_lerp_axis(coarse, h, 0), w, 1)
+    dy, dx = (int(v) for v in rng.integers(0, 64, 2))
+    img += grain[dy:dy + h, dx:dx + w]
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def wav2lip_bank(n_frames: int = 250, full_hw: Tuple[int, int] = (720, 1280), box: int = 320, seed: int = 0
+                 ) -> Tuple[List[np.ndarray], List[np.ndarray], List[Tuple[int, int, int, int]]]:
+    """The SURVEY.md 8d bench bank: `n_frames` smooth full frames + 256^2 face crops + jittered (y1,y2,x1,x2) boxes of
+    about box^2 pixels (box 320: the paste-back upscales the 256^2 prediction, box 200: it shrinks it), in the layout
+    `load_avatar` returns (avatars/wav2lip_avatar.py:72-88).  Same contract as `wav2lip_avatar`, ~15x faster per frame."""
+    rng = np.random.default_rng([seed, n_frames, box])
+    H, W_ = full_hw
+    grain = rng.normal(0, 3.0, (H + 64, W_ + 64, 3)).astype(np.float32)
+    frames, faces, coords = [], [], []
+    cy, cx = H // 2, W_ // 2
+    for _ in range(n_frames):
+        frames.append(_smooth_image_fast(rng, H, W_, grain))
+        faces.append(_smooth_image_fast(rng, 256, 256, grain, cells=10))
+        j = rng.integers(-4, 5, 4)
+        coords.append((int(cy - box // 2 + j[0]), int(cy + box // 2 + j[1]), int(cx - box // 2 + j[2]), int(cx + box // 2 + j[3])))
+    return frames, faces, coords
+
+
 # ---------------------------------------------------------------------------------------------------------
 # MuseTalk: seeded state dicts under diffusers' key names (UNet2DConditionModel with the MuseTalk-1.5 config,
 # AutoencoderKL decoder of sd-vae-ft-mse).  No checkpoint or config exists in the reference tree

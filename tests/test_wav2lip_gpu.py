@@ -85,6 +85,27 @@ def test_infer_vs_reference_golden(engine, golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 2])
+def test_infer_one_and_two_frames(engine, golden_dir, B):
+    """--batch_size 1 (config.py:65) and a 2-frame call through ltk_wav2lip_infer with the fused head (the default): the
+    output conv must pick a tile the fused epilogue exists for also when a launch has a single frame.  Frames against the
+    reference's LipReal.inference_batch golden (frame i of the B=4 golden depends on bank index and window i only)."""
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    index = int(g["index"])
+    aid = engine.register_avatar(faces, frames, coords)
+    mel = torch.from_numpy(np.stack(feats[:B]).astype(np.float32)).cuda()
+    pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
+    got = pred.cpu().numpy()
+    ref = g["ref_pred_u8"][:B]
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    p = psnr_u8(got, ref)
+    print(f"[infer B={B}] PSNR {p:.2f} dB, max abs {d.max()} LSB")
+    assert p >= 40.0 and d.max() <= 6
+    engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
 def test_infer_batching_invariance(engine, golden_dir):
     """Two sessions coalesced into one launch vs the same sessions run one by one: cross-session batching
     must not change a session's frames.  Tiling never changes an output element's summation order; the
@@ -218,5 +239,102 @@ def test_full_size_batching_properties(golden_dir):
             assert torch.equal(whole[:16], both[:16]) or mode == 1
     finally:
         Engine.set_knob("SPLITK", 1)
+        Engine.set_knob("MICROBATCH", 0)
+        eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the BENCHMARKED configuration (BASELINE.json configs[1] / configs[3] share): B = 16 on the 250-frame 720p bank
+# ---------------------------------------------------------------------------------------------------------------
+def _bench_inputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wav2lip_bench_golden.npz"))
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    hw = tuple(int(v) for v in g["bank_hw"])
+    frames, faces, coords = synth.wav2lip_bank(int(g["bank_frames"]), hw, int(g["bank_box"]), int(g["bank_seed"]))
+    assert zlib.crc32(b"".join(f.tobytes() for f in faces)) == int(g["face_crc"]), "synthetic bank drifted"
+    return g, gm, frames, faces, coords
+
+
+def _frame_report(tag, got, ref_f32):
+    """got uint8 (B,256,256,3) from the HIP path, ref_f32 the oracle's float frames (truncated like paste_back does)."""
+    ref = ref_f32.astype(np.uint8)
+    worst_p, worst_d = 99.0, 0
+    for i in range(got.shape[0]):
+        d = np.abs(got[i].astype(np.int32) - ref[i].astype(np.int32))
+        worst_p, worst_d = min(worst_p, psnr_u8(got[i], ref[i])), max(worst_d, int(d.max()))
+    frac2 = float((np.abs(got.astype(np.int32) - ref.astype(np.int32)) <= 2).mean())
+    print(f"[{tag}] worst frame PSNR {worst_p:.2f} dB, max abs {worst_d} LSB, within+-2: {frac2:.5f}")
+    return worst_p, worst_d, frac2
+
+
+@pytest.mark.gpu
+def test_bench_config_b16_vs_oracle(engine, golden_dir):
+    """One bench step (bench.py: 1 session x 16 frames, 250-frame 720p bank, ~320-px boxes) through ltk_wav2lip_infer +
+    ltk_paste_back against the oracle run live on the same inputs, every one of the 16 frames; the oracle itself is held to
+    the reference's own LipReal output at this configuration (tests/golden/wav2lip_bench_golden.npz).  The composite is
+    bit-exact given the prediction bytes, on the upscaling (320-px) and on the shrinking (200-px) bank."""
+    g, gm, frames, faces, coords = _bench_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    feats = [gm["ref_chunks"][int(g["mel_step"])][i] for i in range(B)]
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(int(g["weight_seed"])).items()}
+    ref = plugin_oracle.inference_batch(sd, faces, index, B, feats)                       # float32 (16,256,256,3)
+    assert np.abs(ref[:, ::8, ::8] - g["ref_pred_sub"]).max() < 2e-3                      # the oracle's pin at this configuration
+    aid = engine.register_avatar(faces, frames, coords)
+    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+    engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
+    got = pred.cpu().numpy()
+    p, dmax, frac2 = _frame_report("bench B=16", got, ref)
+    assert p >= 40.0 and dmax <= 6 and frac2 >= 0.99
+    from oracle import paste_oracle
+    out = np.empty_like(frames[0])
+    for i in range(B):
+        idx = int(g["bank_idx"][i])
+        engine.paste_back(aid, idx, pred[i].data_ptr(), out)
+        assert np.array_equal(out, paste_oracle.paste_back_frame(got[i].astype(np.float32), frames[idx], coords[idx])), i
+        y1, y2, x1, x2 = coords[idx]          # and the composited box stays within the frame tolerance of the reference's composite
+        dd = np.abs(out[y1:y2:8, x1:x2:8][:39, :39].astype(np.int32) - g["bbox_sub"][i].astype(np.int32))
+        assert dd.max() <= 6, (i, int(dd.max()))
+    engine.release_avatar(aid)
+    hw = tuple(int(v) for v in g["bank_hw"])
+    fr_s, fa_s, co_s = synth.wav2lip_bank(int(g["shrink_frames"]), hw, int(g["shrink_box"]), int(g["shrink_seed"]))
+    aid2 = engine.register_avatar(fa_s, fr_s, co_s)
+    for i in range(B):
+        k = i % len(fr_s)
+        engine.paste_back(aid2, k, pred[i].data_ptr(), out)
+        assert np.array_equal(out, paste_oracle.paste_back_frame(got[i].astype(np.float32), fr_s[k], co_s[k])), i
+        y1, y2, x1, x2 = co_s[k]
+        dd = np.abs(out[y1:y2:8, x1:x2:8][:24, :24].astype(np.int32) - g["shrink_sub"][i].astype(np.int32))
+        assert dd.max() <= 6, (i, int(dd.max()))
+    engine.release_avatar(aid2)
+
+
+@pytest.mark.gpu
+def test_coalesced_256_frames_vs_oracle(golden_dir):
+    """BASELINE.json configs[3]'s per-GPU share: 16 sessions x 16 frames coalesced into ONE 256-frame call on the bench bank,
+    every session with its own bank position and its own audio windows; the first and the last session's frames are checked
+    against the ORACLE (not against the engine's own 16-frame calls)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    g, gm, frames, faces, coords = _bench_inputs(golden_dir)
+    B, S = 16, 16
+    chunks = gm["ref_chunks"]                                             # (3,16,80,16): three MelASR steps of the reference
+    sess_feats = [[chunks[(s + i) % 3][(i + 5 * s) % 16] for i in range(B)] for s in range(S)]
+    index = [(243 + 37 * s) % (2 * len(frames)) for s in range(S)]
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(int(g["weight_seed"])).items()}
+    Engine.set_knob("MICROBATCH", 256)
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(int(g["weight_seed"])), max_frames=S * B)
+        aid = eng.register_avatar(faces, frames, coords)
+        mel = torch.from_numpy(np.asarray(sess_feats, dtype=np.float32)).cuda()              # (S,B,80,16)
+        pred = torch.zeros(S, B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+        eng.wav2lip_infer([(aid, index[s], B, mel[s].data_ptr(), pred[s].data_ptr()) for s in range(S)])
+        for s in (0, S - 1):
+            ref = plugin_oracle.inference_batch(sd, faces, index[s], B, sess_feats[s])
+            p, dmax, frac2 = _frame_report(f"256-frame call, session {s}", pred[s].cpu().numpy(), ref)
+            assert p >= 40.0 and dmax <= 6 and frac2 >= 0.99
+    finally:
         Engine.set_knob("MICROBATCH", 0)
         eng.close()
