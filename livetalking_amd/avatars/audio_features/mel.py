@@ -43,7 +43,6 @@ class MelASR(BaseASR):
         self.engine = engine
         import torch  # device buffers only
         self._torch = torch
-        self._ring = None
 
     def run_step(self):
         for _ in range(self.batch_size * 2):

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 namespace ltk {
@@ -20,16 +21,21 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_ABLATE", 0},
 };
 
-int g_val[K_COUNT];
+std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
 std::once_flag g_once;
 
 void init() {
     for (int i = 0; i < K_COUNT; ++i) {
         const char* e = getenv(kDefs[i].name);
-        // presence-style switches (LTK_NO_*): any value, also the empty string, means 1 unless it parses as a number
-        if (!e) g_val[i] = kDefs[i].dflt;
-        else if (*e == 0) g_val[i] = 1;
-        else g_val[i] = atoi(e);
+        // presence-style switches (LTK_NO_*): any value means 1 - the empty string, "true", "yes" - unless the WHOLE value
+        // parses as a number (LTK_NO_AUX_STREAM=0 switches it off again)
+        int v = kDefs[i].dflt;
+        if (e) {
+            char* end = nullptr;
+            const long n = strtol(e, &end, 10);
+            v = (*e != 0 && end && *end == 0) ? (int)n : 1;
+        }
+        g_val[i].store(v, std::memory_order_relaxed);
     }
 }
 
@@ -37,14 +43,14 @@ void init() {
 
 int knob(Knob k) {
     std::call_once(g_once, init);
-    return g_val[k];
+    return g_val[k].load(std::memory_order_relaxed);
 }
 
 int knob_set(const char* name, int value) {
     std::call_once(g_once, init);
     if (!name) return -1;
     for (int i = 0; i < K_COUNT; ++i)
-        if (!strcmp(name, kDefs[i].name) || !strcmp(name, kDefs[i].name + 4)) { g_val[i] = value; return 0; }
+        if (!strcmp(name, kDefs[i].name) || !strcmp(name, kDefs[i].name + 4)) { g_val[i].store(value, std::memory_order_relaxed); return 0; }
     return -1;
 }
 

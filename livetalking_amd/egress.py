@@ -52,6 +52,24 @@ class I420Frame(np.ndarray):
         return y, u, v
 
 
+def host_bgr_to_i420(frame: np.ndarray, chroma: int = 1) -> "I420Frame":
+    """Host twin of the device BGR24 -> I420 conversion (csrc/egress_kernels.hip; libswscale's 15-bit BT.601 limited-range
+    matrix, round to nearest; chroma from the 2x2 mean, or from the top-left pixel when chroma == 0), for the one frame kind
+    that cannot go through the engine's egress session: a custom-action clip whose size differs from the avatar's
+    (base_avatar.py:410-416).  An odd trailing row / column is dropped (4:2:0 needs even dimensions)."""
+    H, W = frame.shape[0] & ~1, frame.shape[1] & ~1
+    f = np.ascontiguousarray(frame[:H, :W]).astype(np.int32)
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    y = ((8414 * r + 16519 * g + 3208 * b + 16384) >> 15) + 16
+    q = ((f[0::2, 0::2] + f[0::2, 1::2] + f[1::2, 0::2] + f[1::2, 1::2] + 2) >> 2) if chroma else f[0::2, 0::2]
+    cb, cg, cr = q[..., 0], q[..., 1], q[..., 2]
+    u = ((-4865 * cr - 9528 * cg + 14392 * cb + 16384) >> 15) + 128
+    v = ((14392 * cr - 12061 * cg - 2332 * cb + 16384) >> 15) + 128
+    out = np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8).reshape(H * 3 // 2, W).view(I420Frame)
+    out.width, out.height = W, H
+    return out
+
+
 class DeviceEgress:
     """One per render session: the engine-side egress session plus the transition clock of process_frames."""
 
@@ -166,6 +184,10 @@ class DeviceEgressMixin:
                             cv2.putText(frame, WATERMARK_TEXT, WATERMARK_ORG, cv2.FONT_HERSHEY_SIMPLEX, 0.3, WATERMARK_COLOR, 1)
                         except Exception:  # noqa: BLE001
                             pass
+                        if eg.fmt == FMT_I420:
+                            # keep ONE frame type per stream: the odd-sized clip is converted on the host with the same
+                            # BT.601 limited-range integer arithmetic the device kernel uses
+                            frame = host_bgr_to_i420(frame, eg.chroma)
                     except Exception as e:  # noqa: BLE001 - log and drop the frame, like the speaking path below
                         import logging
                         logging.getLogger(__name__).warning("silent frame error: %s", e)

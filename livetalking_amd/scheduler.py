@@ -101,11 +101,21 @@ class BatchingScheduler:
             group, frames = self._take_batch()
         if not group:
             return
-        err = None
+        errs = [None] * len(group)
         try:
             self._call([q.args for q in group])
-        except Exception as ex:  # noqa: BLE001 - every caller of this batch gets the error
-            err = ex
+        except Exception as ex:  # noqa: BLE001
+            if len(group) == 1:
+                errs[0] = ex
+            else:
+                # One bad request (released avatar, bad pointer, oversize batch) must not kill the inference threads of the
+                # sessions it happened to be batched with (base_avatar.py:366 has no try/except): the engine validates a
+                # call before it launches anything, so the requests are re-issued one by one and only the offender raises.
+                for i, q in enumerate(group):
+                    try:
+                        self._call([q.args])
+                    except Exception as ex_i:  # noqa: BLE001
+                        errs[i] = ex_i
         with self._cv:
             self.stats["calls"] += 1
             self.stats["requests"] += len(group)
@@ -113,7 +123,7 @@ class BatchingScheduler:
             self.stats["max_requests_per_call"] = max(self.stats["max_requests_per_call"], len(group))
             if len(group) > 1:
                 self._last_multi = time.perf_counter()
-        for q in group:
+        for q, err in zip(group, errs):
             q.err = err
             q.done.set()
 
@@ -123,7 +133,8 @@ class BatchingScheduler:
             with self._cv:
                 while not self._handoff and not self._closed:
                     self._cv.wait()
-                if self._closed:
+                if self._closed and not self._handoff:
+                    self._worker = None
                     return
                 self._handoff = False
             while True:
@@ -134,15 +145,28 @@ class BatchingScheduler:
                 self._run_one_batch()
 
     def close(self):
+        """Stop the worker.  Requests already queued are failed (their callers raise) instead of being left blocked; a later
+        infer() still works: it runs as a leader and starts a new worker when it needs one."""
         with self._cv:
             self._closed = True
+            dropped = []
+            if not self._busy or self._handoff:           # nobody is about to drain the queue
+                dropped = list(self._pending)
+                self._pending.clear()
+                if self._handoff:
+                    self._handoff = False
+                    self._busy = False
             self._cv.notify_all()
-
-
-# kept under the old names for callers that construct them directly
-class DirectScheduler(BatchingScheduler):
-    def __init__(self, engine, kind: str = "wav2lip"):
-        super().__init__(engine, kind, 0.0)
+        for q in dropped:
+            q.err = RuntimeError("scheduler closed")
+            q.done.set()
+        w = self._worker
+        if w is not None and w is not threading.current_thread():
+            w.join(timeout=5.0)
+        with self._cv:
+            if self._worker is not None and not self._worker.is_alive():
+                self._worker = None
+            self._closed = False
 
 
 class CoalescingScheduler(BatchingScheduler):
@@ -150,15 +174,16 @@ class CoalescingScheduler(BatchingScheduler):
         super().__init__(engine, kind, window_ms)
 
 
-_SCHEDULERS = {}
+# one scheduler per (engine, kind), held on the engine object itself: it goes away with the engine (a registry keyed by
+# id(engine) kept every engine - and its GPU weights - alive for the life of the process)
 _LOCK = threading.Lock()
 
 
 def get_scheduler(engine, kind: str = "wav2lip"):
     with _LOCK:
-        key = (id(engine), kind)
-        s = _SCHEDULERS.get(key)
+        table = engine.__dict__.setdefault("_ltk_schedulers", {})
+        s = table.get(kind)
         if s is None:
             s = BatchingScheduler(engine, kind, float(os.environ.get("LTK_COALESCE_MS", "0")))
-            _SCHEDULERS[key] = s
+            table[kind] = s
         return s

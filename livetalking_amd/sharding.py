@@ -5,8 +5,8 @@ avatar banks between them, app.py:62-63,99), so an 8-GPU node runs 8 replicas
 of the engine and every session lives on exactly one of them: no collective, no
 exchange step, xGMI unused.  Two deployment shapes use the same assignment:
 
-* one process per GPU (bench.py under torch.distributed.run): rank r serves
-  `shard_for_rank(...)`;
+* one process per GPU (bench.py under torch.distributed.run): rank r owns GPU r, its own engine, bank replica and
+  `--sessions` sessions (weak scaling: the per-GPU share is fixed, BASELINE.json configs[3] = 16 per GPU);
 * one process, several GPUs (`EnginePool`, what the plugin modules' load_model builds): a new session goes to the least
   loaded engine; weights are replicated at load time, avatar banks on first use per engine.
 """
@@ -14,22 +14,6 @@ from __future__ import annotations
 
 import threading
 from typing import Dict, List, Sequence
-
-
-def assign_round_robin(n_sessions: int, n_gpus: int) -> List[List[int]]:
-    """Session ids per GPU; sizes differ by at most one."""
-    if n_gpus <= 0:
-        raise ValueError("n_gpus must be positive")
-    shards: List[List[int]] = [[] for _ in range(n_gpus)]
-    for s in range(n_sessions):
-        shards[s % n_gpus].append(s)
-    return shards
-
-
-def shard_for_rank(n_sessions: int, world_size: int, rank: int) -> List[int]:
-    if not 0 <= rank < world_size:
-        raise ValueError("rank outside world")
-    return assign_round_robin(n_sessions, world_size)[rank]
 
 
 class LeastLoaded:

@@ -154,11 +154,52 @@ def test_continuous_batching_without_a_window():
     sch.close()
 
 
-def test_least_loaded_placement_and_round_robin():
-    from livetalking_amd.sharding import LeastLoaded, assign_round_robin, shard_for_rank
-    shards = assign_round_robin(128, 8)
-    assert all(len(s) == 16 for s in shards) and sorted(sum(shards, [])) == list(range(128))
-    assert shard_for_rank(10, 4, 3) == [3, 7]
+def test_poisoned_request_fails_alone_and_close_unblocks():
+    """One bad request inside a 3-request batch raises only in its own caller (the reference's inference thread has no
+    try/except, base_avatar.py:366: an error delivered to every co-batched session would kill all of their threads); close()
+    never leaves a queued caller blocked and the scheduler keeps working afterwards."""
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+
+    class SlowEngine(FakeEngine):
+        def wav2lip_infer(self, reqs, stream=0):
+            if any(r[0] == 99 for r in reqs):
+                raise RuntimeError("unknown avatar 99")
+            time.sleep(0.1)
+            super().wav2lip_infer(reqs, stream)
+
+    eng = SlowEngine()
+    sch = scheduler.BatchingScheduler(eng, "wav2lip")
+    results = {}
+
+    def call(tag, aid, index):
+        try:
+            sch.infer(aid, index, 16, 1000 + index, 2000 + index)
+            results[tag] = "ok"
+        except RuntimeError as ex:
+            results[tag] = str(ex)
+
+    first = threading.Thread(target=call, args=("first", 1, 0))
+    first.start()
+    time.sleep(0.03)                                     # in flight: the next three queue up and go down as one call
+    late = [threading.Thread(target=call, args=(tag, aid, idx)) for tag, aid, idx in (("a", 1, 16), ("bad", 99, 32), ("c", 1, 48))]
+    for t in late:
+        t.start()
+    for t in [first] + late:
+        t.join(timeout=10)
+        assert not t.is_alive()
+    assert results == {"first": "ok", "a": "ok", "bad": "unknown avatar 99", "c": "ok"}, results
+    served = sorted(r[1] for c in eng.infer_calls for r in c)
+    assert served == [0, 16, 48], eng.infer_calls          # the good requests of the poisoned batch were re-issued and served
+    assert scheduler.get_scheduler(eng) is scheduler.get_scheduler(eng)      # held on the engine object, not in a global table
+    assert not hasattr(scheduler, "_SCHEDULERS")
+    sch.close()
+    sch.infer(1, 64, 16, 1, 2)                           # usable after close()
+    sch.close()
+
+
+def test_least_loaded_placement():
+    from livetalking_amd.sharding import LeastLoaded
     p = LeastLoaded(2, capacity_per_gpu=2)
     assert [p.place(s) for s in "abcd"] == [0, 1, 0, 1]
     with pytest.raises(RuntimeError):

@@ -226,3 +226,18 @@ def test_process_frames_mixin_control_flow():
     assert len(s.output.video) == 5 and len(s.output.audio) == 10
     assert s.output.audio[0][0] == np.int16 and s.output.audio[0][2] == {"k": 1}
     assert calls[-1] == ("close", 7)
+
+
+def test_host_i420_twin_matches_the_oracle_and_keeps_one_frame_type():
+    """The odd-size custom-clip fallback of DeviceEgressMixin.process_frames converts on the host when the stream is I420
+    (one frame type per stream): same bytes as the oracle's swscale restatement, both chroma sitings; odd sizes are cropped."""
+    from livetalking_amd.egress import I420Frame, host_bgr_to_i420
+    from oracle import egress_oracle
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (38, 54, 3), dtype=np.uint8)
+    for chroma in (1, 0):
+        got = host_bgr_to_i420(img, chroma)
+        assert isinstance(got, I420Frame) and (got.height, got.width) == (38, 54)
+        assert np.array_equal(np.asarray(got), egress_oracle.bgr_to_i420(img, chroma))
+    odd = host_bgr_to_i420(img[:37, :53])
+    assert (odd.height, odd.width) == (36, 52) and np.array_equal(np.asarray(odd), egress_oracle.bgr_to_i420(img[:36, :52]))

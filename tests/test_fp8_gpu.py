@@ -7,7 +7,9 @@
    rounding decisions on fp16-vs-fp32 GroupNorm outputs differ for ~1 % of the values, each a 6 % step; measured 2.4e-2 /
    4.5e-2), frames PSNR >= 37 dB (measured 40.9);
 3. the quantisation cost itself, fp8 engine vs the UNQUANTISED fp32 oracle: reported (measured 39.2 dB; the emulation
-   itself is 39.3 dB from the fp32 oracle), frames PSNR >= 35 dB asserted.
+   itself is 39.3 dB from the fp32 oracle), frames PSNR >= 38 dB asserted.  This is the STATED fp8 tolerance of configs[4]
+   (DESIGN.md section 4): e4m3 carries 3 mantissa bits, its 6 % relative step does not depend on the activation scale, so a
+   calibrated per-tensor scale cannot buy the 40 dB of the fp16 path back; only fewer fp8 layers could.
 """
 import numpy as np
 import pytest
@@ -128,6 +130,6 @@ def test_musetalk_fp8_vs_emulation_and_fp32():
         print(f"[fp8] engine vs fp8 emulation: latents rel_l2={r_lat:.3e} image rel_l2={r_img:.3e} frames {p_emul:.1f} dB")
         print(f"[fp8] engine vs fp32 oracle  : latents rel_l2={q_lat:.3e} frames {p_fp32:.1f} dB (emulation vs fp32 oracle: {p_or:.1f} dB)")
         assert r_lat <= 4e-2 and r_img <= 7e-2 and p_emul >= 37.0
-        assert p_fp32 >= 35.0
+        assert p_fp32 >= 38.0
     finally:
         eng.close()

@@ -101,6 +101,14 @@ def test_unet_and_vae_vs_oracle(mt):
     psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
     print(f"[mt] frames PSNR {psnr:.2f} dB, max {d.max()} LSB, within+-2: {float((d <= 2).mean()):.5f}")
     assert psnr >= 45.0 and float((d <= 2).mean()) >= 0.999
+    # END TO END: PE + U-Net + VAE on the device against the oracle decoding the ORACLE's own latents (no device value enters
+    # the reference side): frames PSNR >= 40 dB, max-abs <= 6 LSB, >= 99 % of the bytes within +-2 LSB (the Wav2Lip frame tolerance)
+    e2e_frames = ((ref_img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).round().astype(np.uint8)[..., ::-1]
+    de = np.abs(got_frames.astype(np.int32) - e2e_frames.astype(np.int32))
+    mse_e = float((de.astype(np.float64) ** 2).mean())
+    psnr_e = 99.0 if mse_e == 0 else 10 * np.log10(255.0 ** 2 / mse_e)
+    print(f"[mt] END-TO-END frames PSNR {psnr_e:.2f} dB, max {de.max()} LSB, within+-2: {float((de <= 2).mean()):.5f}")
+    assert psnr_e >= 40.0 and de.max() <= 6 and float((de <= 2).mean()) >= 0.99
 
 
 @pytest.mark.gpu
@@ -207,5 +215,48 @@ def test_full_size_batching_properties():
         psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
         print(f"[mt full size] 64-frame call vs 16-frame calls: max diff {int(d.max())} LSB, differing bytes {float((d != 0).float().mean()):.2e}, PSNR {psnr:.1f} dB")
         assert int(d.max()) <= 2 and psnr >= 50.0
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_infer_b16_end_to_end_vs_oracle():
+    """BASELINE.json configs[2] at its batch size: ONE 16-frame ltk_musetalk_infer call (latent gather by mirror_index across the
+    ping-pong turn, PE, U-Net, VAE decode, uint8 BGR) against the oracle run end to end on the same latents / features -
+    frames out vs frames out, asserted: PSNR >= 40 dB, max-abs <= 6 LSB, >= 99 % of the bytes within +-2 LSB."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    from oracle import paste_oracle
+    Bf, n = 16, 5
+    unet_sd, vae_sd = synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict()
+    eng = Engine(0)
+    try:
+        eng.load_musetalk(unet_sd, vae_sd, max_frames=Bf)
+        lats = synth.musetalk_latents(n)
+        frames, _, _ = synth.wav2lip_avatar(n_frames=n, full_hw=(360, 640), box=160, seed=2)
+        aid = eng.register_musetalk_avatar(lats, frames, [(240, 100, 400, 280)] * n, [np.full((255, 220, 3), 255, np.uint8)] * n,
+                                           [(210, 60, 430, 315)] * n)
+        feat = synth.musetalk_whisper_feats(Bf, seed=77)
+        d_feat = torch.from_numpy(feat).cuda()
+        d_pred = torch.zeros(Bf, 256, 256, 3, dtype=torch.uint8, device="cuda")
+        index = 2                                                  # bank positions 2,3,4,4,3,2,1,0,0,1,... (n = 5)
+        eng.musetalk_infer([(aid, index, Bf, d_feat.data_ptr(), d_pred.data_ptr())])
+        got = d_pred.cpu().numpy()
+        usd = {k: torch.from_numpy(v) for k, v in unet_sd.items()}
+        vsd = {k: torch.from_numpy(v) for k, v in vae_sd.items()}
+        lat = np.concatenate([lats[paste_oracle.mirror_index(n, index + i)] for i in range(Bf)])
+        with torch.no_grad():
+            ref_lat = M.unet_forward(usd, torch.from_numpy(lat), M.positional_encoding(torch.from_numpy(feat)))
+            ref_img = M.vae_decode(vsd, ref_lat / M.VAE_SCALING)
+        ref = ((ref_img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).round().astype(np.uint8)[..., ::-1]
+        worst = 99.0
+        for i in range(Bf):
+            di = got[i].astype(np.float64) - ref[i].astype(np.float64)
+            mse = float((di * di).mean())
+            worst = min(worst, 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse))
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        print(f"[mt B=16] worst frame PSNR {worst:.2f} dB, max {d.max()} LSB, within+-2: {float((d <= 2).mean()):.5f}")
+        assert worst >= 40.0 and d.max() <= 6 and float((d <= 2).mean()) >= 0.99
     finally:
         eng.close()
