@@ -1,0 +1,62 @@
+#!/bin/bash
+# One entry point for the jobs sent to the GPU box (`gpurun -- 'bash scripts/gpu_job.sh <mode> ...'`); everything lands under
+# gpurun_out/.  Modes:
+#   tests [pytest args]            the -m gpu suite (default: all of tests/), compact log
+#   bench [bench.py args]          one bench line -> gpurun_out/bench_<TAG>.json
+#   profile <tag>                  default bench + rocprofv3 kernel trace + the PMC passes (separate runs) of the Wav2Lip 16-frame,
+#                                  256-frame and MuseTalk (fp16 / fp8) workloads -> gpurun_out/<tag>/ ; summarise with make_profile_summary.py
+#   layers <knob-settings...> -- <frames...>   scripts/layer_times.py: per-layer times under knob settings, interleaved rounds
+#   ab-lib <tag> <a.so> <b.so> ... in-job A/B of several builds of libltk_hip.so (LTK_LIB), two interleaved rounds (MT=0 skips MuseTalk)
+#   ablate [small|big]             conv3 ablation masks per layer (needs ab_libs/libltk_hip_ablate.so: scripts/build_variant.sh ablate -DLTK_ABLATE_BUILD=1)
+#   pmc-layer                      SQ counters of single-layer launches (conv_ablate.py under rocprofv3 --pmc)
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(cd "$(dirname "$0")/.." && pwd)
+O=$R/gpurun_out; mkdir -p $O; cd $R
+MODE=$1; shift
+case $MODE in
+tests)
+  ARGS=${*:-tests}
+  timeout 1500 python -m pytest $ARGS -m gpu -x -q -s 2>&1 | grep -E "^\[|passed|failed|Error|error|FAIL|assert" | grep -v "^\[layer\]\|^\[mt\] [a-z_]*\.[a-z_0-9.]* " > $O/pytest_${TAG:-gpu}.log
+  tail -40 $O/pytest_${TAG:-gpu}.log ;;
+bench)
+  timeout 600 python bench.py "$@" > $O/bench_${TAG:-default}.json 2> $O/bench_${TAG:-default}.err; tail -c 1500 $O/bench_${TAG:-default}.json ;;
+profile)
+  TAG=${1:-r03}; P=$O/$TAG; mkdir -p $P
+  timeout 900 python bench.py --steps 50 --warmup 5 > $P/bench_default.json 2> $P/bench_default.err; head -c 400 $P/bench_default.json; echo
+  cd /tmp && export TMPDIR=/tmp
+  prof() {   # prof <name> <bench args...>: kernel trace + FETCH / WRITE / SQ / L2 counter passes, each its own run
+    local n=$1; shift; local CMD="python $R/bench.py $* --no-cpu-baseline --no-also --no-traffic"
+    timeout 400 rocprofv3 --kernel-trace --stats -d $P/${n}_trace -o r -- $CMD > $P/${n}_trace.log 2>&1
+    timeout 400 rocprofv3 --pmc FETCH_SIZE -d $P/${n}_pmc_fetch -o r -- $CMD > $P/${n}_pmc_fetch.log 2>&1
+    timeout 400 rocprofv3 --pmc WRITE_SIZE -d $P/${n}_pmc_write -o r -- $CMD > $P/${n}_pmc_write.log 2>&1
+    timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $P/${n}_pmc_sq -o r -- $CMD > $P/${n}_pmc_sq.log 2>&1
+    timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $P/${n}_pmc_l2 -o r -- $CMD > $P/${n}_pmc_l2.log 2>&1
+  }
+  prof w2l --steps 6 --warmup 2
+  prof w2l256 --sessions 16 --steps 3 --warmup 1
+  prof mt --model musetalk --steps 2 --warmup 1
+  prof mtfp8 --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1
+  ls $P ;;
+layers)
+  ROUNDS=${ROUNDS:-3} timeout 900 python scripts/layer_times.py "$@" 2>&1 | tee $O/layers_${TAG:-run}.txt | tail -70 ;;
+ab-lib)
+  TAG=$1; shift; LOG=$O/ab_$TAG.log; : > $LOG
+  for rnd in 1 2; do for lib in "$@"; do
+    echo "######## round $rnd lib $lib" >> $LOG
+    LTK_LIB=$R/$lib ROUNDS=3 timeout 300 python scripts/layer_times.py "TILE_RULE=1" -- ${FRAMES:-16 256} 2>&1 | grep -E "${ROWS:-^(====|sum|conv stack|face_decoder_blocks.[3-7]|face_encoder_blocks.[2-6].[01]|output)}" >> $LOG
+    if [ "${MT:-1}" != "0" ]; then
+      LTK_LIB=$R/$lib timeout 300 python scripts/mt_op_times.py 16 2>&1 | grep -E "pass|conv/linear|GroupNorm|resnets.1.conv2|resnets.1.conv1" | head -8 >> $LOG
+    fi
+  done; done
+  cat $LOG ;;
+ablate)
+  LTK_LIB=$R/ab_libs/libltk_hip_ablate.so ABLATE_SET=$1 SWEEP_FRAMES=${FRAMES:-16} ABLATE_MASKS=${MASKS:-0,1,2,3,4,7,16,64,68} timeout 900 python scripts/conv_ablate.py 2>&1 | tee $O/ablate_${TAG:-run}.txt ;;
+pmc-layer)
+  P=$O/pmc_layer; mkdir -p $P; cd /tmp; export TMPDIR=/tmp
+  export LTK_LIB=$R/ab_libs/libltk_hip_ablate.so ABLATE_MASKS=${MASKS:-0} ABLATE_SET=${SET:-big}
+  CMD="python $R/scripts/conv_ablate.py"
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $P/a -o r -- $CMD > $P/a.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_MISC -d $P/b -o r -- $CMD > $P/b.log 2>&1
+  rocprofv3 --kernel-trace -d $P/t -o r -- $CMD > $P/t.log 2>&1
+  tail -3 $P/b.log ;;
+*) echo "unknown mode $MODE"; exit 2 ;;
+esac

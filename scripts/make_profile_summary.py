@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn one scripts/gpu_profile.sh output directory (gpurun_out/<tag>) into the committed summaries under
+"""Turn one scripts/gpu_job.sh profile output directory (gpurun_out/<tag>) into the committed summaries under
 profiles/: per-kernel stats (rocprofv3 --kernel-trace --stats), per-launch timeline of one inference pass, and
 the PMC-derived HBM traffic / MFMA utilisation of the conv kernels.
 
