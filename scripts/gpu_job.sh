@@ -15,7 +15,7 @@ MODE=$1; shift
 case $MODE in
 tests)
   ARGS=${*:-tests}
-  timeout 1500 python -m pytest $ARGS -m gpu -x -q -s 2>&1 | grep -E "^\[|passed|failed|Error|error|FAIL|assert" | grep -v "^\[layer\]\|^\[mt\] [a-z_]*\.[a-z_0-9.]* " > $O/pytest_${TAG:-gpu}.log
+  timeout 1500 python -m pytest $ARGS -m gpu -x -q -s 2>&1 | grep -E "^\.*\[|passed|failed|Error|error|FAIL|assert" | grep -v "^\[layer\]\|^\[mt\] [a-z_]*\.[a-z_0-9.]* " > $O/pytest_${TAG:-gpu}.log
   tail -40 $O/pytest_${TAG:-gpu}.log ;;
 bench)
   timeout 600 python bench.py "$@" > $O/bench_${TAG:-default}.json 2> $O/bench_${TAG:-default}.err; tail -c 1500 $O/bench_${TAG:-default}.json ;;
