@@ -14,8 +14,12 @@ threads; the threads meet only before the first and after the last call.
 Default (N=1): the timed line is BASELINE.json configs[1] (wav2lip256, 1 session, 16-frame batch, fp16).  Rank 0 then
 adds, OUTSIDE the timed region (each in its own subprocess, so `ms_per_step x steps` stays what was timed):
   also[]        configs[3]'s per-GPU share (16 wav2lip sessions on one GPU, saturating and paced at 25 fps),
-                configs[2] (MuseTalk + Whisper step) and configs[4]'s per-GPU share (4 MuseTalk sessions, fp8 conv path)
-  paced         the largest number of 25-fps wav2lip sessions one GPU sustains (bisection, engine level)
+                configs[2] (MuseTalk + Whisper step) and configs[4]'s per-GPU share (4 MuseTalk sessions) in fp16 AND with the
+                fp8 conv path, each with its own PMC `roofline.traffic`
+  paced         the largest number of 25-fps wav2lip sessions one GPU sustains with the frames left on the device
+                (bisection, engine level: "kernel capacity")
+  delivered     the same with every session's 16 composited 720p frames copied to the host per period, through the plugin
+                (inference_batch + paste_back_frame, one thread per session): what a deployment can actually serve
   cpu_baseline  the reference's LipReal.inference_batch on the host cores (kind "reference" when a LiveTalking checkout
                 is importable, else the oracle port), B=16 and B=1 (configs[0]), median of 5
   roofline.traffic  HBM bytes per pass from two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) of the conv stack
@@ -47,6 +51,7 @@ MACS_PER_FRAME = 27_788_599_296       # SURVEY.md Appendix A (54 conv/convT laye
 PEAK_F16_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_FP8_TFLOPS = 5000.0              # MI355X_MICROARCH.md: dense fp8 MFMA (MX-scaled instruction)
 REF_ROOT = os.environ.get("LTK_REFERENCE", "/root/reference")
+BANK_FRAMES = 250                     # avatar bank of the bench (740 MB of 720p frames + 49 MB of face crops per GPU)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -233,7 +238,7 @@ def run_wav2lip(args, ranks: Ranks):
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=frames_per_step, device=ranks.local_rank)
     eng = model.engine
     plugin.warm_up(B, model, 256)
-    avatar = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
+    avatar = synth.wav2lip_bank(n_frames=BANK_FRAMES, full_hw=(720, 1280), box=320, seed=0)     # 250 frames, 720p, ~320-px boxes
     opt = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=0)
     sessions = []
     for s in range(S):
@@ -271,6 +276,7 @@ def run_wav2lip(args, ranks: Ranks):
     pcie = None
     if ranks.rank == 0 and S == 1:
         import numpy as np
+        from livetalking_amd.hostshim import mirror_index
         s0 = sessions[0]
         host_mel = [np.ascontiguousarray(m) for m in d_mel[0].cpu().numpy()]
         nloop = 10
@@ -280,13 +286,13 @@ def run_wav2lip(args, ranks: Ranks):
                 tp = time.perf_counter()
             pred = s0.inference_batch(it * B, host_mel)
             for i in range(B):
-                s0.paste_back_frame(pred[i], (it * B + i) % 32)
+                s0.paste_back_frame(pred[i], mirror_index(BANK_FRAMES, it * B + i))
         dtp = time.perf_counter() - tp
         h, w = avatar[0][0].shape[:2]
         pcie = {"value": round(nloop * B / dtp, 1), "unit": "frames/s", "ms_per_step": round(dtp / nloop * 1e3, 3),
                 "bytes_down_per_frame": int(h * w * 3),
                 "note": "one session thread: host mel in, inference_batch, then paste_back_frame for each of the B frames "
-                        "(composited 720p BGR frame copied to the host per call); not `value`"}
+                        "(B composites on the device, one pinned device-to-host copy per batch); not `value`"}
     drv.close()
     # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass, the head fused into the last):
     # HIP events on the engine's own streams around the conv stack only (no gather/pack), averaged over 10 passes of the
@@ -422,7 +428,7 @@ def paced_capacity(args):
     os.environ.setdefault("LTK_MICROBATCH", "256")
     eng = Engine(0)
     eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=4096)
-    frames, faces, coords = synth.wav2lip_avatar(n_frames=32, full_hw=(720, 1280), box=320, seed=0)
+    frames, faces, coords = synth.wav2lip_bank(n_frames=BANK_FRAMES, full_hw=(720, 1280), box=320, seed=0)
     aid = eng.register_avatar(faces, frames, coords)
     SMAX = 1024
     d_mel = torch.randn(B, 80, 16, dtype=torch.float32, device="cuda")
@@ -466,6 +472,99 @@ def paced_capacity(args):
             "latency_ms_at_max": round(best_lat * 1e3, 1) if best_lat is not None else None,
             "tested": [{"sessions": s, "latency_ms": l, "sustained": o} for s, l, o in tested],
             "note": "bisection in steps of 16 sessions, 3 paced periods per trial, requests of a period coalesced (engine level)"}
+
+
+def delivered_capacity(args):
+    """DELIVERABLE session capacity of one GPU, plugin level: S sessions, each with its own thread doing per 0.64-s period
+    what the reference's inference thread and process thread do for it (avatars/base_avatar.py:326-381, 383-467):
+    `inference_batch` for B frames, then `paste_back_frame` for every one of them - the composited 720p BGR frame as a host
+    array, which is what `output.push_video_frame` receives (server/webrtc.py:144-151).  A session count is sustained when
+    every session has its B host frames before the next period starts (finalfps >= 25).  Reported per count: the worst
+    period latency, frames delivered per second and session, and the device-to-host rate."""
+    import argparse as ap
+    import numpy as np
+    import torch
+    os.environ.setdefault("LTK_MICROBATCH", "256")
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd.hostshim import mirror_index
+    import synth_inputs as synth
+    B = args.batch
+    counts = [int(v) for v in (args.delivered_sessions or "16,64,128,256").split(",")]
+    model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
+    eng = model.engine
+    plugin.warm_up(B, model, 256)
+    avatar = synth.wav2lip_bank(n_frames=BANK_FRAMES, full_hw=(720, 1280), box=320, seed=0)
+    H, W = avatar[0][0].shape[:2]
+    audio = synth.synthetic_audio(4.0)
+    starts = [int(16 + i * 3.2) for i in range(B)]
+    d_mel = torch.zeros(16, B, 80, 16, dtype=torch.float32, device="cuda")
+    for s in range(16):
+        off = (s * 977) % (len(audio) - (20 + 2 * B) * 320)
+        eng.mel_step(audio[off: off + (20 + 2 * B) * 320], starts, d_mel[s].data_ptr())
+    sessions = []
+    period = B / 25.0
+    results = []
+    for S in counts:
+        while len(sessions) < S:
+            o = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=len(sessions))
+            sessions.append(plugin.LipReal(o, model, avatar))
+        periods = 4
+        go = threading.Barrier(S + 1)
+        lat = [[0.0] * periods for _ in range(S)]
+        infer_s = [0.0] * S
+        errs = []
+        t_start = [0.0]
+
+        def work(i):
+            sess = sessions[i]
+            try:
+                go.wait()
+                for p in range(periods):
+                    due = t_start[0] + p * period
+                    while time.perf_counter() < due:
+                        time.sleep(0.0005)
+                    index = (p * B + 7 * i) % (2 * BANK_FRAMES)
+                    t0 = time.perf_counter()
+                    pred = sess.inference_batch(index, d_mel[i % 16])
+                    infer_s[i] += time.perf_counter() - t0
+                    chk = 0
+                    for k in range(B):
+                        frame = sess.paste_back_frame(pred[k], mirror_index(BANK_FRAMES, index + k))
+                        chk += int(frame[0, 0, 0])            # the host array is real
+                    lat[i][p] = time.perf_counter() - due
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(S)]
+        for t in th:
+            t.start()
+        # one untimed warm-up period (pinned blocks, stream pool), then the paced periods
+        t_start[0] = time.perf_counter() + 0.05
+        go.wait()
+        for t in th:
+            t.join(timeout=120)
+        if errs:
+            results.append({"sessions": S, "error": errs[0][:200]})
+            break
+        steady = [max(l[1:]) for l in lat]                      # period 0 pays the first-use allocations
+        worst = max(steady)
+        mean_lat = float(np.mean([np.mean(l[1:]) for l in lat]))
+        ok = worst < period
+        results.append({"sessions": S, "sustained": bool(ok), "latency_ms_max": round(worst * 1e3, 1), "latency_ms_mean": round(mean_lat * 1e3, 1),
+                        "finalfps_per_session": round(B / max(period, worst), 2),
+                        "inferfps_per_session_min": round(periods * B / max(infer_s), 1),
+                        "d2h_GBps_needed": round(S * B * H * W * 3 / period / 1e9, 2),
+                        "d2h_GBps_while_busy": round(S * B * H * W * 3 / max(mean_lat, 1e-9) / 1e9, 2)})
+        if not ok:
+            break
+    for e in model.engines:
+        e.close()
+    best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
+    return {"max_sessions_25fps_delivered": best, "period_ms": period * 1e3, "frame_bytes": H * W * 3, "bank_frames": BANK_FRAMES,
+            "tested": results,
+            "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 paste_back_frame calls "
+                    "returning host 720p BGR frames (B composites on the GPU, one pinned device-to-host copy per batch); one Python "
+                    "thread per session; period 0 (first-use allocations) excluded"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -527,10 +626,12 @@ def cpu_baseline(batch: int):
             "b1": {"value": round(f1, 3), "unit": "frames/s", "sample": "same, B=1 (BASELINE.json configs[0])"}}
 
 
-def measure_traffic(args):
-    """HBM bytes per conv-stack pass from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
-    and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), KiB
-    units.  Each pass profiles `bench.py --sub convpasses` (P conv-stack passes of the same workload)."""
+def measure_traffic(sub, extra, passes, conv_only):
+    """HBM bytes per pass from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
+    SEPARATE --pmc passes (TCC slots), FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), KiB units.  Each pass
+    profiles `bench.py --sub <sub>` (`passes` timed passes + 1 warm pass of the same workload and nothing else).
+    conv_only: count the conv kernels (Wav2Lip conv stack); else every kernel of the run except the runtime's copy / fill
+    blits of the model load."""
     import glob
     import shutil
     import sqlite3
@@ -538,14 +639,13 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
-    passes = 6
     tot = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ltk_pmc_")
-        cmd = [exe, "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--sub", "convpasses",
-               "--sessions", str(args.sessions), "--batch", str(args.batch), "--steps", str(passes)]
+        cmd = [exe, "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--sub", sub,
+               "--steps", str(passes)] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         except subprocess.TimeoutExpired:
             return None, f"rocprofv3 --pmc {counter} timed out"
         dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
@@ -553,21 +653,25 @@ def measure_traffic(args):
             return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
         db = sqlite3.connect(dbs[0])
         names = [t[0] for t in db.execute("select name from sqlite_master where type in ('table','view')")]
-        view = "counters_collection" if "counters_collection" in names else None
-        if view is None:
+        if "counters_collection" not in names:
             return None, "no counters_collection view in the rocprofv3 database"
         v = 0.0
         for k, c, val in db.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
-            if c == counter and "conv" in k and "finish" not in k or (c == counter and "conv3_finish" in k):
-                v += float(val)
+            if c != counter:
+                continue
+            if conv_only and "conv" not in k:
+                continue
+            if not conv_only and ("__amd_rocclr" in k or "debug" in k):
+                continue
+            v += float(val)
         tot[counter] = v
         shutil.rmtree(d, ignore_errors=True)
-    # the sub-run executes `passes` timed passes + 1 warm pass of the conv stack and nothing else
     n = passes + 1
     rd = tot["FETCH_SIZE"] * 1024.0 * 2.0 / n
     wr = tot["WRITE_SIZE"] * 1024.0 / n
     return rd + wr, {"read_bytes": rd, "write_bytes": wr, "passes_profiled": n,
-                     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), conv kernels only, FETCH_SIZE x2 (gfx950), KiB units"}
+                     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+                               + ("conv kernels only" if conv_only else "all kernels of the pass") + ", FETCH_SIZE x2 (gfx950), KiB units"}
 
 
 def sub_convpasses(args):
@@ -577,7 +681,18 @@ def sub_convpasses(args):
     nf = min(args.sessions * args.batch, 256)
     eng = Engine(0)
     eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=nf)
-    eng.time_convs(nf, args.steps)
+    eng.time_convs(nf, args.steps)          # = 1 warm pass + `steps` passes
+    eng.close()
+
+
+def sub_mtpasses(args):
+    """Body profiled by measure_traffic: K MuseTalk passes (U-Net + VAE decoder) of min(sessions x batch, 64) frames."""
+    import synth_inputs as synth
+    from livetalking_amd.engine import Engine
+    nt = min(args.sessions * args.batch, 64)
+    eng = Engine(0)
+    eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=nt, fp8=args.fp8)
+    eng.musetalk_time(nt, args.steps)       # = 1 warm pass + `steps` passes
     eng.close()
 
 
@@ -628,22 +743,30 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,64,128,256)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.sub == "convpasses":
         return sub_convpasses(args)
+    if args.sub == "mtpasses":
+        return sub_mtpasses(args)
     if args.sub == "paced-capacity":
         print(json.dumps(paced_capacity(args)), flush=True)
+        return
+    if args.sub == "delivered-capacity":
+        print(json.dumps(delivered_capacity(args)), flush=True)
         return
     if args.sub == "musetalk-both":        # configs[2] then configs[4]'s share in one process: the synthetic weights are made once
         ranks = Ranks()
         shared = {}
         a2 = argparse.Namespace(**vars(args)); a2.sessions, a2.fp8, a2.steps, a2.warmup = 1, False, 4, 2
         o2 = run_musetalk(a2, ranks, shared)
+        a3 = argparse.Namespace(**vars(args)); a3.sessions, a3.fp8, a3.steps, a3.warmup = 4, False, 3, 1
+        o3 = run_musetalk(a3, ranks, shared)
         a4 = argparse.Namespace(**vars(args)); a4.sessions, a4.fp8, a4.steps, a4.warmup = 4, True, 3, 1
         o4 = run_musetalk(a4, ranks, shared)
-        print(json.dumps([o2, o4]), flush=True)
+        print(json.dumps([o2, o3, o4]), flush=True)
         return
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -662,26 +785,45 @@ def main():
         return
     primary = not args.sub and not args.dry_ranks
     if primary and ranks.world == 1 and args.model == "wav2lip":
+        def add_traffic(rl, sub, extra, passes, conv_only, what):
+            traffic, info = measure_traffic(sub, extra, passes, conv_only)
+            rl["traffic"] = traffic
+            rl["traffic_unit"] = what
+            rl["traffic_info"] = info
+
         if not args.no_traffic:
-            traffic, info = measure_traffic(args)
-            out["roofline"]["traffic"] = traffic
-            out["roofline"]["traffic_unit"] = "HBM bytes per conv-stack pass"
-            out["roofline"]["traffic_info"] = info
+            add_traffic(out["roofline"], "convpasses", ["--sessions", str(args.sessions), "--batch", str(args.batch)], 6, True,
+                        "HBM bytes per conv-stack pass")
         if not args.no_also:
             mt = run_sub("musetalk-both", ["--batch", str(args.batch)])
             also = [run_sub("also-w2l16", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "3", "--paced", "4"])]
             also += mt if isinstance(mt, list) else [mt]
             tags = ["configs[3] per-GPU share: 16 wav2lip256 sessions on one GPU (16 session threads, continuous batching)",
-                    "configs[2]: MuseTalk, 1 session", "configs[4] per-GPU share: 4 MuseTalk sessions, fp8 conv path"]
+                    "configs[2]: MuseTalk, 1 session",
+                    "configs[4] per-GPU share WITHOUT fp8: 4 MuseTalk sessions, fp16 (the like-for-like partner of the next entry)",
+                    "configs[4] per-GPU share: 4 MuseTalk sessions, fp8 conv path"]
             for a, t in zip(also, tags):
                 if isinstance(a, dict):
                     a["baseline_config"] = t
+            if not args.no_traffic:          # HBM bytes of the other BASELINE shares (each two short rocprofv3 --pmc runs)
+                subs = [("convpasses", ["--sessions", "16", "--batch", str(args.batch)], 3, True, "HBM bytes per 256-frame conv-stack pass"),
+                        ("mtpasses", ["--sessions", "1", "--batch", str(args.batch)], 2, False, "HBM bytes per 16-frame MuseTalk pass"),
+                        None,
+                        ("mtpasses", ["--sessions", "4", "--batch", str(args.batch), "--fp8"], 1, False, "HBM bytes per 64-frame MuseTalk pass")]
+                for a, sb in zip(also, subs):
+                    if sb is not None and isinstance(a, dict) and isinstance(a.get("roofline"), dict):
+                        add_traffic(a["roofline"], *sb)
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
+            out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
             w16 = also[0] if isinstance(also[0], dict) else {}
-            out["sessions_25fps"] = {"per_gpu_sustained": out["paced"].get("max_sessions_25fps"),
+            out["sessions_25fps"] = {"per_gpu_delivered": out["delivered"].get("max_sessions_25fps_delivered"),
+                                     "per_gpu_kernel_capacity": out["paced"].get("max_sessions_25fps"),
                                      "at_16_sessions_per_gpu": w16.get("paced"),
-                                     "note": "per_gpu_sustained: paced bisection (engine level); at_16_sessions_per_gpu: 16 paced session threads through LipReal.inference_batch"}
+                                     "note": "per_gpu_delivered: plugin level, every session gets its 16 composited 720p frames on the host per "
+                                             "period (inference_batch + paste_back_frame, one thread per session); per_gpu_kernel_capacity: "
+                                             "engine level, frames stay on the device (paced bisection); at_16_sessions_per_gpu: 16 paced "
+                                             "session threads through LipReal.inference_batch"}
     if primary and ranks.world == 1 and not args.no_cpu_baseline:         # the CPU baseline is timed at N=1 only
         out["cpu_baseline"] = cpu_baseline(args.batch) if args.model == "wav2lip" else cpu_baseline_musetalk()
     print(json.dumps(out), flush=True)

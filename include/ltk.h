@@ -102,6 +102,13 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
 int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, void* out,
                    int out_is_device, void* stream);
 
+/* The same composite for the `n` frames of one inference_batch result at once (the process thread of
+ * avatars/base_avatar.py:383-467 calls paste_back_frame once per frame, in order, for the items inference_batch returned):
+ * d_pred = n contiguous device uint8 [256][256][3] predictions, idx[i] = bank frame of prediction i, out = HOST uint8
+ * [n][H][W][3] - pinned memory moves at the PCIe rate.  n composites on the device, ONE device-to-host copy, one
+ * synchronisation (per frame: ltk_paste_back costs a 2.76 MB pageable copy and a stream synchronisation each). */
+int ltk_paste_back_batch(ltk_engine* e, int avatar_id, const int32_t* idx, const void* d_pred, int n, void* out, void* stream);
+
 /* =========================== MuseTalk path (avatars/musetalk_avatar.py) =========================== */
 
 /* avatars/musetalk_avatar.py:57-67 load_model + avatars/musetalk/utils/utils.py:16-37 load_all_model: the

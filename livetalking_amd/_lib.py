@@ -51,6 +51,7 @@ SYMBOLS = {
     "ltk_mel_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_wav2lip_infer": (C.c_int, [C.c_void_p, C.POINTER(W2lReq), C.c_int, C.c_void_p]),
     "ltk_paste_back": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ltk_paste_back_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_musetalk_load": (C.c_int, [C.c_void_p, C.POINTER(NamedTensor), C.c_int, C.POINTER(NamedTensor), C.c_int, C.c_int]),
     "ltk_musetalk_set_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "ltk_musetalk_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -32,6 +32,17 @@ from ..scheduler import get_scheduler
 from ..sharding import EnginePool, visible_devices
 from .audio_features.mel import MelASR
 
+_PASTE_BATCH = os.environ.get("LTK_PASTE_BATCH", "1") != "0"     # 0: one composite + one pageable copy per paste_back_frame call
+
+
+class _PasteGroup:
+    """The B predictions of one inference_batch call and their bank frames, shared by the B items it returned."""
+    __slots__ = ("pred", "idx", "host", "lock")
+
+    def __init__(self, pred, idx):
+        self.pred, self.idx, self.host, self.lock = pred, idx, None, threading.Lock()
+
+
 class Wav2LipModel:
     """Opaque `model` object handed back to app.py; process-global, shared by sessions (app.py:62-63).  Owns one engine
     per GPU (sharding.EnginePool); a session is pinned to one of them when it is constructed."""
@@ -162,7 +173,15 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
         pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=mel.device)
         self._sched.infer(self._aid, int(index), B, mel.data_ptr(), pred.data_ptr())
         self._last_mel = mel            # keep inputs alive until the call returned (it has)
-        return [pred[i] for i in range(B)]
+        items = [pred[i] for i in range(B)]
+        if _PASTE_BATCH and hasattr(self.engine, "paste_back_batch"):
+            # the process thread will ask for these B composites one by one, in order (base_avatar.py:429-433): remember
+            # the batch so that the FIRST request composites all of them and moves them to the host in one copy
+            n = len(self.frame_list_cycle)
+            grp = _PasteGroup(pred, [mirror_index(n, int(index) + i) for i in range(B)])
+            for i, it in enumerate(items):
+                it._ltk_group, it._ltk_i = grp, i
+        return items
 
     def paste_back_frame(self, pred_frame, idx: int):
         import torch
@@ -170,6 +189,19 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
                 self.engine.torch_device)
         h, w = self._frame_hw
+        grp = getattr(pred_frame, "_ltk_group", None)
+        if grp is not None and grp.idx[pred_frame._ltk_i] == int(idx):
+            with grp.lock:
+                if grp.host is None:
+                    # one pinned host block per batch: n composites on the GPU, ONE device-to-host copy at the PCIe rate.
+                    # The returned frames are views of it; the block lives as long as any of them does (numpy base ->
+                    # tensor -> torch's caching pinned allocator), so a consumer may keep or draw on a frame for as long
+                    # as it likes - the reference's contract (a writable C-contiguous array the caller owns).
+                    host = torch.empty((len(grp.idx), h, w, 3), dtype=torch.uint8, pin_memory=True)
+                    self.engine.paste_back_batch(self._aid, grp.idx, grp.pred.data_ptr(), host.data_ptr())
+                    grp.host = host.numpy()
+                    grp.pred = None             # the device predictions are no longer needed
+            return grp.host[pred_frame._ltk_i]
         out = np.empty((h, w, 3), dtype=np.uint8)
         self.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)
         return out

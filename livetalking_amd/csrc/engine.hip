@@ -911,6 +911,34 @@ int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, vo
     return LTK_OK;
 }
 
+int ltk_paste_back_batch(ltk_engine* e, int avatar_id, const int32_t* idx, const void* d_pred, int n, void* out, void* stream) {
+    if (!e || !idx || !d_pred || !out || n <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    std::shared_ptr<Avatar> ap;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        auto it = e->avatars.find(avatar_id);
+        if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+        ap = it->second;
+    }
+    const Avatar& a = *ap;
+    for (int i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
+    CHK(hipSetDevice(e->device));
+    const size_t bytes = (size_t)a.H * a.W * 3;
+    StreamLease sl(e, stream);
+    ScratchLease sc(e, bytes * n);
+    if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
+    for (int i = 0; i < n; ++i) {
+        const int32_t* c = a.coords.data() + 4 * (size_t)idx[i];
+        launch_paste(a.d_full + (size_t)idx[i] * bytes, a.H, a.W, (const uint8_t*)d_pred + (size_t)i * 256 * 256 * 3, c[0], c[1], c[2], c[3],
+                     (uint8_t*)sc.s.d + (size_t)i * bytes, sl.s);
+    }
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(out, sc.s.d, bytes * n, hipMemcpyDeviceToHost, sl.s));
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
 // ------------------------------------------------------------------ test / measurement hooks
 namespace {
 struct DevBuf {                     // device scratch of a host-side hook: freed on every return path

@@ -144,6 +144,13 @@ class Engine:
         _lib.check(self._lib.ltk_paste_back(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr),
                                             out.ctypes.data, 0, C.c_void_p(stream)))
 
+    def paste_back_batch(self, avatar_id: int, idx: Sequence[int], d_pred_ptr: int, out_ptr: int, stream: int = 0):
+        """n = len(idx) composites (n contiguous device predictions) into host memory at out_ptr [n][H][W][3] (pinned for
+        the PCIe rate): one device-to-host copy, one synchronisation (include/ltk.h: ltk_paste_back_batch)."""
+        arr = np.ascontiguousarray(np.asarray(idx, dtype=np.int32))
+        _lib.check(self._lib.ltk_paste_back_batch(self._h, int(avatar_id), arr.ctypes.data, C.c_void_p(d_pred_ptr), int(arr.size),
+                                                  C.c_void_p(out_ptr), C.c_void_p(stream)))
+
     def paste_back_device(self, avatar_id: int, idx: int, d_pred_ptr: int, d_out_ptr: int, stream: int = 0):
         _lib.check(self._lib.ltk_paste_back(self._h, int(avatar_id), int(idx), C.c_void_p(d_pred_ptr),
                                             C.c_void_p(d_out_ptr), 1, C.c_void_p(stream)))

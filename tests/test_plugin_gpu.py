@@ -162,3 +162,44 @@ def test_two_engines_two_sessions_render_concurrently(monkeypatch):
     assert s0._sched.stats["calls"] == 3 and s1._sched.stats["calls"] == 3 and s0._sched is not s1._sched
     for e in model.engines:
         e.close()
+
+
+@pytest.mark.gpu
+def test_paste_back_batch_equals_per_frame_and_frames_stay_valid():
+    """LipReal.paste_back_frame through the batch path (B composites on the device + ONE pinned device-to-host copy on the first
+    request of a batch: ltk_paste_back_batch) returns, frame by frame, exactly what the per-frame entry point returns, the
+    arrays are writable C-contiguous (H,W,3) uint8 as base_avatar.py:449-452 needs, and a frame the caller keeps (or draws on)
+    is not touched by later batches."""
+    import argparse
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    B = 6
+    model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=B, device=0)
+    try:
+        avatar = synth.wav2lip_avatar(n_frames=4, full_hw=(360, 640), box=160, seed=0)
+        opt = argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=0)
+        sess = plugin.LipReal(opt, model, avatar)
+        feat = torch.from_numpy(np.random.default_rng(3).standard_normal((B, 80, 16)).astype(np.float32)).cuda()
+        index = 2                                       # bank frames 2,3,3,2,1,0: across the ping-pong turn
+        items = sess.inference_batch(index, feat)
+        got = [sess.paste_back_frame(items[i], plugin.mirror_index(4, index + i)) for i in range(B)]
+        for i in range(B):
+            ref = np.empty((360, 640, 3), np.uint8)
+            sess.engine.paste_back(sess._aid, plugin.mirror_index(4, index + i), items[i].data_ptr(), ref)
+            assert got[i].dtype == np.uint8 and got[i].shape == (360, 640, 3) and got[i].flags["C_CONTIGUOUS"] and got[i].flags["WRITEABLE"]
+            assert np.array_equal(got[i], ref), i
+        keep = got[1].copy()
+        got[2][:40, :200] = 7                           # the caller draws on ITS frame (cv2.putText in the reference)
+        for step in range(3):                           # later batches allocate / reuse pinned blocks
+            more = sess.inference_batch(index + (step + 1) * B, feat)
+            [sess.paste_back_frame(more[i], plugin.mirror_index(4, index + (step + 1) * B + i)) for i in range(B)]
+        assert np.array_equal(got[1], keep) and (got[2][:40, :200] == 7).all()
+        # an index that is not the batch's own falls back to the per-frame path and still composites the asked frame
+        other = sess.paste_back_frame(items[0], 0)
+        ref0 = np.empty((360, 640, 3), np.uint8)
+        sess.engine.paste_back(sess._aid, 0, items[0].data_ptr(), ref0)
+        assert np.array_equal(other, ref0)
+    finally:
+        for e in model.engines:
+            e.close()
