@@ -489,7 +489,7 @@ def delivered_capacity(args):
     from livetalking_amd.hostshim import mirror_index
     import synth_inputs as synth
     B = args.batch
-    counts = [int(v) for v in (args.delivered_sessions or "16,64,128,256").split(",")]
+    counts = [int(v) for v in (args.delivered_sessions or "16,64,128,256,384").split(",")]
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
     eng = model.engine
     plugin.warm_up(B, model, 256)
@@ -743,7 +743,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
-    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,64,128,256)")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,64,128,256,384)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

@@ -5,7 +5,7 @@
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/livetalking_amd/csrc
+SRC=${SRC:-$ROOT/livetalking_amd/csrc}
 OBJ=$ROOT/build/$NAME
 mkdir -p $OBJ $ROOT/ab_libs
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"

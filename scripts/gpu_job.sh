@@ -31,10 +31,21 @@ profile)
     timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $P/${n}_pmc_sq -o r -- $CMD > $P/${n}_pmc_sq.log 2>&1
     timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $P/${n}_pmc_l2 -o r -- $CMD > $P/${n}_pmc_l2.log 2>&1
   }
+  # MuseTalk twice: the weight upload of the model load shows up as ~1100 __amd_rocclr_copyBuffer / ~470 fillBufferAligned launches
+  # whatever the number of passes (mt: 3 passes, mt12: 12 passes) - they are not part of a pass
   prof w2l --steps 6 --warmup 2
   prof w2l256 --sessions 16 --steps 3 --warmup 1
   prof mt --model musetalk --steps 2 --warmup 1
   prof mtfp8 --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $P/mt12_trace -o r -- python $R/bench.py --model musetalk --steps 11 --warmup 1 --no-cpu-baseline > $P/mt12_trace.log 2>&1
+  cd $R; S=$O/${TAG}_summary; mkdir -p $S
+  python scripts/make_profile_summary.py $P $S/$TAG --name w2l --frames 16 --cmd "bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic  (wav2lip256, 1 session, 16-frame batch)" > /dev/null
+  python scripts/make_profile_summary.py $P $S/$TAG --name w2l256 --frames 256 --cmd "bench.py --sessions 16 --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-traffic  (16 sessions, 256-frame passes)" > /dev/null
+  python scripts/make_profile_summary.py $P $S/$TAG --name mt --all-kernels --frames 16 --cmd "bench.py --model musetalk --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
+  python scripts/make_profile_summary.py $P $S/$TAG --name mtfp8 --all-kernels --frames 64 --cmd "bench.py --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
+  python scripts/prof_report.py $P/mt12_trace 2>/dev/null | grep -E "^kernel|amd_rocclr|gn_|conv3_kernel<1, 2, 4" | head -12 > $S/${TAG}_mt12_blits.txt
+  cp $P/bench_default.json $S/${TAG}_bench_default.json
+  rm -rf $P
   ls $P ;;
 layers)
   ROUNDS=${ROUNDS:-3} timeout 900 python scripts/layer_times.py "$@" 2>&1 | tee $O/layers_${TAG:-run}.txt | tail -70 ;;

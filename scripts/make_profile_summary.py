@@ -3,7 +3,10 @@
 profiles/: per-kernel stats (rocprofv3 --kernel-trace --stats), per-launch timeline of one inference pass, and
 the PMC-derived HBM traffic / MFMA utilisation of the conv kernels.
 
-    python scripts/make_profile_summary.py gpurun_out/r01 profiles/r01 [--passes 19]
+    python scripts/make_profile_summary.py gpurun_out/r03 profiles/r03 --name w2l --cmd "bench.py --steps 6 --warmup 2" [--all-kernels]
+
+`--name` selects the workload's sub-directories (<name>_trace, <name>_pmc_fetch, ...) that `gpu_job.sh profile` writes; the outputs
+are <dst_prefix>_<name>_kernel_stats.csv, _pmc.json, _pmc_per_kernel.csv (and _pass_timeline.txt for the Wav2Lip workloads).
 
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
 the bytes of a wide coalesced stream (TCC_EA0_RDREQ tallied at 64 B for 128-B requests), so reads are doubled;
@@ -36,11 +39,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst_prefix")
-    ap.add_argument("--passes", type=int, default=19, help="conv-stack passes in the profiled command (8 inference + 11 timing)")
+    ap.add_argument("--passes", type=int, default=0, help="passes in the profiled command; 0 = counted from the trace (Wav2Lip: launches of the fused "
+                                                           "head kernel = one per pass; MuseTalk: gn_apply launches / 91)")
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--name", default="", help="workload prefix of the sub-directories (w2l, w2l256, mt, mtfp8); empty = round-2 layout")
+    ap.add_argument("--cmd", default="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic", help="the profiled command (for the headers)")
+    ap.add_argument("--all-kernels", action="store_true", help="PMC sums over every kernel of the run except the runtime's copy / fill blits (MuseTalk)")
     a = ap.parse_args()
+    sub = (lambda d: os.path.join(a.src, f"{a.name}_{d}")) if a.name else (lambda d: os.path.join(a.src, d))
+    if a.name:
+        a.dst_prefix = f"{a.dst_prefix}_{a.name}"
     os.makedirs(os.path.dirname(a.dst_prefix) or ".", exist_ok=True)
-    db = sqlite3.connect(os.path.join(a.src, "trace", "r_results.db"))
+    db = sqlite3.connect(os.path.join(sub("trace"), "r_results.db"))
     rows = db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, stream_id from kernels order by start").fetchall()
     stats = collections.OrderedDict()
     for r in rows:
@@ -48,8 +58,12 @@ def main():
         d = (r[2] - r[1]) / 1e3
         s[0] += 1; s[1] += d; s[2] = min(s[2], d); s[3] = max(s[3], d)
     tot = sum(s[1] for s in stats.values())
+    if a.passes <= 0:
+        heads = sum(v[0] for k, v in stats.items() if "conv3_head_kernel" in k)
+        gn = sum(v[0] for k, v in stats.items() if "gn_apply_kernel" in k)
+        a.passes = heads if heads else max(1, gn // 91)
     with open(a.dst_prefix + "_kernel_stats.csv", "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic  (wav2lip256, 1 session, 16-frame batch)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python {a.cmd}\n")
         f.write("kernel,calls,total_us,avg_us,min_us,max_us,pct,vgpr,sgpr\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1]):
             f.write(f"\"{k}\",{s[0]},{s[1]:.1f},{s[1]/s[0]:.2f},{s[2]:.2f},{s[3]:.2f},{100*s[1]/tot:.2f},{s[4]},{s[5]}\n")
@@ -72,20 +86,26 @@ def main():
                     f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us; {nlaunch} launches\n")
                     break
 
-    fetch = counters(os.path.join(a.src, "pmc_fetch", "r_results.db"))
-    write = counters(os.path.join(a.src, "pmc_write", "r_results.db"))
-    sq = counters(os.path.join(a.src, "pmc_sq", "r_results.db"))
-    l2 = counters(os.path.join(a.src, "pmc_l2", "r_results.db"))
-    conv = [k for k in stats if k.startswith("conv")]
+    fetch = counters(os.path.join(sub("pmc_fetch"), "r_results.db"))
+    write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
+    sq = counters(os.path.join(sub("pmc_sq"), "r_results.db"))
+    l2 = counters(os.path.join(sub("pmc_l2"), "r_results.db"))
+    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else k.startswith("conv"))]
+    blits = {k: stats[k][0] for k in stats if "__amd_rocclr" in k}
     rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
     wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024
     mfma = sum(sq.get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0] for k in conv)
     gui = sum(l2.get(k, {}).get("GRBM_GUI_ACTIVE", (0, 0))[0] for k in conv)       # summed over the 8 XCDs
     hit = sum(l2.get(k, {}).get("TCC_HIT_sum", (0, 0))[0] for k in conv)
     miss = sum(l2.get(k, {}).get("TCC_MISS_sum", (0, 0))[0] for k in conv)
+    wave = sum(sq.get(k, {}).get("SQ_WAVE_CYCLES", (0, 0))[0] for k in conv)
     summary = {
-        "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic",
-        "conv_passes_in_run": a.passes,
+        "command": "python " + a.cmd,
+        "kernels_counted": "all kernels of the run except the runtime's copy / fill blits" if a.all_kernels else "conv kernels",
+        "runtime_blit_launches_in_run": blits,
+        "passes_in_run": a.passes,
+        "passes_note": "one pass = one launch sequence (<= one arena of frames); with session threads the coalesced calls differ in size, so "
+                       "per-pass figures of a multi-session run are averages - bench.py's own roofline.traffic (fixed-size passes) is the reference figure",
         "frames_per_pass": a.frames,
         "hbm_read_bytes_per_pass": rd / a.passes,
         "hbm_write_bytes_per_pass": wr / a.passes,
@@ -96,6 +116,8 @@ def main():
         "mfma_util_conv_kernels": (mfma / 1024.0) / (gui / 8.0) if gui else None,
         "l2_hit_rate_conv_kernels": hit / (hit + miss) if hit + miss else None,
         "conv_kernel_us_last_pass": conv_us,
+        "wave_cycles_split": {c: (sum(sq.get(k, {}).get(c, (0, 0))[0] for k in conv) / wave if wave else None)
+                              for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")},
     }
     with open(a.dst_prefix + "_pmc.json", "w") as f:
         json.dump(summary, f, indent=1)
