@@ -19,7 +19,8 @@ adds, OUTSIDE the timed region (each in its own subprocess, so `ms_per_step x st
   paced         the largest number of 25-fps wav2lip sessions one GPU sustains with the frames left on the device
                 (bisection, engine level: "kernel capacity")
   delivered     the same with every session's 16 composited 720p frames copied to the host per period, through the plugin
-                (inference_batch + paste_back_frame, one thread per session): what a deployment can actually serve
+                (inference_batch + paste_back_frame, one thread per session): what a deployment can actually serve;
+                delivered_i420: through the plugin's opt.egress = i420 path (composite + watermark + BGR->I420 on the GPU)
   cpu_baseline  the reference's LipReal.inference_batch on the host cores (kind "reference" when a LiveTalking checkout
                 is importable, else the oracle port), B=16 and B=1 (configs[0]), median of 5
   roofline.traffic  HBM bytes per pass from two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) of the conv stack
@@ -489,7 +490,8 @@ def delivered_capacity(args):
     from livetalking_amd.hostshim import mirror_index
     import synth_inputs as synth
     B = args.batch
-    counts = [int(v) for v in (args.delivered_sessions or "16,64,128,256,384").split(",")]
+    egress_fmt = args.egress if args.egress in ("bgr24", "i420") else ""
+    counts = [int(v) for v in (args.delivered_sessions or ("256,384,512" if egress_fmt == "i420" else "16,128,256,384")).split(",")]
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
     eng = model.engine
     plugin.warm_up(B, model, 256)
@@ -501,13 +503,17 @@ def delivered_capacity(args):
     for s in range(16):
         off = (s * 977) % (len(audio) - (20 + 2 * B) * 320)
         eng.mel_step(audio[off: off + (20 + 2 * B) * 320], starts, d_mel[s].data_ptr())
-    sessions = []
+    sessions, egs = [], []
     period = B / 25.0
     results = []
+    frame_bytes = H * W * 3 // 2 if egress_fmt == "i420" else H * W * 3
     for S in counts:
         while len(sessions) < S:
             o = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=len(sessions))
             sessions.append(plugin.LipReal(o, model, avatar))
+            if egress_fmt:                     # opt.egress: device-side process_frames (egress.py) - composite + watermark + format on the GPU
+                sessions[-1].opt.egress = egress_fmt
+                egs.append(sessions[-1]._make_egress())
         periods = 4
         go = threading.Barrier(S + 1)
         lat = [[0.0] * periods for _ in range(S)]
@@ -529,8 +535,12 @@ def delivered_capacity(args):
                     infer_s[i] += time.perf_counter() - t0
                     chk = 0
                     for k in range(B):
-                        frame = sess.paste_back_frame(pred[k], mirror_index(BANK_FRAMES, index + k))
-                        chk += int(frame[0, 0, 0])            # the host array is real
+                        if egress_fmt:
+                            frame = egs[i].speaking_frame_of(pred[k], mirror_index(BANK_FRAMES, index + k))
+                            chk += int(frame.reshape(-1)[0])
+                        else:
+                            frame = sess.paste_back_frame(pred[k], mirror_index(BANK_FRAMES, index + k))
+                            chk += int(frame[0, 0, 0])        # the host array is real
                     lat[i][p] = time.perf_counter() - due
             except Exception as ex:  # noqa: BLE001
                 errs.append(repr(ex))
@@ -553,15 +563,17 @@ def delivered_capacity(args):
         results.append({"sessions": S, "sustained": bool(ok), "latency_ms_max": round(worst * 1e3, 1), "latency_ms_mean": round(mean_lat * 1e3, 1),
                         "finalfps_per_session": round(B / max(period, worst), 2),
                         "inferfps_per_session_min": round(periods * B / max(infer_s), 1),
-                        "d2h_GBps_needed": round(S * B * H * W * 3 / period / 1e9, 2),
-                        "d2h_GBps_while_busy": round(S * B * H * W * 3 / max(mean_lat, 1e-9) / 1e9, 2)})
+                        "d2h_GBps_needed": round(S * B * frame_bytes / period / 1e9, 2),
+                        "d2h_GBps_while_busy": round(S * B * frame_bytes / max(mean_lat, 1e-9) / 1e9, 2)})
         if not ok:
             break
+    for g in egs:
+        g.close()
     for e in model.engines:
         e.close()
     best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
-    return {"max_sessions_25fps_delivered": best, "period_ms": period * 1e3, "frame_bytes": H * W * 3, "bank_frames": BANK_FRAMES,
-            "tested": results,
+    return {"max_sessions_25fps_delivered": best, "period_ms": period * 1e3, "frame_format": egress_fmt or "bgr24 (paste_back_frame)",
+            "frame_bytes": frame_bytes, "bank_frames": BANK_FRAMES, "tested": results,
             "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 paste_back_frame calls "
                     "returning host 720p BGR frames (B composites on the GPU, one pinned device-to-host copy per batch); one Python "
                     "thread per session; period 0 (first-use allocations) excluded"}
@@ -743,7 +755,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
-    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,64,128,256,384)")
+    ap.add_argument("--egress", default="", help="delivered-capacity run: bgr24 | i420 = frames through the device egress path "
+                    "(opt.egress of the plugin: composite + watermark + format conversion on the GPU) instead of paste_back_frame")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,128,256,384; with --egress i420: 256,384,512)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -816,12 +830,15 @@ def main():
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
             out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
+            out["delivered_i420"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--egress", "i420"])
             w16 = also[0] if isinstance(also[0], dict) else {}
             out["sessions_25fps"] = {"per_gpu_delivered": out["delivered"].get("max_sessions_25fps_delivered"),
+                                     "per_gpu_delivered_i420": out["delivered_i420"].get("max_sessions_25fps_delivered"),
                                      "per_gpu_kernel_capacity": out["paced"].get("max_sessions_25fps"),
                                      "at_16_sessions_per_gpu": w16.get("paced"),
                                      "note": "per_gpu_delivered: plugin level, every session gets its 16 composited 720p frames on the host per "
-                                             "period (inference_batch + paste_back_frame, one thread per session); per_gpu_kernel_capacity: "
+                                             "period (inference_batch + paste_back_frame, one thread per session); per_gpu_delivered_i420: the same "
+                                             "through the plugin's opt.egress = i420 path (watermarked I420 frames, half the PCIe bytes); per_gpu_kernel_capacity: "
                                              "engine level, frames stay on the device (paced bisection); at_16_sessions_per_gpu: 16 paced "
                                              "session threads through LipReal.inference_batch"}
     if primary and ranks.world == 1 and not args.no_cpu_baseline:         # the CPU baseline is timed at N=1 only

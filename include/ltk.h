@@ -191,6 +191,16 @@ typedef struct ltk_egress_req {
 /* h_out: host uint8, H*W*3 bytes (BGR24) or H*W*3/2 bytes (I420); returns after the copy completed. */
 int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* req, uint8_t* h_out, void* stream);
 
+/* The speaking frames of ONE inference_batch result at once, for sessions without the transition effect (the reference's
+ * default, base_avatar.py:384 enable_transition = False): n composites (ltk_paste_back / ltk_paste_blend of prediction i onto
+ * bank frame idx[i]), watermark and format conversion on the device, ONE device-to-host copy into `h_out`
+ * ([n][H][W][3] for LTK_FMT_BGR24, [n][H*3/2][W] for LTK_FMT_I420; pinned memory moves at the PCIe rate) and one
+ * synchronisation.  With I420 a 25-fps 720p session costs 35 MB/s of PCIe instead of 69: the link, not the GPU, bounds
+ * how many sessions a GPU can serve (bench.py `delivered`).  source: LTK_SRC_WAV2LIP or LTK_SRC_MUSETALK; d_pred: n
+ * contiguous device uint8 [256][256][3] predictions.  The session's transition caches are neither read nor written. */
+int ltk_egress_batch(ltk_engine* e, ltk_egress* s, int source, int avatar, const int32_t* idx, const void* d_pred, int n, int format,
+                     int chroma, uint8_t* h_out, void* stream);
+
 /* avatars/musetalk/whisper/audio2feature.py:15-23 Audio2Feature.__init__: the Whisper-tiny ENCODER
  * (transformers WhisperModel(...).encoder.state_dict(): conv1, conv2, embed_positions, layers.{0..3}.*, layer_norm),
  * fp32 host tensors.  The WhisperFeatureExtractor constants (n_fft 400, hop 160, 80 slaney mels, 30-s padding) are

@@ -63,6 +63,8 @@ SYMBOLS = {
     "ltk_egress_close": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ltk_egress_watermark": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ltk_egress_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(EgressReq), C.c_void_p, C.c_void_p]),
+    "ltk_egress_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
     "ltk_musetalk_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ltk_musetalk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "ltk_musetalk_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),

@@ -22,9 +22,9 @@ import weakref
 
 import numpy as np
 
-from ..egress import SRC_MUSETALK, DeviceEgressMixin
+from ..egress import SRC_MUSETALK, DeviceEgressMixin, FrameGroup
 from ..engine import Engine
-from ..hostshim import BaseAvatar, register
+from ..hostshim import BaseAvatar, mirror_index, register
 from ..scheduler import get_scheduler
 from ..sharding import EnginePool, visible_devices
 from .audio_features.whisper import Audio2Feature, WhisperASR
@@ -199,7 +199,11 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
             raise ValueError(f"expected {B} whisper chunks, got {feat.shape[0]}")
         pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=dev)
         self._sched.infer(self._aid, int(index), B, feat.data_ptr(), pred.data_ptr())
-        return [pred[i] for i in range(B)]
+        items = [pred[i] for i in range(B)]
+        if hasattr(self.engine, "egress_batch"):        # opt.egress sessions convert the batch's frames in one go (egress.py)
+            n = len(self.frame_list_cycle)
+            FrameGroup.attach(items, pred, [mirror_index(n, int(index) + i) for i in range(B)])
+        return items
 
     def paste_back_frame(self, pred_frame, idx: int):
         import torch

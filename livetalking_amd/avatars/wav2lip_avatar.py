@@ -25,7 +25,7 @@ import weakref
 
 import numpy as np
 
-from ..egress import SRC_WAV2LIP, DeviceEgressMixin
+from ..egress import SRC_WAV2LIP, DeviceEgressMixin, FrameGroup
 from ..engine import Engine
 from ..hostshim import BaseAvatar, mirror_index, register
 from ..scheduler import get_scheduler
@@ -33,14 +33,6 @@ from ..sharding import EnginePool, visible_devices
 from .audio_features.mel import MelASR
 
 _PASTE_BATCH = os.environ.get("LTK_PASTE_BATCH", "1") != "0"     # 0: one composite + one pageable copy per paste_back_frame call
-
-
-class _PasteGroup:
-    """The B predictions of one inference_batch call and their bank frames, shared by the B items it returned."""
-    __slots__ = ("pred", "idx", "host", "lock")
-
-    def __init__(self, pred, idx):
-        self.pred, self.idx, self.host, self.lock = pred, idx, None, threading.Lock()
 
 
 class Wav2LipModel:
@@ -178,9 +170,7 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
             # the process thread will ask for these B composites one by one, in order (base_avatar.py:429-433): remember
             # the batch so that the FIRST request composites all of them and moves them to the host in one copy
             n = len(self.frame_list_cycle)
-            grp = _PasteGroup(pred, [mirror_index(n, int(index) + i) for i in range(B)])
-            for i, it in enumerate(items):
-                it._ltk_group, it._ltk_i = grp, i
+            FrameGroup.attach(items, pred, [mirror_index(n, int(index) + i) for i in range(B)])
         return items
 
     def paste_back_frame(self, pred_frame, idx: int):
@@ -200,7 +190,6 @@ class LipReal(DeviceEgressMixin, BaseAvatar):
                     host = torch.empty((len(grp.idx), h, w, 3), dtype=torch.uint8, pin_memory=True)
                     self.engine.paste_back_batch(self._aid, grp.idx, grp.pred.data_ptr(), host.data_ptr())
                     grp.host = host.numpy()
-                    grp.pred = None             # the device predictions are no longer needed
             return grp.host[pred_frame._ltk_i]
         out = np.empty((h, w, 3), dtype=np.uint8)
         self.engine.paste_back(self._aid, int(idx), pred_frame.data_ptr(), out)

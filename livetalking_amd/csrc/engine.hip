@@ -1515,6 +1515,63 @@ int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* q, uint
     return LTK_OK;
 }
 
+int ltk_egress_batch(ltk_engine* e, ltk_egress* s, int source, int avatar, const int32_t* idx, const void* d_pred, int n, int format,
+                     int chroma, uint8_t* h_out, void* stream) {
+    if (!e || !s || !idx || !d_pred || !h_out || n <= 0) return fail(LTK_E_INVALID, "bad arguments");
+    const int H = s->H, W = s->W;
+    const size_t bytes = (size_t)H * W * 3;
+    if (format != LTK_FMT_BGR24 && format != LTK_FMT_I420) return fail(LTK_E_INVALID, "unknown output format");
+    if (format == LTK_FMT_I420 && ((H | W) & 1)) return fail(LTK_E_INVALID, "I420 needs even frame dimensions");
+    if (source != LTK_SRC_WAV2LIP && source != LTK_SRC_MUSETALK) return fail(LTK_E_INVALID, "batch egress: Wav2Lip or MuseTalk frames only");
+    CHK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> gs(s->mu);
+    std::shared_ptr<Avatar> hold_w;           // keep the bank alive until the stream has been synchronised below
+    std::shared_ptr<MtAvatar> hold_m;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        if (source == LTK_SRC_WAV2LIP) {
+            auto it = e->avatars.find(avatar);
+            if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+            hold_w = it->second;
+        } else {
+            auto it = e->mt_avatars.find(avatar);
+            if (it == e->mt_avatars.end()) return fail(LTK_E_STATE, "unknown MuseTalk avatar id");
+            hold_m = it->second;
+        }
+    }
+    const int bank_n = hold_w ? hold_w->n : hold_m->n, bank_h = hold_w ? hold_w->H : hold_m->H, bank_w = hold_w ? hold_w->W : hold_m->W;
+    if (bank_h != H || bank_w != W) return fail(LTK_E_INVALID, "avatar frame size differs from the egress session");
+    for (int i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= bank_n) return fail(LTK_E_INVALID, "frame index outside the bank");
+    const size_t out_bytes = format == LTK_FMT_I420 ? bytes / 2 : bytes;
+    StreamLease sl(e, stream);
+    ScratchLease sc(e, (bytes + out_bytes) * n);           // [n composites][n converted frames]
+    if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
+    uint8_t* const comp = (uint8_t*)sc.s.d;
+    uint8_t* const conv = comp + bytes * n;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* pred = (const uint8_t*)d_pred + (size_t)i * 256 * 256 * 3;
+        uint8_t* dst = comp + bytes * i;
+        if (hold_w) {
+            const Avatar& a = *hold_w;
+            const int32_t* c = a.coords.data() + 4 * (size_t)idx[i];
+            launch_paste(a.d_full + (size_t)idx[i] * bytes, H, W, pred, c[0], c[1], c[2], c[3], dst, sl.s);
+        } else {
+            const MtAvatar& a = *hold_m;
+            const int32_t* fb = a.face_box.data() + 4 * (size_t)idx[i];
+            const int32_t* cb = a.crop_box.data() + 4 * (size_t)idx[i];
+            launch_paste_blend(a.d_full + (size_t)idx[i] * bytes, H, W, pred, fb[0], fb[1], fb[2], fb[3], cb[0], cb[1], cb[2], cb[3],
+                               a.d_masks + a.mask_off[idx[i]], dst, sl.s);
+        }
+        launch_egress(dst, nullptr, 0.f, 1.f, nullptr, s->d_wm, s->wm_x, s->wm_y, s->wm_w, s->wm_h, s->wm_b, s->wm_g, s->wm_r,
+                      conv + out_bytes * i, H, W, format == LTK_FMT_I420, chroma, sl.s);
+    }
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(h_out, conv, out_bytes * n, hipMemcpyDeviceToHost, sl.s));
+    CHK(hipStreamSynchronize(sl.s));
+    return LTK_OK;
+}
+
 int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* feat, int B, float* unet_out, float* image,
                               uint8_t* frames) {
     if (!e || !latents || !feat || B <= 0) return fail(LTK_E_INVALID, "bad arguments");

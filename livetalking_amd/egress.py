@@ -38,6 +38,27 @@ def watermark_mask(H: int, W: int):
     return np.ascontiguousarray(canvas[y0:y1, x0:x1]), x0, y0
 
 
+class FrameGroup:
+    """The B device predictions of ONE inference_batch call and the bank frame of each (shared by the B items the call returned):
+    the process thread asks for them one by one, in order (base_avatar.py:429-433); the first request composites all B on the GPU
+    and moves them to the host in one copy."""
+    __slots__ = ("pred", "idx", "host", "eg_host", "eg_key", "lock")
+
+    def __init__(self, pred, idx):
+        import threading
+        self.pred, self.idx = pred, idx
+        self.host = None            # paste_back_frame path: numpy [B][H][W][3] over a pinned block
+        self.eg_host, self.eg_key = None, None      # device-egress path: numpy over a pinned block of converted frames
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def attach(items, pred, idx):
+        grp = FrameGroup(pred, idx)
+        for i, it in enumerate(items):
+            it._ltk_group, it._ltk_i = grp, i
+        return grp
+
+
 class I420Frame(np.ndarray):
     """uint8 [H*3/2][W] planar YUV 4:2:0 as `av.VideoFrame.from_ndarray(..., format="yuv420p")` takes it."""
     width: int
@@ -125,6 +146,32 @@ class DeviceEgress:
         return self.engine.egress_frame(self._h, self._out(), self.source, self.avatar_id, idx, d_pred_ptr, None, True, alpha,
                                         self.enable_transition, self.fmt, self.chroma)
 
+    def speaking_frame_of(self, res_frame, idx: int) -> np.ndarray:
+        """speaking_frame for an ITEM of inference_batch (a device tensor that may carry its FrameGroup): without the
+        transition effect (the reference's default) the first frame of a batch converts all of them - composite, watermark,
+        format - and copies them to the host at once (ltk_egress_batch); the returned frames are views of one pinned block that
+        lives as long as any of them."""
+        grp = getattr(res_frame, "_ltk_group", None)
+        if (grp is None or self.enable_transition or not hasattr(self.engine, "egress_batch")
+                or grp.idx[res_frame._ltk_i] != int(idx)):
+            return self.speaking_frame(res_frame.data_ptr(), idx)
+        self._alpha(True)                                   # keeps the speaking / silent state machine in step
+        key = (id(self), self.fmt)
+        with grp.lock:
+            if grp.eg_host is None or grp.eg_key != key:
+                import torch
+                n = len(grp.idx)
+                shape = (n, self.H * 3 // 2, self.W) if self.fmt == FMT_I420 else (n, self.H, self.W, 3)
+                host = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+                self.engine.egress_batch(self._h, self.source, self.avatar_id, grp.idx, grp.pred.data_ptr(), host.data_ptr(), self.fmt,
+                                         self.chroma)
+                grp.eg_host, grp.eg_key = host.numpy(), key
+        out = grp.eg_host[res_frame._ltk_i]
+        if self.fmt == FMT_I420:
+            out = out.view(I420Frame)
+            out.width, out.height = self.W, self.H
+        return out
+
     def silent_frame(self, idx: int, custom_frame: np.ndarray = None) -> np.ndarray:
         """base_avatar.py:408-428: the cached full frame (or a custom-action frame) + speaking->silent blend."""
         alpha = self._alpha(False)
@@ -195,7 +242,7 @@ class DeviceEgressMixin:
                 else:
                     self.speaking = True
                     try:
-                        frame = eg.speaking_frame(res_frame.data_ptr(), idx)
+                        frame = eg.speaking_frame_of(res_frame, idx)
                     except Exception as e:  # noqa: BLE001 - base_avatar.py:432-436 logs and drops the frame
                         import logging
                         logging.getLogger(__name__).warning("paste_back_frame error: %s", e)

@@ -215,6 +215,15 @@ class Engine:
         _lib.check(self._lib.ltk_egress_frame(self._h, C.c_void_p(session), C.byref(req), out.ctypes.data, C.c_void_p(stream)))
         return out
 
+    def egress_batch(self, session: int, source: int, avatar_id: int, idx: Sequence[int], d_pred_ptr: int, out_ptr: int, fmt: int = 0,
+                     chroma: int = 1, stream: int = 0) -> None:
+        """The speaking frames of one inference_batch result: len(idx) composites + watermark + format conversion on the device, one
+        device-to-host copy into host memory at out_ptr (include/ltk.h: ltk_egress_batch)."""
+        arr = np.ascontiguousarray(np.asarray(idx, dtype=np.int32))
+        _lib.check(self._lib.ltk_egress_batch(self._h, C.c_void_p(session), int(source), int(avatar_id), arr.ctypes.data,
+                                              C.c_void_p(d_pred_ptr), int(arr.size), int(fmt), int(chroma), C.c_void_p(out_ptr),
+                                              C.c_void_p(stream)))
+
     def musetalk_forward_host(self, latents: np.ndarray, feat: np.ndarray, want_image=True, want_frames=True):
         latents = np.ascontiguousarray(latents, dtype=np.float32).reshape(-1, 8, 32, 32)
         feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(-1, 50, 384)

@@ -173,3 +173,50 @@ def test_lipreal_device_process_frames_loop():
         got = sess.output.video[1 + i]
         assert got.width == 640 and got.height == 360
         assert np.array_equal(np.asarray(got), eo.egress_frame(comp, wm, "i420", 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bgr24", "i420"])
+def test_egress_batch_equals_per_frame_and_oracle(engine, fmt):
+    """ltk_egress_batch (the speaking frames of one inference_batch result: n composites + watermark + format conversion on the
+    device, ONE device-to-host copy) is, frame by frame, what ltk_egress_frame delivers and what the oracle computes, bit for bit;
+    through DeviceEgress.speaking_frame_of the frames of a batch come out of one pinned block and stay valid afterwards."""
+    from livetalking_amd import egress
+    H, W = 360, 640
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=4, full_hw=(H, W), box=160, seed=3)
+    aid = engine.register_avatar(faces, frames, coords)
+    rng = np.random.default_rng(4)
+    n = 6
+    preds = rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    d_preds = torch.from_numpy(preds).cuda()
+    idx = [2, 3, 3, 2, 1, 0]
+    mask, wx, wy, col = _wm(2)
+    fcode = egress.FMT_I420 if fmt == "i420" else egress.FMT_BGR24
+    h = engine.egress_open(H, W)
+    engine.egress_watermark(h, mask, wx, wy, col)
+    shape = (n, H * 3 // 2, W) if fmt == "i420" else (n, H, W, 3)
+    host = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+    engine.egress_batch(h, egress.SRC_WAV2LIP, aid, idx, d_preds.data_ptr(), host.data_ptr(), fcode, 1)
+    got = host.numpy()
+    for i in range(n):
+        one = np.empty(shape[1:], dtype=np.uint8)
+        engine.egress_frame(h, one, egress.SRC_WAV2LIP, aid, idx[i], d_preds[i].data_ptr(), None, True, -1.0, False, fcode, 1)
+        ref = eo.egress_frame(paste_oracle.paste_back_frame(preds[i].astype(np.float32), frames[idx[i]], coords[idx[i]]), (mask, wx, wy, col), fmt, 1)
+        assert np.array_equal(got[i], one) and np.array_equal(got[i], ref), (fmt, i)
+    engine.egress_close(h)
+    # the plugin-side path: items of a batch carrying their FrameGroup
+    eg = egress.DeviceEgress(engine, H, W, egress.SRC_WAV2LIP, aid, fmt=fmt, watermark=(mask, wx, wy))
+    items = [d_preds[i] for i in range(n)]
+    egress.FrameGroup.attach(items, d_preds, idx)
+    outs = [eg.speaking_frame_of(items[i], idx[i]) for i in range(n)]
+    keep = outs[1].copy()
+    more = [d_preds[i] for i in range(n)]
+    egress.FrameGroup.attach(more, d_preds, idx)
+    [eg.speaking_frame_of(more[i], idx[i]) for i in range(n)]
+    for i in range(n):
+        assert np.array_equal(np.asarray(outs[i]), got[i]), i
+        if fmt == "i420":
+            assert isinstance(outs[i], egress.I420Frame) and (outs[i].height, outs[i].width) == (H, W)
+    assert np.array_equal(np.asarray(outs[1]), keep)
+    eg.close()
+    engine.release_avatar(aid)
