@@ -491,7 +491,7 @@ def delivered_capacity(args):
     import synth_inputs as synth
     B = args.batch
     egress_fmt = args.egress if args.egress in ("bgr24", "i420") else ""
-    counts = [int(v) for v in (args.delivered_sessions or ("256,384,512" if egress_fmt == "i420" else "16,128,256,384")).split(",")]
+    counts = [int(v) for v in (args.delivered_sessions or ("384,512" if egress_fmt == "i420" else "128,256,384")).split(",")]
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
     eng = model.engine
     plugin.warm_up(B, model, 256)
@@ -757,7 +757,7 @@ def main():
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
     ap.add_argument("--egress", default="", help="delivered-capacity run: bgr24 | i420 = frames through the device egress path "
                     "(opt.egress of the plugin: composite + watermark + format conversion on the GPU) instead of paste_back_frame")
-    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 16,128,256,384; with --egress i420: 256,384,512)")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 128,256,384; with --egress i420: 384,512)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
