@@ -33,7 +33,7 @@ struct EgressArgs {
 };
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void egress_kernel(const EgressArgs a) {
+__device__ __forceinline__ void egress_body(const EgressArgs& a) {
     // OpenCV evaluates a*w1 + b*w2 as two products and a sum; hipcc's default -ffp-contract=fast would fuse one of them
 #pragma clang fp contract(off)
     const int pw = (a.W + 3) >> 2;                       // 4-pixel patches per row pair
@@ -146,6 +146,30 @@ __global__ __launch_bounds__(256) void egress_kernel(const EgressArgs a) {
     } else {
         for (int q = 0; q < (nx >> 1); ++q) { U[coff + q] = (uint8_t)(uw >> (8 * q)); V[coff + q] = (uint8_t)(vw >> (8 * q)); }
     }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void egress_kernel(const EgressArgs a) {
+    egress_body<VEC>(a);
+}
+
+// n frames of one batch in one launch (blockIdx.y = frame): no transition blend, no cache write
+template <bool VEC>
+__global__ __launch_bounds__(256) void egress_batch_kernel(EgressArgs a, size_t src_stride, size_t out_stride) {
+    a.src += (size_t)blockIdx.y * src_stride;
+    a.out += (size_t)blockIdx.y * out_stride;
+    egress_body<VEC>(a);
+}
+
+void launch_egress_batch(const uint8_t* src0, size_t src_stride, int n, const uint8_t* wm, int wm_x, int wm_y, int wm_w, int wm_h, int wm_b,
+                         int wm_g, int wm_r, uint8_t* out0, size_t out_stride, int H, int W, int i420, int chroma, hipStream_t s) {
+    EgressArgs a{src0, nullptr, 0.f, 1.f, nullptr, wm, wm_x, wm_y, wm_w, wm_h, wm_b, wm_g, wm_r, out0, H, W, i420, chroma};
+    const int patches = ((W + 3) >> 2) * ((H + 1) >> 1);
+    const dim3 grid((unsigned)((patches + 255) / 256), (unsigned)n);
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)src0 | (uintptr_t)out0 | src_stride | out_stride) & 3) == 0) &&
+                     (!i420 || (((size_t)H * W) % 4 == 0 && ((size_t)(H >> 1) * (W >> 1)) % 2 == 0));
+    if (vec) hipLaunchKernelGGL(egress_batch_kernel<true>, grid, dim3(256), 0, s, a, src_stride, out_stride);
+    else hipLaunchKernelGGL(egress_batch_kernel<false>, grid, dim3(256), 0, s, a, src_stride, out_stride);
 }
 
 void launch_egress(const uint8_t* src, const uint8_t* prev, float w_prev, float w_src, uint8_t* cache, const uint8_t* wm, int wm_x,

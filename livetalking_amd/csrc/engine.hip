@@ -928,10 +928,15 @@ int ltk_paste_back_batch(ltk_engine* e, int avatar_id, const int32_t* idx, const
     StreamLease sl(e, stream);
     ScratchLease sc(e, bytes * n);
     if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
-    for (int i = 0; i < n; ++i) {
-        const int32_t* c = a.coords.data() + 4 * (size_t)idx[i];
-        launch_paste(a.d_full + (size_t)idx[i] * bytes, a.H, a.W, (const uint8_t*)d_pred + (size_t)i * 256 * 256 * 3, c[0], c[1], c[2], c[3],
-                     (uint8_t*)sc.s.d + (size_t)i * bytes, sl.s);
+    for (int i0 = 0; i0 < n; i0 += kPasteBatch) {          // one launch per 16 frames
+        const int m = std::min(kPasteBatch, n - i0);
+        PasteBatch pb;
+        for (int i = 0; i < m; ++i) {
+            const int32_t* c = a.coords.data() + 4 * (size_t)idx[i0 + i];
+            pb.full[i] = a.d_full + (size_t)idx[i0 + i] * bytes;
+            pb.y1[i] = c[0]; pb.y2[i] = c[1]; pb.x1[i] = c[2]; pb.x2[i] = c[3];
+        }
+        launch_paste_batch(pb, m, a.H, a.W, (const uint8_t*)d_pred + (size_t)i0 * 256 * 256 * 3, (uint8_t*)sc.s.d + (size_t)i0 * bytes, bytes, sl.s);
     }
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(out, sc.s.d, bytes * n, hipMemcpyDeviceToHost, sl.s));
@@ -1549,23 +1554,30 @@ int ltk_egress_batch(ltk_engine* e, ltk_egress* s, int source, int avatar, const
     if (!sc.s.d) return fail(LTK_E_NOMEM, "scratch allocation failed");
     uint8_t* const comp = (uint8_t*)sc.s.d;
     uint8_t* const conv = comp + bytes * n;
-    for (int i = 0; i < n; ++i) {
-        const uint8_t* pred = (const uint8_t*)d_pred + (size_t)i * 256 * 256 * 3;
-        uint8_t* dst = comp + bytes * i;
-        if (hold_w) {
-            const Avatar& a = *hold_w;
-            const int32_t* c = a.coords.data() + 4 * (size_t)idx[i];
-            launch_paste(a.d_full + (size_t)idx[i] * bytes, H, W, pred, c[0], c[1], c[2], c[3], dst, sl.s);
-        } else {
-            const MtAvatar& a = *hold_m;
+    if (hold_w) {                                          // composites: one launch per 16 frames
+        const Avatar& a = *hold_w;
+        for (int i0 = 0; i0 < n; i0 += kPasteBatch) {
+            const int m = std::min(kPasteBatch, n - i0);
+            PasteBatch pb;
+            for (int i = 0; i < m; ++i) {
+                const int32_t* c = a.coords.data() + 4 * (size_t)idx[i0 + i];
+                pb.full[i] = a.d_full + (size_t)idx[i0 + i] * bytes;
+                pb.y1[i] = c[0]; pb.y2[i] = c[1]; pb.x1[i] = c[2]; pb.x2[i] = c[3];
+            }
+            launch_paste_batch(pb, m, H, W, (const uint8_t*)d_pred + (size_t)i0 * 256 * 256 * 3, comp + bytes * i0, bytes, sl.s);
+        }
+    } else {
+        const MtAvatar& a = *hold_m;
+        for (int i = 0; i < n; ++i) {
             const int32_t* fb = a.face_box.data() + 4 * (size_t)idx[i];
             const int32_t* cb = a.crop_box.data() + 4 * (size_t)idx[i];
-            launch_paste_blend(a.d_full + (size_t)idx[i] * bytes, H, W, pred, fb[0], fb[1], fb[2], fb[3], cb[0], cb[1], cb[2], cb[3],
-                               a.d_masks + a.mask_off[idx[i]], dst, sl.s);
+            launch_paste_blend(a.d_full + (size_t)idx[i] * bytes, H, W, (const uint8_t*)d_pred + (size_t)i * 256 * 256 * 3, fb[0], fb[1], fb[2], fb[3],
+                               cb[0], cb[1], cb[2], cb[3], a.d_masks + a.mask_off[idx[i]], comp + bytes * i, sl.s);
         }
-        launch_egress(dst, nullptr, 0.f, 1.f, nullptr, s->d_wm, s->wm_x, s->wm_y, s->wm_w, s->wm_h, s->wm_b, s->wm_g, s->wm_r,
-                      conv + out_bytes * i, H, W, format == LTK_FMT_I420, chroma, sl.s);
     }
+    // watermark + format conversion of all n composites in one launch
+    launch_egress_batch(comp, bytes, n, s->d_wm, s->wm_x, s->wm_y, s->wm_w, s->wm_h, s->wm_b, s->wm_g, s->wm_r, conv, out_bytes, H, W,
+                        format == LTK_FMT_I420, chroma, sl.s);
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(h_out, conv, out_bytes * n, hipMemcpyDeviceToHost, sl.s));
     CHK(hipStreamSynchronize(sl.s));

@@ -52,11 +52,23 @@ void launch_mel(const float* pcm, int n_samples, const int32_t* win_start, int n
 void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
                   uint8_t* out, hipStream_t s);
 
+// the same for up to kPasteBatch frames in one launch (the B composites of one inference_batch result): frame f pastes prediction
+// pred0 + f * 256*256*3 onto full[f] with box (y1,y2,x1,x2)[f] and writes out0 + f * out_stride
+constexpr int kPasteBatch = 16;
+struct PasteBatch {
+    const uint8_t* full[kPasteBatch];
+    int y1[kPasteBatch], y2[kPasteBatch], x1[kPasteBatch], x2[kPasteBatch];
+};
+void launch_paste_batch(const PasteBatch& b, int n, int H, int W, const uint8_t* pred0, uint8_t* out0, size_t out_stride, hipStream_t s);
+
 // musetalk_avatar.py:154-164 paste_back_frame (resize + paste into the crop + cv2.blendLinear under the mask).
 void launch_paste_blend(const uint8_t* full, int H, int W, const uint8_t* pred256, int x1, int y1, int x2, int y2, int xs, int ys,
                         int xe, int ye, const uint8_t* mask, uint8_t* out, hipStream_t s);
 
 // Frame egress (base_avatar.py:419-449 transition blend + watermark, BGR24 -> I420): see egress_kernels.hip
+// launch_egress for n frames in one launch, no transition blend / cache: frame f reads src0 + f * src_stride, writes out0 + f * out_stride
+void launch_egress_batch(const uint8_t* src0, size_t src_stride, int n, const uint8_t* wm, int wm_x, int wm_y, int wm_w, int wm_h, int wm_b,
+                         int wm_g, int wm_r, uint8_t* out0, size_t out_stride, int H, int W, int i420, int chroma, hipStream_t s);
 void launch_egress(const uint8_t* src, const uint8_t* prev, float w_prev, float w_src, uint8_t* cache, const uint8_t* wm, int wm_x,
                    int wm_y, int wm_w, int wm_h, int wm_b, int wm_g, int wm_r, uint8_t* out, int H, int W, int i420, int chroma,
                    hipStream_t s);

@@ -229,9 +229,9 @@ __device__ __forceinline__ AxisTap axis_tap(int d, int dst, int src, bool clamp_
     return t;
 }
 
-__global__ __launch_bounds__(256) void paste_kernel(const uint8_t* __restrict__ full, int H, int W,
-                                                     const uint8_t* __restrict__ pred, int y1, int y2, int x1, int x2,
-                                                     uint8_t* __restrict__ out) {
+__device__ __forceinline__ void paste_body(const uint8_t* __restrict__ full, int H, int W,
+                                           const uint8_t* __restrict__ pred, int y1, int y2, int x1, int x2,
+                                           uint8_t* __restrict__ out) {
     const size_t total = (size_t)H * W * 3;
     const size_t b0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (b0 >= total) return;
@@ -272,6 +272,19 @@ __global__ __launch_bounds__(256) void paste_kernel(const uint8_t* __restrict__ 
     } else {
         for (int k = 0; k < nb; ++k) out[b0 + k] = (uint8_t)(word >> (8 * k));
     }
+}
+
+__global__ __launch_bounds__(256) void paste_kernel(const uint8_t* __restrict__ full, int H, int W,
+                                                     const uint8_t* __restrict__ pred, int y1, int y2, int x1, int x2,
+                                                     uint8_t* __restrict__ out) {
+    paste_body(full, H, W, pred, y1, y2, x1, x2, out);
+}
+
+// the composites of up to kPasteBatch frames of ONE inference_batch result in one launch: blockIdx.y = frame
+__global__ __launch_bounds__(256) void paste_batch_kernel(const PasteBatch b, int H, int W, const uint8_t* __restrict__ pred0,
+                                                           uint8_t* __restrict__ out0, size_t out_stride) {
+    const int f = blockIdx.y;
+    paste_body(b.full[f], H, W, pred0 + (size_t)f * (256 * 256 * 3), b.y1[f], b.y2[f], b.x1[f], b.x2[f], out0 + (size_t)f * out_stride);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -339,6 +352,11 @@ void launch_paste_blend(const uint8_t* full, int H, int W, const uint8_t* pred25
     const size_t words = (total + 3) / 4;
     hipLaunchKernelGGL(paste_blend_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, full, H, W, pred256, x1, y1, x2, y2,
                        xs, ys, xe, ye, mask, out);
+}
+
+void launch_paste_batch(const PasteBatch& b, int n, int H, int W, const uint8_t* pred0, uint8_t* out0, size_t out_stride, hipStream_t s) {
+    const size_t words = ((size_t)H * W * 3 + 3) / 4;
+    hipLaunchKernelGGL(paste_batch_kernel, dim3((unsigned)((words + 255) / 256), (unsigned)n), dim3(256), 0, s, b, H, W, pred0, out0, out_stride);
 }
 
 void launch_paste(const uint8_t* full, int H, int W, const uint8_t* pred256, int y1, int y2, int x1, int x2,
