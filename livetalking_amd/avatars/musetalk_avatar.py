@@ -22,12 +22,15 @@ import weakref
 
 import numpy as np
 
-from ..egress import SRC_MUSETALK, DeviceEgressMixin, FrameGroup
+from ..egress import SRC_MUSETALK, DeviceEgress, DeviceEgressMixin, FrameGroup
 from ..engine import Engine
 from ..hostshim import BaseAvatar, mirror_index, register
 from ..scheduler import get_scheduler
 from ..sharding import EnginePool, visible_devices
 from .audio_features.whisper import Audio2Feature, WhisperASR
+
+
+_PASTE_BATCH = os.environ.get("LTK_PASTE_BATCH", "1") != "0"     # 0: one composite + one pageable copy per paste_back_frame call
 
 
 class MuseTalkModel:
@@ -182,6 +185,7 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
         h, w = self.frame_list_cycle[0].shape[:2]
         self._frame_hw = (int(h), int(w))
         self._sched = get_scheduler(self.engine, "musetalk")
+        self._paste_eg = None           # lazily: the BGR24 egress session behind the batched paste_back_frame
         self.asr = WhisperASR(opt, self, model.audio_processors[self._slot])
         self.asr.warm_up()
 
@@ -211,6 +215,14 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
             pred_frame = torch.from_numpy(np.ascontiguousarray(pred_frame).astype(np.uint8)).to(
                 self.engine.torch_device)
         h, w = self._frame_hw
+        grp = getattr(pred_frame, "_ltk_group", None)
+        if grp is not None and _PASTE_BATCH and grp.idx[pred_frame._ltk_i] == int(idx):
+            # the B blended composites of the batch on the GPU and ONE pinned device-to-host copy: a watermark-less BGR24 egress
+            # session delivers exactly paste_back_frame's array (ltk_egress_batch = ltk_paste_blend per frame + a plain copy-out)
+            if self._paste_eg is None:
+                self._paste_eg = DeviceEgress(self.engine, h, w, SRC_MUSETALK, self._aid, fmt="bgr24", watermark=None)
+                weakref.finalize(self, self._paste_eg.close)
+            return self._paste_eg.speaking_frame_of(pred_frame, int(idx))
         out = np.empty((h, w, 3), dtype=np.uint8)
         self.engine.paste_blend(self._aid, int(idx), pred_frame.data_ptr(), out)
         return out
