@@ -20,7 +20,7 @@ adds, OUTSIDE the timed region (each in its own subprocess, so `ms_per_step x st
                 (bisection, engine level: "kernel capacity")
   delivered     the same with every session's 16 composited 720p frames copied to the host per period, through the plugin
                 (inference_batch + paste_back_frame, one thread per session): what a deployment can actually serve;
-                delivered_i420: through the plugin's opt.egress = i420 path (composite + watermark + BGR->I420 on the GPU)
+                .bgr24 through paste_back_frame, .i420 through the plugin's opt.egress path (composite + watermark + BGR->I420 on the GPU)
   cpu_baseline  the reference's LipReal.inference_batch on the host cores (kind "reference" when a LiveTalking checkout
                 is importable, else the oracle port), B=16 and B=1 (configs[0]), median of 5
   roofline.traffic  HBM bytes per pass from two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) of the conv stack
@@ -478,10 +478,12 @@ def paced_capacity(args):
 def delivered_capacity(args):
     """DELIVERABLE session capacity of one GPU, plugin level: S sessions, each with its own thread doing per 0.64-s period
     what the reference's inference thread and process thread do for it (avatars/base_avatar.py:326-381, 383-467):
-    `inference_batch` for B frames, then `paste_back_frame` for every one of them - the composited 720p BGR frame as a host
-    array, which is what `output.push_video_frame` receives (server/webrtc.py:144-151).  A session count is sustained when
-    every session has its B host frames before the next period starts (finalfps >= 25).  Reported per count: the worst
-    period latency, frames delivered per second and session, and the device-to-host rate."""
+    `inference_batch` for B frames, then one host frame per prediction - `paste_back_frame` (the composited 720p BGR frame
+    `output.push_video_frame` receives, server/webrtc.py:144-151) or, with the plugin's opt.egress = "i420", the device
+    egress path (composite + watermark + BGR->I420 on the GPU, half the PCIe bytes).  A session count is sustained when every
+    session has its B host frames before the next period starts (finalfps >= 25) in every measured period.  Both frame
+    formats run in this one process (one model, one 250-frame bank); the pinned host pool is warmed before a count is timed
+    (a deployment's sessions do not all start in the same 640 ms)."""
     import argparse as ap
     import numpy as np
     import torch
@@ -490,8 +492,6 @@ def delivered_capacity(args):
     from livetalking_amd.hostshim import mirror_index
     import synth_inputs as synth
     B = args.batch
-    egress_fmt = args.egress if args.egress in ("bgr24", "i420") else ""
-    counts = [int(v) for v in (args.delivered_sessions or ("384,512" if egress_fmt == "i420" else "256,384,512")).split(",")]
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
     eng = model.engine
     plugin.warm_up(B, model, 256)
@@ -505,78 +505,92 @@ def delivered_capacity(args):
         eng.mel_step(audio[off: off + (20 + 2 * B) * 320], starts, d_mel[s].data_ptr())
     sessions, egs = [], []
     period = B / 25.0
-    results = []
-    frame_bytes = H * W * 3 // 2 if egress_fmt == "i420" else H * W * 3
-    for S in counts:
-        while len(sessions) < S:
-            o = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=len(sessions))
-            sessions.append(plugin.LipReal(o, model, avatar))
-            if egress_fmt:                     # opt.egress: device-side process_frames (egress.py) - composite + watermark + format on the GPU
-                sessions[-1].opt.egress = egress_fmt
-                egs.append(sessions[-1]._make_egress())
-        periods = 5                                            # the first two are warm-up (pinned blocks, stream and scratch pools)
-        go = threading.Barrier(S + 1)
-        lat = [[0.0] * periods for _ in range(S)]
-        infer_s = [0.0] * S
-        errs = []
-        t_start = [0.0]
 
-        def work(i):
-            sess = sessions[i]
-            try:
-                go.wait()
-                for p in range(periods):
-                    due = t_start[0] + p * period
-                    while time.perf_counter() < due:
-                        time.sleep(0.0005)
-                    index = (p * B + 7 * i) % (2 * BANK_FRAMES)
-                    t0 = time.perf_counter()
-                    pred = sess.inference_batch(index, d_mel[i % 16])
-                    infer_s[i] += time.perf_counter() - t0
-                    chk = 0
-                    for k in range(B):
-                        if egress_fmt:
-                            frame = egs[i].speaking_frame_of(pred[k], mirror_index(BANK_FRAMES, index + k))
-                            chk += int(frame.reshape(-1)[0])
-                        else:
-                            frame = sess.paste_back_frame(pred[k], mirror_index(BANK_FRAMES, index + k))
-                            chk += int(frame[0, 0, 0])        # the host array is real
-                    lat[i][p] = time.perf_counter() - due
-            except Exception as ex:  # noqa: BLE001
-                errs.append(repr(ex))
+    def run_format(egress_fmt, counts):
+        frame_bytes = H * W * 3 // 2 if egress_fmt == "i420" else H * W * 3
+        results = []
+        for S in counts:
+            while len(sessions) < S:
+                o = ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=len(sessions), egress="i420")
+                sessions.append(plugin.LipReal(o, model, avatar))
+                egs.append(None)
+            if egress_fmt:
+                for i in range(S):
+                    if egs[i] is None:
+                        egs[i] = sessions[i]._make_egress()      # opt.egress = "i420": the device-side process_frames path (egress.py)
+            # warm the pinned host pool: S blocks of one batch each, allocated together, then returned to torch's caching allocator
+            shape = (B, H * 3 // 2, W) if egress_fmt == "i420" else (B, H, W, 3)
+            warm = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(S)]
+            del warm
+            periods = 4                                            # the first one is warm-up (stream and scratch pools)
+            go = threading.Barrier(S + 1)
+            lat = [[0.0] * periods for _ in range(S)]
+            infer_s = [0.0] * S
+            errs = []
+            t_start = [0.0]
 
-        th = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(S)]
-        for t in th:
-            t.start()
-        # one untimed warm-up period (pinned blocks, stream pool), then the paced periods
-        t_start[0] = time.perf_counter() + 0.05
-        go.wait()
-        for t in th:
-            t.join(timeout=120)
-        if errs:
-            results.append({"sessions": S, "error": errs[0][:200]})
-            break
-        steady = [max(l[2:]) for l in lat]                      # periods 0-1 pay the first-use allocations of a cold pool
-        worst = max(steady)
-        mean_lat = float(np.mean([np.mean(l[2:]) for l in lat]))
-        ok = worst < period
-        results.append({"sessions": S, "sustained": bool(ok), "latency_ms_max": round(worst * 1e3, 1), "latency_ms_mean": round(mean_lat * 1e3, 1),
-                        "finalfps_per_session": round(B / max(period, worst), 2),
-                        "inferfps_per_session_min": round(periods * B / max(infer_s), 1), "first_periods_ms_max": [round(max(l[k] for l in lat) * 1e3, 1) for k in (0, 1)],
-                        "d2h_GBps_needed": round(S * B * frame_bytes / period / 1e9, 2),
-                        "d2h_GBps_while_busy": round(S * B * frame_bytes / max(mean_lat, 1e-9) / 1e9, 2)})
-        if not ok:
-            break
+            def work(i):
+                sess = sessions[i]
+                try:
+                    go.wait()
+                    for p in range(periods):
+                        due = t_start[0] + p * period
+                        while time.perf_counter() < due:
+                            time.sleep(0.0005)
+                        index = (p * B + 7 * i) % (2 * BANK_FRAMES)
+                        t0 = time.perf_counter()
+                        pred = sess.inference_batch(index, d_mel[i % 16])
+                        infer_s[i] += time.perf_counter() - t0
+                        chk = 0
+                        for k in range(B):
+                            if egress_fmt:
+                                frame = egs[i].speaking_frame_of(pred[k], mirror_index(BANK_FRAMES, index + k))
+                                chk += int(frame.reshape(-1)[0])
+                            else:
+                                frame = sess.paste_back_frame(pred[k], mirror_index(BANK_FRAMES, index + k))
+                                chk += int(frame[0, 0, 0])        # the host array is real
+                        lat[i][p] = time.perf_counter() - due
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(repr(ex))
+
+            th = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(S)]
+            for t in th:
+                t.start()
+            t_start[0] = time.perf_counter() + 0.05
+            go.wait()
+            for t in th:
+                t.join(timeout=120)
+            if errs:
+                results.append({"sessions": S, "error": errs[0][:200]})
+                break
+            steady = [max(l[1:]) for l in lat]
+            worst = max(steady)
+            mean_lat = float(np.mean([np.mean(l[1:]) for l in lat]))
+            ok = worst < period
+            results.append({"sessions": S, "sustained": bool(ok), "latency_ms_max": round(worst * 1e3, 1), "latency_ms_mean": round(mean_lat * 1e3, 1),
+                            "finalfps_per_session": round(B / max(period, worst), 2),
+                            "inferfps_per_session_min": round(periods * B / max(infer_s), 1),
+                            "first_period_ms_max": round(max(l[0] for l in lat) * 1e3, 1),
+                            "d2h_GBps_needed": round(S * B * frame_bytes / period / 1e9, 2)})
+            if not ok:
+                break
+        best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
+        return {"max_sessions_25fps_delivered": best, "frame_format": egress_fmt or "bgr24 (paste_back_frame)", "frame_bytes": frame_bytes,
+                "tested": results}
+
+    custom = [int(v) for v in args.delivered_sessions.split(",")] if args.delivered_sessions else None
+    out = {"period_ms": period * 1e3, "bank_frames": BANK_FRAMES,
+           "bgr24": run_format("", custom or [256, 384]),
+           "i420": run_format("i420", custom or [384, 512]),
+           "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 host frames (bgr24: paste_back_frame - "
+                   "the batch's composites on the GPU, one pinned device-to-host copy; i420: the plugin's opt.egress path, + watermark + BGR->I420 "
+                   "on the GPU); one Python thread per session; pinned pool warmed, period 0 excluded"}
     for g in egs:
-        g.close()
+        if g is not None:
+            g.close()
     for e in model.engines:
         e.close()
-    best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
-    return {"max_sessions_25fps_delivered": best, "period_ms": period * 1e3, "frame_format": egress_fmt or "bgr24 (paste_back_frame)",
-            "frame_bytes": frame_bytes, "bank_frames": BANK_FRAMES, "tested": results,
-            "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 paste_back_frame calls "
-                    "returning host 720p BGR frames (B composites on the GPU, one pinned device-to-host copy per batch); one Python "
-                    "thread per session; periods 0-1 (first-use allocations: first_periods_ms_max) excluded"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -585,7 +599,7 @@ def delivered_capacity(args):
 def cpu_baseline(batch: int):
     """LipReal.inference_batch on the host cores: the reference's own class from a LiveTalking checkout when one is
     importable (kind "reference": build container), else the oracle restatement (kind "port": the GPU box).  fp32
-    torch CPU, all cores, seeded synthetic weights / bank / audio; median of 5 after one warm-up, B=batch and B=1."""
+    torch CPU, all cores, seeded synthetic weights / bank / audio; median of 3 after one warm-up, B=batch and B=1."""
     import numpy as np
     import torch
     import synth_inputs as synth
@@ -624,7 +638,7 @@ def cpu_baseline(batch: int):
         feats = mel_oracle.mel_chunks(audio[: (20 + 2 * B) * 320], 20 + 2 * B)
         call(0, B, feats)
         ts = []
-        for i in range(5):
+        for i in range(3):
             t0 = time.perf_counter()
             call((i + 1) * B, B, feats)
             ts.append(time.perf_counter() - t0)
@@ -634,7 +648,7 @@ def cpu_baseline(batch: int):
     what = "the reference's LipReal.inference_batch (avatars/wav2lip_avatar.py:116-139)" if kind == "reference" else \
         "oracle port of LipReal.inference_batch"
     return {"value": round(fb, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": kind,
-            "sample": f"median of 5 x {what}, B={batch}, fp32 torch-CPU, seeded synthetic weights/bank/audio",
+            "sample": f"median of 3 x {what}, B={batch}, fp32 torch-CPU, seeded synthetic weights/bank/audio",
             "b1": {"value": round(f1, 3), "unit": "frames/s", "sample": "same, B=1 (BASELINE.json configs[0])"}}
 
 
@@ -755,9 +769,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
-    ap.add_argument("--egress", default="", help="delivered-capacity run: bgr24 | i420 = frames through the device egress path "
-                    "(opt.egress of the plugin: composite + watermark + format conversion on the GPU) instead of paste_back_frame")
-    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default 256,384,512; with --egress i420: 384,512)")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default: bgr24 256,384; i420 384,512)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -823,17 +835,16 @@ def main():
                 subs = [("convpasses", ["--sessions", "16", "--batch", str(args.batch)], 3, True, "HBM bytes per 256-frame conv-stack pass"),
                         ("mtpasses", ["--sessions", "1", "--batch", str(args.batch)], 2, False, "HBM bytes per 16-frame MuseTalk pass"),
                         None,
-                        ("mtpasses", ["--sessions", "4", "--batch", str(args.batch), "--fp8"], 1, False, "HBM bytes per 64-frame MuseTalk pass")]
+                        None]      # fp8, 4 sessions: profiles/r03_mtfp8_pmc.json (148 GB per 64-frame pass); two more 25-s profiler runs here would not fit "minutes"
                 for a, sb in zip(also, subs):
                     if sb is not None and isinstance(a, dict) and isinstance(a.get("roofline"), dict):
                         add_traffic(a["roofline"], *sb)
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
             out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
-            out["delivered_i420"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--egress", "i420"])
             w16 = also[0] if isinstance(also[0], dict) else {}
-            out["sessions_25fps"] = {"per_gpu_delivered": out["delivered"].get("max_sessions_25fps_delivered"),
-                                     "per_gpu_delivered_i420": out["delivered_i420"].get("max_sessions_25fps_delivered"),
+            out["sessions_25fps"] = {"per_gpu_delivered": (out["delivered"].get("bgr24") or {}).get("max_sessions_25fps_delivered"),
+                                     "per_gpu_delivered_i420": (out["delivered"].get("i420") or {}).get("max_sessions_25fps_delivered"),
                                      "per_gpu_kernel_capacity": out["paced"].get("max_sessions_25fps"),
                                      "at_16_sessions_per_gpu": w16.get("paced"),
                                      "note": "per_gpu_delivered: plugin level, every session gets its 16 composited 720p frames on the host per "
