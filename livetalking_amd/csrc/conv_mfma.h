@@ -136,6 +136,21 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::s
 // upper bound of the split-K scratch a launch of `N` images of H x W may use
 size_t conv3_partial_bytes(const ConvPlan& p, int N, int H, int W);
 
+// rowgemm.hip: the layers whose maps are one pixel per frame (plain GEMMs with as many rows as frames), for launches of up to
+// kRowGemmMaxFrames frames: Y[frame][y_coff + j] = act(scale[j] * sum_k X[frame][x_coff + k] * W[j][k] + shift[j]), j < J, k < K
+constexpr int kRowGemmMaxFrames = 32;
+struct RowGemmPlan {
+    f16* d_w = nullptr;            // packed MFMA fragments [J/16][K/32][64][8]
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+    int J = 0, K = 0;
+};
+int rowgemm_plan_create(RowGemmPlan* p, const float* w_eff /*[J][K]*/, int J, int K, const float* scale /*[J]*/, const float* shift /*[J]*/,
+                        std::string* err);
+void rowgemm_plan_destroy(RowGemmPlan* p);
+int rowgemm_launch(const RowGemmPlan& p, const f16* x, int x_ld, int x_coff, f16* y, int y_ld, int y_coff, int M, int relu,
+                   hipStream_t stream, std::string* err);
+
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;
 struct FacePtrs;

@@ -122,6 +122,8 @@ enum BufId { B_MEL = 0, B_AT0, B_AT1, B_X0, B_T0, B_T1, B_OUT32, B_CAT0, B_COUNT
 struct Layer {
     std::string name;
     ConvPlan plan;
+    RowGemmPlan rg;                 // set for the layers whose input and output maps are one pixel per frame (rowgemm.hip)
+    int rg_y_ld = 0;               // output row pitch of that GEMM (the 1x1-expand layer writes k*k*Cout contiguous channels)
     int cin_real = 0;
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
     int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
@@ -386,6 +388,40 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
                               sc.data(), sf.data(), &err, hint_hw);
     }
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+    // one pixel per frame on both sides: a plain GEMM with as many rows as frames (rowgemm.hip, used for launches of <= 32 frames)
+    {
+        std::vector<float> we, se, fe;
+        int J = 0, K = 0;
+        if (flat_ld > 0) {                                            // k x k valid conv collapsing the k x k map: W = the flattened weights above
+            const int kk = d.k * d.k;
+            J = d.cout; K = kk * d.cin;
+            we.assign((size_t)J * K, 0.f);
+            for (int co = 0; co < d.cout; ++co)
+                for (int ci = 0; ci < d.cin; ++ci)
+                    for (int t = 0; t < kk; ++t)
+                        we[(size_t)co * K + ((size_t)(ci >> 4) * kk + t) * 16 + (ci & 15)] = w[((size_t)co * d.cin + ci) * kk + t];
+            se = sc; fe = sf;
+        } else if (!d.transposed && d.k == 1 && hint_hw == 1 && d.cin % 32 == 0 && d.cout % 16 == 0) {
+            J = d.cout; K = d.cin;
+            we.assign(w, w + (size_t)J * K);
+            se = sc; fe = sf;
+        } else if (d.transposed && hint_hw == 1 && d.sh == 1 && d.pad == 0 && d.out_pad == 0 && d.cin % 32 == 0 && d.cout % 16 == 0) {
+            // ConvTranspose2d(k, 1, 0) on a 1x1 map: output channel-blocked k x k map [cout block][position][16] = k*k*Cout columns
+            const int kk = d.k * d.k;
+            J = kk * d.cout; K = d.cin;
+            we.assign((size_t)J * K, 0.f); se.assign(J, 0.f); fe.assign(J, 0.f);
+            for (int j = 0; j < J; ++j) {
+                const int c16 = j & 15, tt = j >> 4, pos = tt % kk, co = (tt / kk) * 16 + c16;
+                for (int ci = 0; ci < d.cin; ++ci) we[(size_t)j * K + ci] = w[((size_t)ci * d.cout + co) * kk + pos];
+                se[j] = sc[co]; fe[j] = sf[co];
+            }
+        }
+        if (J > 0) {
+            rc = rowgemm_plan_create(&L->rg, we.data(), J, K, se.data(), fe.data(), &err);
+            if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+            L->rg_y_ld = (d.transposed ? J : 0);
+        }
+    }
     if (!d.transposed && d.k == 7 && d.cin == 6 && d.cout == 16 && d.sh == 1 && d.pad == 3 && knob(K_CONV7) && !e->c7) {
         rc = conv7_plan_create(&e->c7, w, sc.data(), sf.data(), &err);
         if (rc) return fail(LTK_E_HIP, p + ": " + err);
@@ -402,7 +438,7 @@ void bump(size_t* cur, size_t v) { if (v > *cur) *cur = v; }
 // Everything ltk_wav2lip_load creates (layer plans, head weights, first-layer plan, activation arena): a failed load leaves
 // the engine as it found it, and can be retried.
 void wav2lip_unload(ltk_engine* e) {
-    for (Layer& L : e->layers) conv_plan_destroy(&L.plan);
+    for (Layer& L : e->layers) { conv_plan_destroy(&L.plan); rowgemm_plan_destroy(&L.rg); }
     e->layers.clear();
     for (int i = 0; i < B_COUNT; ++i)
         if (e->buf[i]) { (void)hipFree(e->buf[i]); e->buf[i] = nullptr; }
@@ -579,6 +615,11 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         int rc;
         if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
             rc = conv7_launch(e->c7, faces, e->buf[B_X0], nf, e->buf[L.out_buf], L.out_ld, L.out_coff, s, &err);
+        // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
+        // output element whatever the launch's frame count (larger launches run these layers on conv3)
+        else if (L.rg.d_w && nf <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK))
+            rc = rowgemm_launch(L.rg, e->buf[L.in_buf], L.in_ld, L.in_coff, e->buf[L.out_buf], L.rg_y_ld ? L.rg_y_ld : L.out_ld, L.out_coff, nf, 1,
+                                on_aux ? e->aux : s, &err);
         else
             rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);

@@ -33,6 +33,7 @@ enum Knob {
     K_UPS4,               // LTK_UPS4           1: nearest-2x upsample + 3x3 conv as four 2x2-tap phases (16 instead of 36 MACs per source pixel)
     K_FP8_MX,             // LTK_FP8_MX         fp8 convs on the MX-scaled MFMA (32x32x64, 2x MAC rate): 1 = where it wins (Cin >= 512:
                           //                    its 64-channel chunks leave one block per CU, which only deep K loops repay), 2 = all, 0 = none
+    K_ROWGEMM,            // LTK_ROWGEMM        1: the one-pixel-map layers of a <= 32-frame launch as skinny GEMMs (rowgemm.hip) instead of conv3 + split-K finish
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
     K_COUNT
 };

@@ -18,6 +18,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_CONV_PERSIST", 512}, {"LTK_NO_FOLD_RESIDUAL", 0}, {"LTK_NO_FLATTEN", 0},       {"LTK_NO_AUX_STREAM", 0},
     {"LTK_MICROBATCH", 0},     {"LTK_MT_NO_QKV_FUSE", 0},  {"LTK_HEAD_FUSED", 1},
     {"LTK_CONV3_NC8", 0},      {"LTK_TILE_RULE", 1},       {"LTK_TILE_TABLE", 1},        {"LTK_CONV7", 1},           {"LTK_ATTN_WIDE", 1},       {"LTK_UPS4", 1},            {"LTK_FP8_MX", 1},
+    {"LTK_ROWGEMM", 1},
     {"LTK_ABLATE", 0},
 };
 

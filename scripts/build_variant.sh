@@ -10,7 +10,7 @@ OBJ=$ROOT/build/$NAME
 mkdir -p $OBJ $ROOT/ab_libs
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
-for f in tune conv_mfma conv3_mfma conv7_mfma misc_kernels egress_kernels nn_kernels musetalk engine; do
+for f in tune conv_mfma conv3_mfma conv7_mfma rowgemm misc_kernels egress_kernels nn_kernels musetalk engine; do
   extra=""
   case $f in misc_kernels|egress_kernels) extra="-ffp-contract=off";; esac
   if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ -n "$(find $SRC -name '*.h' -newer $OBJ/$f.o)" ] || [ -n "$FORCE" ]; then
