@@ -32,6 +32,13 @@ using namespace ltk;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
+// Entry of every call that launches: select the engine's GPU, and drop whatever error an EARLIER runtime call left behind on this
+// host thread (ours after a reported failure, or another library's) - hipGetLastError() after a launch must speak about that launch
+static hipError_t enter_device(int device) {
+    (void)hipGetLastError();
+    return hipSetDevice(device);
+}
+
 #define CHK(expr)                                                                        \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \
@@ -752,7 +759,7 @@ void ltk_engine_destroy(ltk_engine* e) {
 
 int ltk_engine_sync(ltk_engine* e) {
     if (!e) return fail(LTK_E_INVALID, "engine is null");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     CHK(hipDeviceSynchronize());
     return LTK_OK;
 }
@@ -762,7 +769,7 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
     if (max_frames < 1 || max_frames > 4096) return fail(LTK_E_INVALID, "max_frames must be in [1, 4096]");
     std::lock_guard<std::mutex> g(e->mu);
     if (e->loaded) return fail(LTK_E_STATE, "a model is already loaded in this engine");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const int rc = [&]() -> int {
         const int brc = build_program(e, sd, n);
         if (brc) return brc;
@@ -792,7 +799,7 @@ int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* 
         if (c[0] < 0 || c[2] < 0 || c[1] > H || c[3] > W || c[1] <= c[0] || c[3] <= c[2])
             return fail(LTK_E_INVALID, "coords box outside the frame");
     }
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     auto ap = std::make_shared<Avatar>();
     Avatar& a = *ap;
     a.device = e->device;
@@ -831,7 +838,7 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
         if (win_start[i] < cmin) cmin = win_start[i];
         if (win_start[i] + 15 > cmax) cmax = win_start[i] + 15;
     }
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const size_t pcm_bytes = (size_t)n_samples * sizeof(float);
     const size_t ws_off = (pcm_bytes + 255) / 256 * 256;
     ScratchLease sc(e, ws_off + (size_t)n_win * sizeof(int32_t));
@@ -867,7 +874,7 @@ static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mel
 int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream) {
     if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     // resolve every frame's bank crop and mel window up front
     std::vector<const uint8_t*> fptr;
     std::vector<const float*> mptr;
@@ -932,7 +939,7 @@ int ltk_paste_back(ltk_engine* e, int avatar_id, int idx, const void* d_pred, vo
     }
     const Avatar& a = *ap;
     if (idx < 0 || idx >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const int32_t* c = a.coords.data() + 4 * (size_t)idx;
     const size_t bytes = (size_t)a.H * a.W * 3;
     StreamLease sl(e, stream);
@@ -964,7 +971,7 @@ int ltk_paste_back_batch(ltk_engine* e, int avatar_id, const int32_t* idx, const
     const Avatar& a = *ap;
     for (int i = 0; i < n; ++i)
         if (idx[i] < 0 || idx[i] >= a.n) return fail(LTK_E_INVALID, "frame index outside the bank");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const size_t bytes = (size_t)a.H * a.W * 3;
     StreamLease sl(e, stream);
     ScratchLease sc(e, bytes * n);
@@ -999,7 +1006,7 @@ int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6
     if (!e || !mel || !face6 || !pred || B <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
     if (B > e->max_frames) return fail(LTK_E_INVALID, "B exceeds max_frames");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const int mb = std::min(e->micro_batch, kPackMaxFrames);
     const int cap = std::min(B, mb);
     DevBuf d_mel, d_face, d_pred;
@@ -1050,7 +1057,7 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
     if (frames > e->max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     hipEvent_t t0, t1;
@@ -1111,7 +1118,7 @@ int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
     if (frames > e->micro_batch || frames > kPackMaxFrames) return fail(LTK_E_INVALID, "frames exceeds one arena pass");
     if (n_layers != (int)e->layers.size()) return fail(LTK_E_INVALID, "n_layers != ltk_wav2lip_layer_count");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     std::vector<hipEvent_t> evs(e->layers.size() + 1);
@@ -1147,7 +1154,7 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
                    int transposed, int out_pad, const float* scale, const float* shift,
                    const void* d_res, int relu, void* d_y, int iters, float* ms_avg) {
     if (!e || !d_x || !weight || !d_y) return fail(LTK_E_INVALID, "bad arguments");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     ConvPlan plan;
     std::string err;
     int rc = conv_plan_create(&plan, weight, Cin, Cout, kh, kw, sh, sw, ph, pw, transposed != 0, out_pad, scale, shift, &err, H * W);
@@ -1190,7 +1197,7 @@ int ltk_conv2d_fp8(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
                    const float* scale, const float* shift, float act_scale, const void* d_res, int act, void* d_y, int iters,
                    float* ms_avg) {
     if (!e || !d_x || !weight || !d_y) return fail(LTK_E_INVALID, "bad arguments");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     ConvPlan plan;
     std::string err;
     int rc = conv_plan_create(&plan, weight, Cin, Cout, 3, 3, 1, 1, 1, 1, false, 0, scale, shift, &err, H * W,
@@ -1248,7 +1255,7 @@ int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet
     if (max_frames < 1 || max_frames > 64) return fail(LTK_E_INVALID, "max_frames must be in [1, 64] for MuseTalk");
     std::lock_guard<std::mutex> g(e->mu);
     if (e->mt) return fail(LTK_E_STATE, "a MuseTalk model is already loaded in this engine");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     MtGraph* mg = mt_graph_new();
     mt_set_fp8(mg, e->mt_fp8, e->mt_fp8_ascale);
     const int rc = mt_build(mg, unet_sd, n_unet, vae_sd, n_vae, max_frames);
@@ -1299,7 +1306,7 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
         if (mask_offsets[i + 1] - mask_offsets[i] != (int64_t)(c[3] - c[1]) * (c[2] - c[0]) * 3)
             return fail(LTK_E_INVALID, "mask size does not match its crop box");
     }
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     auto ap = std::make_shared<MtAvatar>();
     MtAvatar& a = *ap;
     a.device = e->device;
@@ -1344,7 +1351,7 @@ static int mt_run_locked(ltk_engine* e, const float* d_feat, const PtrList64* fe
 int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* stream) {
     if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::vector<const float*> lptr, fptr;
     std::vector<uint8_t*> optr;
     std::vector<std::shared_ptr<MtAvatar>> hold;      // the banks stay alive until this call has synchronised
@@ -1415,7 +1422,7 @@ int ltk_paste_blend(ltk_engine* e, int avatar_id, int idx, const void* d_pred, v
         mask = a.d_masks + a.mask_off[idx];
         for (int k = 0; k < 4; ++k) { fb[k] = a.face_box[4 * idx + k]; cb[k] = a.crop_box[4 * idx + k]; }
     }
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     const size_t bytes = (size_t)H * W * 3;
     StreamLease sl(e, stream);
     if (out_is_device) {
@@ -1447,7 +1454,7 @@ struct ltk_egress {
 
 int ltk_egress_open(ltk_engine* e, int H, int W, ltk_egress** out) {
     if (!e || !out || H <= 0 || W <= 0) return fail(LTK_E_INVALID, "bad arguments");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     ltk_egress* s = new ltk_egress();
     s->H = H; s->W = W;
     const size_t bytes = (size_t)H * W * 3;
@@ -1463,7 +1470,7 @@ int ltk_egress_open(ltk_engine* e, int H, int W, ltk_egress** out) {
 
 int ltk_egress_close(ltk_engine* e, ltk_egress* s) {
     if (!e || !s) return fail(LTK_E_INVALID, "bad arguments");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     {
         std::lock_guard<std::mutex> g(s->mu);
         (void)hipFree(s->d_cache[0]); (void)hipFree(s->d_cache[1]); (void)hipFree(s->d_frame); (void)hipFree(s->d_out); (void)hipFree(s->d_wm);
@@ -1474,7 +1481,7 @@ int ltk_egress_close(ltk_engine* e, ltk_egress* s) {
 
 int ltk_egress_watermark(ltk_engine* e, ltk_egress* s, const uint8_t* mask, int x, int y, int w, int h, int b, int g, int r) {
     if (!e || !s) return fail(LTK_E_INVALID, "bad arguments");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> gd(s->mu);
     (void)hipFree(s->d_wm);
     s->d_wm = nullptr;
@@ -1493,7 +1500,7 @@ int ltk_egress_frame(ltk_engine* e, ltk_egress* s, const ltk_egress_req* q, uint
     const size_t bytes = (size_t)H * W * 3;
     if (q->format != LTK_FMT_BGR24 && q->format != LTK_FMT_I420) return fail(LTK_E_INVALID, "unknown output format");
     if (q->format == LTK_FMT_I420 && ((H | W) & 1)) return fail(LTK_E_INVALID, "I420 needs even frame dimensions");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> gs(s->mu);
     StreamLease sl(e, stream);
     const uint8_t* src = nullptr;
@@ -1569,7 +1576,7 @@ int ltk_egress_batch(ltk_engine* e, ltk_egress* s, int source, int avatar, const
     if (format != LTK_FMT_BGR24 && format != LTK_FMT_I420) return fail(LTK_E_INVALID, "unknown output format");
     if (format == LTK_FMT_I420 && ((H | W) & 1)) return fail(LTK_E_INVALID, "I420 needs even frame dimensions");
     if (source != LTK_SRC_WAV2LIP && source != LTK_SRC_MUSETALK) return fail(LTK_E_INVALID, "batch egress: Wav2Lip or MuseTalk frames only");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> gs(s->mu);
     std::shared_ptr<Avatar> hold_w;           // keep the bank alive until the stream has been synchronised below
     std::shared_ptr<MtAvatar> hold_m;
@@ -1630,7 +1637,7 @@ int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* 
     if (!e || !latents || !feat || B <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
     if (B > e->mt_max_frames) return fail(LTK_E_INVALID, "B exceeds max_frames");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = e->compute;
     CHK(hipMemcpyAsync(e->d_mt_lat, latents, (size_t)B * 8 * 1024 * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1666,7 +1673,7 @@ int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* 
 int ltk_musetalk_debug_get(ltk_engine* e, const char* name, int frames, float* out, size_t n_floats) {
     if (!e || !name || !out || frames <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     int C, ld, coff, H, W;
     f16* t = mt_named(e->mt, name, &C, &ld, &coff, &H, &W);
@@ -1697,7 +1704,7 @@ int ltk_musetalk_time_ops(ltk_engine* e, int frames, int iters, float* ms_per_op
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
     if (frames > e->mt_max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
     if (n_ops != mt_op_count(e->mt)) return fail(LTK_E_INVALID, "n_ops != ltk_musetalk_op_count");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     std::vector<hipEvent_t> evs((size_t)n_ops + 1);
     for (auto& ev : evs) CHK(hipEventCreate(&ev));
@@ -1723,7 +1730,7 @@ int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, 
     if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->mt) return fail(LTK_E_STATE, "ltk_musetalk_load has not been called");
     if (frames > e->mt_max_frames) return fail(LTK_E_INVALID, "frames exceeds max_frames");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
@@ -1748,7 +1755,7 @@ int ltk_whisper_load(ltk_engine* e, const ltk_named_tensor* encoder_sd, int n) {
     if (!e || !encoder_sd || n <= 0) return fail(LTK_E_INVALID, "bad arguments");
     std::lock_guard<std::mutex> g(e->mu);
     if (e->whisper) return fail(LTK_E_STATE, "a Whisper encoder is already loaded in this engine");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     MtGraph* wg = mt_graph_new();
     if (mt_build_whisper_graph(wg, encoder_sd, n)) {
         const std::string msg = mt_graph_error(wg);
@@ -1772,7 +1779,7 @@ int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, 
     if (!e || !pcm || !d_out || n_samples <= 0 || n_samples > 479000 || batch <= 0 || rows <= 0 || rows > 64)
         return fail(LTK_E_INVALID, "bad arguments");
     if (!e->whisper) return fail(LTK_E_STATE, "ltk_whisper_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     Ev done_ev;
     CHK(done_ev.create());
     const hipEvent_t done = done_ev.e;
@@ -1804,7 +1811,7 @@ int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, 
 int ltk_whisper_debug_get(ltk_engine* e, const char* name, float* out, size_t n_floats) {
     if (!e || !name || !out) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->whisper) return fail(LTK_E_STATE, "ltk_whisper_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     int C, ld, coff, H, W;
     f16* t = (std::string(name) == "input_features") ? mt_named(e->whisper, "input_features", &C, &ld, &coff, &H, &W) : mt_named(e->whisper, name, &C, &ld, &coff, &H, &W);
@@ -1825,7 +1832,7 @@ int ltk_vae_encoder_load(ltk_engine* e, const ltk_named_tensor* vae_sd, int n, i
     if (!e || !vae_sd || n <= 0 || max_faces < 1 || max_faces > 32) return fail(LTK_E_INVALID, "bad arguments (max_faces in [1,32])");
     std::lock_guard<std::mutex> g(e->mu);
     if (e->vae_enc) return fail(LTK_E_STATE, "a VAE encoder is already loaded in this engine");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     MtGraph* vg = mt_graph_new();
     if (mt_build_vae_encoder_graph(vg, vae_sd, n, 2 * max_faces)) {
         const std::string msg = mt_graph_error(vg);
@@ -1840,7 +1847,7 @@ int ltk_vae_encoder_load(ltk_engine* e, const ltk_named_tensor* vae_sd, int n, i
 int ltk_vae_encode_faces(ltk_engine* e, const uint8_t* faces_bgr, int nfaces, const float* noise, float* latents_out) {
     if (!e || !faces_bgr || !latents_out || nfaces <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->vae_enc) return fail(LTK_E_STATE, "ltk_vae_encoder_load has not been called");
-    CHK(hipSetDevice(e->device));
+    CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = e->compute;
     uint8_t* d_faces = nullptr;

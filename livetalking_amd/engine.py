@@ -35,12 +35,21 @@ class Engine:
         self.max_frames = 0
         self._closed = False
         self._lock = threading.Lock()
+        self._egress_open = set()       # egress sessions still open: closed with the engine
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
+        """Destroys the engine.  The handle is dropped with it: a later call on this object (a session's finalizer, a
+        straggling paste) reaches the C ABI with a null engine and gets LTK_E_INVALID instead of touching freed memory."""
         if not self._closed:
             self._closed = True
-            self._lib.ltk_engine_destroy(self._h)
+            for sess in list(self._egress_open):
+                try:
+                    self.egress_close(sess)
+                except Exception:
+                    pass
+            h, self._h = self._h, None
+            self._lib.ltk_engine_destroy(h)
 
     def __del__(self):
         try:
@@ -192,11 +201,17 @@ class Engine:
     def egress_open(self, H: int, W: int) -> int:
         h = C.c_void_p()
         _lib.check(self._lib.ltk_egress_open(self._h, int(H), int(W), C.byref(h)))
+        with self._lock:
+            self._egress_open.add(h.value)
         return h.value
 
     def egress_close(self, session: int) -> None:
-        if self._h:
-            _lib.check(self._lib.ltk_egress_close(self._h, C.c_void_p(session)))
+        """No-op on a session this engine no longer holds (closed already, or closed with the engine)."""
+        with self._lock:
+            if not self._h or session not in self._egress_open:
+                return
+            self._egress_open.discard(session)
+        _lib.check(self._lib.ltk_egress_close(self._h, C.c_void_p(session)))
 
     def egress_watermark(self, session: int, mask, x: int = 0, y: int = 0, color=(128, 128, 128)) -> None:
         if mask is None:

@@ -220,3 +220,33 @@ def test_egress_batch_equals_per_frame_and_oracle(engine, fmt):
     assert np.array_equal(np.asarray(outs[1]), keep)
     eg.close()
     engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
+def test_engine_closed_before_its_sessions_fails_cleanly():
+    """A session's finalizer (MuseReal's batched-paste egress, a DeviceEgress held by a render thread) may run after the
+    engine was closed: the late calls must come back as LtkError / no-ops, not touch the freed engine, and must not
+    leave a stale HIP error behind for the next engine's first launch on this thread."""
+    from livetalking_amd._lib import LtkError
+    from livetalking_amd.egress import SRC_HOST, DeviceEgress
+    from livetalking_amd.engine import Engine
+
+    sd = synth.wav2lip_state_dict(5)
+    e1 = Engine(0)
+    e1.load_wav2lip(sd, max_frames=4)
+    eg = DeviceEgress(e1, 64, 96, SRC_HOST, 0, fmt="bgr24", watermark=None)
+    e1.close()
+    eg.close()                      # no-op: the engine closed the session with itself
+    eg.close()
+    with pytest.raises(LtkError):
+        e1.sync()
+    with pytest.raises(LtkError):
+        e1.egress_open(64, 96)
+
+    e2 = Engine(0)                  # the next engine's first launches see a clean error state
+    e2.load_wav2lip(sd, max_frames=4)
+    mel = np.zeros((2, 80, 16), np.float32)
+    face = np.zeros((2, 6, 256, 256), np.float32)
+    out = e2.wav2lip_forward_host(mel, face)
+    assert out.shape[0] == 2
+    e2.close()
