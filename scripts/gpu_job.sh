@@ -21,10 +21,13 @@ bench)
   timeout 600 python bench.py "$@" > $O/bench_${TAG:-default}.json 2> $O/bench_${TAG:-default}.err; tail -c 1500 $O/bench_${TAG:-default}.json ;;
 profile)
   TAG=${1:-r03}; P=$O/$TAG; mkdir -p $P
-  timeout 900 python bench.py --steps 50 --warmup 5 > $P/bench_default.json 2> $P/bench_default.err; head -c 400 $P/bench_default.json; echo
+  # ONLY="w2l": re-profile just the named workloads (no default bench run), e.g. after a change that touches one of them
+  ONLY=${ONLY:-}
+  want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }
+  if [ -z "$ONLY" ]; then timeout 900 python bench.py --steps 50 --warmup 5 > $P/bench_default.json 2> $P/bench_default.err; head -c 400 $P/bench_default.json; echo; fi
   cd /tmp && export TMPDIR=/tmp
   prof() {   # prof <name> <bench args...>: kernel trace + FETCH / WRITE / SQ / L2 counter passes, each its own run
-    local n=$1; shift; local CMD="python $R/bench.py $* --no-cpu-baseline --no-also --no-traffic"
+    local n=$1; shift; want $n || return 0; local CMD="python $R/bench.py $* --no-cpu-baseline --no-also --no-traffic"
     timeout 400 rocprofv3 --kernel-trace --stats -d $P/${n}_trace -o r -- $CMD > $P/${n}_trace.log 2>&1
     timeout 400 rocprofv3 --pmc FETCH_SIZE -d $P/${n}_pmc_fetch -o r -- $CMD > $P/${n}_pmc_fetch.log 2>&1
     timeout 400 rocprofv3 --pmc WRITE_SIZE -d $P/${n}_pmc_write -o r -- $CMD > $P/${n}_pmc_write.log 2>&1
@@ -37,14 +40,14 @@ profile)
   prof w2l256 --sessions 16 --steps 3 --warmup 1
   prof mt --model musetalk --steps 2 --warmup 1
   prof mtfp8 --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1
-  timeout 400 rocprofv3 --kernel-trace --stats -d $P/mt12_trace -o r -- python $R/bench.py --model musetalk --steps 11 --warmup 1 --no-cpu-baseline > $P/mt12_trace.log 2>&1
+  want mt12 && timeout 400 rocprofv3 --kernel-trace --stats -d $P/mt12_trace -o r -- python $R/bench.py --model musetalk --steps 11 --warmup 1 --no-cpu-baseline > $P/mt12_trace.log 2>&1
   cd $R; S=$O/${TAG}_summary; mkdir -p $S
-  python scripts/make_profile_summary.py $P $S/$TAG --name w2l --frames 16 --cmd "bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic  (wav2lip256, 1 session, 16-frame batch)" > /dev/null
-  python scripts/make_profile_summary.py $P $S/$TAG --name w2l256 --frames 256 --cmd "bench.py --sessions 16 --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-traffic  (16 sessions, 256-frame passes)" > /dev/null
-  python scripts/make_profile_summary.py $P $S/$TAG --name mt --all-kernels --frames 16 --cmd "bench.py --model musetalk --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
-  python scripts/make_profile_summary.py $P $S/$TAG --name mtfp8 --all-kernels --frames 64 --cmd "bench.py --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
-  python scripts/prof_report.py $P/mt12_trace 2>/dev/null | grep -E "^kernel|amd_rocclr|gn_|conv3_kernel<1, 2, 4" | head -12 > $S/${TAG}_mt12_blits.txt
-  cp $P/bench_default.json $S/${TAG}_bench_default.json
+  want w2l && python scripts/make_profile_summary.py $P $S/$TAG --name w2l --frames 16 --cmd "bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-traffic  (wav2lip256, 1 session, 16-frame batch)" > /dev/null
+  want w2l256 && python scripts/make_profile_summary.py $P $S/$TAG --name w2l256 --frames 256 --cmd "bench.py --sessions 16 --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-traffic  (16 sessions, 256-frame passes)" > /dev/null
+  want mt && python scripts/make_profile_summary.py $P $S/$TAG --name mt --all-kernels --frames 16 --cmd "bench.py --model musetalk --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
+  want mtfp8 && python scripts/make_profile_summary.py $P $S/$TAG --name mtfp8 --all-kernels --frames 64 --cmd "bench.py --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1 --no-cpu-baseline" > /dev/null
+  want mt12 && python scripts/prof_report.py $P/mt12_trace 2>/dev/null | grep -E "^kernel|amd_rocclr|gn_|conv3_kernel<1, 2, 4" | head -12 > $S/${TAG}_mt12_blits.txt
+  [ -z "$ONLY" ] && cp $P/bench_default.json $S/${TAG}_bench_default.json
   rm -rf $P
   ls $P ;;
 layers)
