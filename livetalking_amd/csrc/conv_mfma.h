@@ -151,6 +151,18 @@ void rowgemm_plan_destroy(RowGemmPlan* p);
 int rowgemm_launch(const RowGemmPlan& p, const f16* x, int x_ld, int x_coff, f16* y, int y_ld, int y_coff, int M, int relu,
                    hipStream_t stream, std::string* err);
 
+// rowconv (rowgemm.hip): k x k convolutions on maps of <= 8 x 8 output pixels as the same weight-streaming GEMM, the im2col rows
+// gathered on the fly; the plan is a RowGemmPlan over W_eff[j][tap * C + c] (tap = ky * k + kx).  Launches of up to kRowConvMaxRows
+// output pixels (frames x Ho x Wo).
+constexpr int kRowConvMaxRows = 2048;
+struct RowConvIO {
+    const f16* x = nullptr; int x_ld = 0, x_coff = 0, H = 0, W = 0;      // input map [N][x_ld/16][H][W][16]
+    f16* y = nullptr; int y_ld = 0, y_coff = 0, Ho = 0, Wo = 0;
+    const f16* res = nullptr; int res_ld = 0, res_coff = 0;              // residual with the output's geometry, or nullptr
+    int N = 0, KW = 3, stride = 1, pad = 1, relu = 1;
+};
+int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream, std::string* err);
+
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;
 struct FacePtrs;

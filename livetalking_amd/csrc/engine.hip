@@ -131,6 +131,8 @@ struct Layer {
     ConvPlan plan;
     RowGemmPlan rg;                 // set for the layers whose input and output maps are one pixel per frame (rowgemm.hip)
     int rg_y_ld = 0;               // output row pitch of that GEMM (the 1x1-expand layer writes k*k*Cout contiguous channels)
+    bool rowconv = false;          // `rg` is a rowconv plan instead: 3x3 conv on a map of <= 8 x 8 output pixels (rowgemm.hip)
+    int rc_stride = 1;
     int cin_real = 0;
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
     int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
@@ -341,7 +343,8 @@ const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& n
 // `hint_hw`: pixels per image of the layer's input map.  `flat_ld` > 0: the k x k "valid" conv that collapses a
 // k x k map to 1x1 (face_encoder_blocks.7.0) is run as a 1x1 conv over the map viewed as ONE pixel of
 // k*k*cin channels (a channel-blocked k x k map is contiguous per channel block).
-int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0) {
+// `map_w` > 0: the input map is map_w x map_w (face encoder / decoder): 3x3 layers whose OUTPUT map is at most 8 x 8 also get a rowconv plan.
+int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0) {
     const std::string p = d.prefix;
     const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
     const float* w = find_tensor(sd, n, p + ".conv_block.0.weight", wcount);
@@ -427,6 +430,19 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
             rc = rowgemm_plan_create(&L->rg, we.data(), J, K, se.data(), fe.data(), &err);
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rg_y_ld = (d.transposed ? J : 0);
+        } else if (flat_ld == 0 && map_w > 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) &&
+                   map_w % d.sh == 0 && map_w / d.sh <= 8 && (d.cin == 256 || d.cin == 512) && d.cout % 256 == 0) {
+            // 3x3 conv whose output map is at most 8 x 8: W_eff[j][tap * Cin + c], tap = ky * 3 + kx (`w` carries the folded identity
+            // of a residual layer, exactly as the conv3 plan above does)
+            J = d.cout; K = 9 * d.cin;
+            we.assign((size_t)J * K, 0.f);
+            for (int co = 0; co < d.cout; ++co)
+                for (int ci = 0; ci < d.cin; ++ci)
+                    for (int t = 0; t < 9; ++t) we[(size_t)co * K + (size_t)t * d.cin + ci] = w[((size_t)co * d.cin + ci) * 9 + t];
+            rc = rowgemm_plan_create(&L->rg, we.data(), J, K, sc.data(), sf.data(), &err);
+            if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+            L->rowconv = true;
+            L->rc_stride = d.sh;
         }
     }
     if (!d.transposed && d.k == 7 && d.cin == 6 && d.cout == 16 && d.sh == 1 && d.pad == 3 && knob(K_CONV7) && !e->c7) {
@@ -496,7 +512,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             // the 4x4 "valid" conv on the 4x4 map: a 1x1 conv over the flattened map (needs in_ld % 64 == 0)
             const bool flat = !bl.d.transposed && bl.d.pad == 0 && bl.d.k > 1 && bl.d.k == H && bl.d.k == W &&
                               bl.d.cin % 64 == 0 && !knob(K_NO_FLATTEN);
-            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, flat ? in_ld : 0))) return rc;
+            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, flat ? in_ld : 0, H == W ? W : 0))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
             if (flat) {
                 L.Ho = 1; L.Wo = 1;
@@ -526,7 +542,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             const BlockLayer& bl = kFaceDec[li];
             const bool last = (li + 1 == nl) || kFaceDec[li + 1].block != bl.block;
             Layer L;
-            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W))) return rc;
+            if ((rc = build_layer(e, bl.d, sd, n, &L, H * W, 0, H == W ? W : 0))) return rc;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = in_coff; L.H = H; L.W = W;
             L.plan.out_dims(H, W, &L.Ho, &L.Wo);
             if (last) {
@@ -624,7 +640,15 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
             rc = conv7_launch(e->c7, faces, e->buf[B_X0], nf, e->buf[L.out_buf], L.out_ld, L.out_coff, s, &err);
         // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
         // output element whatever the launch's frame count (larger launches run these layers on conv3)
-        else if (L.rg.d_w && nf <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK))
+        else if (L.rowconv && L.rg.d_w && (long long)nf * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK)) {
+            // 3x3 layers on the 4x4 / 8x8 maps: the same weight-streaming GEMM over gathered im2col rows (same LTK_SPLITK=0 rule)
+            RowConvIO rio;
+            rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;
+            rio.y = io.y; rio.y_ld = L.out_ld; rio.y_coff = L.out_coff; rio.Ho = L.Ho; rio.Wo = L.Wo;
+            rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
+            rio.N = nf; rio.KW = 3; rio.stride = L.rc_stride; rio.pad = 1; rio.relu = 1;
+            rc = rowconv_launch(L.rg, rio, on_aux ? e->aux : s, &err);
+        } else if (!L.rowconv && L.rg.d_w && nf <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK))
             rc = rowgemm_launch(L.rg, e->buf[L.in_buf], L.in_ld, L.in_coff, e->buf[L.out_buf], L.rg_y_ld ? L.rg_y_ld : L.out_ld, L.out_coff, nf, 1,
                                 on_aux ? e->aux : s, &err);
         else

@@ -103,6 +103,146 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(const RowGemmArgs a) {
     *reinterpret_cast<f16x4*>(a.y + (size_t)fr * a.y_ld + a.y_coff + j0) = o;
 }
 
+// ------------------------------------------------------------------------------------------
+// rowconv: the same weight-streaming GEMM for the 3x3 convolutions on the 4x4 and 8x8 maps (face_encoder_blocks.5.* / 6.*,
+// face_decoder_blocks.1.1 / 2.1: wav2lip_v2.py:32-36,63-66), whose 16-frame launches have only 256 / 1024 output pixels behind
+// 4.7 MB of weights each: rows = output pixels (frame, oy, ox), K = (tap, channel) with the im2col row of a pixel GATHERED from the
+// channel-blocked input map on the fly (16 bytes = 8 channels of one input pixel per lane and k-step, zeros outside the map: the
+// activations of these layers are 0.26 - 1 MB and live in L2).  A block owns 32 output channels x 16*FT rows and all of K; its 8
+// waves split K, stream the weight fragments HBM -> registers and meet in LDS in wave order (deterministic).  Blocks that share
+// weights (same 32 channels, different rows) sit on ONE XCD, so every weight byte leaves HBM once.  conv3 ran these layers as
+// 128..256 items of 4..8 chunks each behind a two-stage DMA pipe + a split-K finish launch: 18-22 us for ~2 us of work.
+struct RowConvArgs {
+    const f16* x; int x_cbt, x_cb0;       // input  [N][x_cbt][H*W][16], this tensor's first channel block
+    f16* y; int y_cbt, y_cb0;             // output [N][y_cbt][Ho*Wo][16]
+    const f16* res; int res_cbt, res_cb0; // residual (same geometry as y) or nullptr
+    const f16* w;                         // packed [J/16][K/32][64][8], K = taps * C ordered (tap, channel)
+    const float* scale; const float* shift;
+    int N, H, W, Ho, Wo, S, pad, KW;      // KW: kernel width (taps = KW * KW)
+    int cpt_log2;                         // log2(C / 32): k-steps per tap
+    int KT;                               // k-steps: taps * C / 32
+    int M;                                // rows: N * Ho * Wo
+    int NR;                               // row groups (16 * FT rows each)
+    int relu;
+};
+
+// FT: 16-row tiles per block; UB: k-steps in flight per trip.  Measured (profiles/r03_rowconv_ab.txt): deeper trips (9 / 6 steps), 32-row
+// blocks at every size and two resident blocks per CU (<= 128 VGPRs) are all equal or slower than <2, 6> up to 512 row tiles x channel
+// pairs and <4, 4> above.
+template <int FT, int UB>
+__global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
+    constexpr int JT = 2;                                      // 32 output channels per block
+    __shared__ f32x4 red[8][FT][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: hardware block b runs on XCD b & 7; all row groups of a channel pair share their weights through that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int jb = xcd + 8 * (slot / a.NR), rg = slot % a.NR;  // host: (J / 32) % 8 == 0
+    const int per = (a.KT + 7) >> 3;
+    const int k0 = wave * per, k1 = min(a.KT, k0 + per);
+    const int i16 = lane & 15, g = lane >> 4;
+    const f16x8* wp = reinterpret_cast<const f16x8*>(a.w) + ((size_t)(jb * JT) * a.KT) * 64 + lane;
+    const size_t wj = (size_t)a.KT * 64;                       // fragments between the block's two 16-channel slabs
+    const int HWi = a.H * a.W, HWo = a.Ho * a.Wo;
+    // this lane's row of each 16-row tile: frame, top-left input pixel of its window
+    int iy0[FT], ix0[FT];
+    const f16* xn[FT];
+    bool live[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        const int r = (rg * FT + ft) * 16 + i16;
+        live[ft] = r < a.M;
+        const int rr = live[ft] ? r : 0;
+        const int n = rr / HWo, pix = rr - n * HWo;
+        const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+        iy0[ft] = oy * a.S - a.pad; ix0[ft] = ox * a.S - a.pad;
+        // channel block (g >> 1) and half (g & 1) of the k-step's 32 channels belong to this lane
+        xn[ft] = a.x + (((size_t)n * a.x_cbt + a.x_cb0 + (g >> 1)) * HWi) * 16 + (g & 1) * 8;
+    }
+    f32x4 acc[JT][FT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) acc[jt][ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int cmask = (1 << a.cpt_log2) - 1;
+    // operand of k-step k for row tile ft: tap = k >> cpt_log2 (wave-uniform), 32 channels from (k & cmask) * 32
+    auto xload = [&](int k, int ft) -> f16x8 {
+        const int tap = k >> a.cpt_log2, cc = k & cmask;
+        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+        const int iy = iy0[ft] + ky, ix = ix0[ft] + kx;
+        const bool ok = live[ft] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        return ok ? *reinterpret_cast<const f16x8*>(xn[ft] + ((size_t)(cc * 2) * HWi + iy * a.W + ix) * 16) : zero;
+    };
+    // One trip = U k-steps: all of its loads in flight, then its MFMAs.  hipcc waits for a trip's loads before its MFMAs and issues
+    // the next trip's loads behind them, so a wave pays one round trip per trip.  A two-set software pipeline (the loads of trip
+    // t+1 issued before the MFMAs of trip t; every load unconditional - zero page for taps outside the map - so that the counted
+    // vmcnt waits really leave the newer set outstanding, checked in the ISA) was built and is 1.5 - 4 us SLOWER per layer
+    // (profiles/r03_rowconv_ab.txt): with ~200 VGPRs and dead trips it loses more than the overlap returns.
+    auto trip = [&](int kt, auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        f16x8 wa[U][JT], xb[U][FT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) wa[u][jt] = wp[jt * wj + (size_t)(kt + u) * 64];      // shared with the XCD's other row groups: cached
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) xb[u][ft] = xload(kt + u, ft);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft)
+                    acc[jt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][jt], xb[u][ft], acc[jt][ft], 0, 0, 0);
+    };
+    int kt = k0;
+    for (; kt + UB <= k1; kt += UB) trip(kt, std::integral_constant<int, UB>{});
+    for (; kt + 2 <= k1; kt += 2) trip(kt, std::integral_constant<int, 2>{});
+    for (; kt < k1; ++kt) trip(kt, std::integral_constant<int, 1>{});
+
+    // ---- the 8 partial tiles meet in LDS, one 16-channel slab at a time; wave ft finishes row tile ft in wave order (deterministic)
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        if (jt) __syncthreads();                               // every finishing wave has read the previous slab
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) red[wave][ft][lane] = acc[jt][ft];
+        __syncthreads();
+        if (wave < FT) {
+            const int ft = wave;
+            f32x4 s = red[0][ft][lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const f32x4 t = red[w][ft][lane];
+                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            }
+            // D layout of the 16x16 MFMA: lane holds output channels 4g .. 4g+3 of row i16
+            const int r = (rg * FT + ft) * 16 + i16;
+            if (r < a.M) {
+                const int n = r / HWo, pix = r - n * HWo;
+                const int cb = jb * JT + jt;                   // 16-channel block of the output
+                const int j0 = cb * 16 + 4 * g;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + j0), sf = *reinterpret_cast<const f32x4*>(a.shift + j0);
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = s[q] * sc[q] + sf[q];
+                if (a.res) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4*>(a.res + (((size_t)n * a.res_cbt + a.res_cb0 + cb) * HWo + pix) * 16 + 4 * g);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += (float)rv[q];
+                }
+                f16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = (f16)(a.relu ? __builtin_amdgcn_fmed3f(v[q], 0.f, 65504.f) : __builtin_amdgcn_fmed3f(v[q], -65504.f, 65504.f));
+                *reinterpret_cast<f16x4*>(a.y + (((size_t)n * a.y_cbt + a.y_cb0 + cb) * HWo + pix) * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
 int rowgemm_plan_create(RowGemmPlan* p, const float* w_eff, int J, int K, const float* scale, const float* shift, std::string* err) {
     *p = RowGemmPlan();
     if (J % 16 || K % 32) { if (err) *err = "rowgemm: J % 16 == 0 and K % 32 == 0"; return -1; }
@@ -145,6 +285,35 @@ int rowgemm_launch(const RowGemmPlan& p, const f16* x, int x_ld, int x_coff, f16
     if (M <= 16) hipLaunchKernelGGL(rowgemm_kernel<1>, dim3((unsigned)(p.J / 16)), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL(rowgemm_kernel<2>, dim3((unsigned)(p.J / 16)), dim3(512), 0, stream, a);
     if (hipGetLastError() != hipSuccess) { if (err) *err = "rowgemm: launch failed"; return -2; }
+    return 0;
+}
+
+int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream, std::string* err) {
+    const int taps = io.KW * io.KW;
+    if (!p.d_w || io.N <= 0 || taps <= 0 || p.K % taps) { if (err) *err = "rowconv: no plan / bad tap count"; return -1; }
+    const int C = p.K / taps;
+    int cl = 0;
+    while ((32 << cl) < C) ++cl;
+    if ((32 << cl) != C || p.J % 256) { if (err) *err = "rowconv: channels must be 32 * 2^n, output channels a multiple of 256"; return -1; }
+    if (((io.x_ld | io.x_coff | io.y_ld | io.y_coff | io.res_ld | io.res_coff) & 15) || io.x_coff + C > io.x_ld || io.y_coff + p.J > io.y_ld) {
+        if (err) *err = "rowconv: channel pitch / offset"; return -1;
+    }
+    const long long M = (long long)io.N * io.Ho * io.Wo;
+    if (M > kRowConvMaxRows) { if (err) *err = "rowconv: more rows than it is built for"; return -1; }
+    RowConvArgs a;
+    a.x = io.x; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
+    a.y = io.y; a.y_cbt = io.y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
+    a.res = io.res; a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
+    a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.pad = io.pad; a.KW = io.KW;
+    a.cpt_log2 = cl; a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
+    const int tiles = (int)((M + 15) / 16);
+    const int FT = tiles * (p.J / 32) <= 512 ? 2 : 4;          // ~2 blocks per CU's worth of row groups before the tiles grow
+    a.NR = (tiles + FT - 1) / FT;
+    const unsigned grid = (unsigned)((p.J / 32) * a.NR);       // (J / 32) % 8 == 0: the XCD mapping of the kernel covers it exactly
+    if (FT == 2) hipLaunchKernelGGL((rowconv_kernel<2, 6>), dim3(grid), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((rowconv_kernel<4, 4>), dim3(grid), dim3(512), 0, stream, a);
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "rowconv: launch failed"; return -2; }
     return 0;
 }
 

@@ -34,6 +34,8 @@ enum Knob {
     K_FP8_MX,             // LTK_FP8_MX         fp8 convs on the MX-scaled MFMA (32x32x64, 2x MAC rate): 1 = where it wins (Cin >= 512:
                           //                    its 64-channel chunks leave one block per CU, which only deep K loops repay), 2 = all, 0 = none
     K_ROWGEMM,            // LTK_ROWGEMM        1: the one-pixel-map layers of a <= 32-frame launch as skinny GEMMs (rowgemm.hip) instead of conv3 + split-K finish
+    K_ROWCONV,            // LTK_ROWCONV        the 3x3 layers on the 4x4 / 8x8 maps as weight-streaming GEMMs over gathered rows (rowgemm.hip rowconv) when the
+                          //                    launch has at most this many output pixels (frames x Ho x Wo); 0 = never
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
     K_COUNT
 };

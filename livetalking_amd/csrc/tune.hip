@@ -19,6 +19,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_MICROBATCH", 0},     {"LTK_MT_NO_QKV_FUSE", 0},  {"LTK_HEAD_FUSED", 1},
     {"LTK_CONV3_NC8", 0},      {"LTK_TILE_RULE", 1},       {"LTK_TILE_TABLE", 1},        {"LTK_CONV7", 1},           {"LTK_ATTN_WIDE", 1},       {"LTK_UPS4", 1},            {"LTK_FP8_MX", 1},
     {"LTK_ROWGEMM", 1},
+    {"LTK_ROWCONV", 1024},
     {"LTK_ABLATE", 0},
 };
 

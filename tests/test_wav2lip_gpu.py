@@ -168,6 +168,36 @@ def test_fused_head_vs_separate_head(engine, golden_dir):
 
 
 @pytest.mark.gpu
+def test_rowconv_and_rowgemm_vs_conv3(engine, golden_dir):
+    """The small-map layers as weight-streaming GEMMs (csrc/rowgemm.hip: rowgemm for the one-pixel maps, rowconv for the 3x3 convs
+    on the 4x4 / 8x8 maps - knobs ROWGEMM / ROWCONV, both on by default) against the same layers on conv3 + split-K finish: another
+    summation order of the same fp16 products, so frames differ by at most 1 LSB, rarely, and are no further from the
+    reference's golden frames."""
+    from livetalking_amd.engine import Engine
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    aid = engine.register_avatar(faces, frames, coords)
+    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
+    out = {}
+    try:
+        for on in (1, 0):
+            Engine.set_knob("ROWCONV", 1024 if on else 0)
+            Engine.set_knob("ROWGEMM", on)
+            pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+            engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
+            out[on] = pred.cpu().numpy()
+    finally:
+        Engine.set_knob("ROWCONV", 1024)
+        Engine.set_knob("ROWGEMM", 1)
+    d = np.abs(out[1].astype(np.int32) - out[0].astype(np.int32))
+    print(f"[rowconv/rowgemm vs conv3] max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
+    assert d.max() <= 1 and float((d != 0).mean()) < 0.10
+    ref = g["ref_pred_u8"]
+    assert psnr_u8(out[1], ref) >= psnr_u8(out[0], ref) - 0.2
+    engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
 def test_forward_host_runs_as_arena_passes(golden_dir):
     """warm_up(batch_size) with an arena (LTK_MICROBATCH) smaller than the session batch: ltk_wav2lip_forward_host runs as
     several passes and returns what one pass returns (frames are independent; split-K off so the summation order is too)."""
