@@ -312,7 +312,7 @@ def run_wav2lip(args, ranks: Ranks):
                        "parallelism": f"session-sharded x{ranks.world} (no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
-                         "kernel": "conv3_kernel + conv_mfma_kernel (the 54 conv/convT layers + fused head = one pass)",
+                         "kernel": "conv3_kernel + conv_mfma_kernel + rowgemm / rowconv_kernel (the 54 conv/convT layers + fused head = one pass)",
                          "conv_stack_ms": round(conv_ms, 4), "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass},
             "per_rank_fps": [round(args.steps * frames_per_step / t, 1) for t in per_rank],
             "scheduler": sched,
@@ -685,7 +685,7 @@ def measure_traffic(sub, extra, passes, conv_only):
         for k, c, val in db.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
             if c != counter:
                 continue
-            if conv_only and "conv" not in k:
+            if conv_only and "conv" not in k and "rowgemm" not in k:       # conv7 / conv3 / conv_mfma / rowconv + rowgemm: the layer kernels
                 continue
             if not conv_only and ("__amd_rocclr" in k or "debug" in k):
                 continue

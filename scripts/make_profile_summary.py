@@ -79,7 +79,7 @@ def main():
             for r in rows[idx[-1]:]:
                 n = short(r[0])
                 f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{r[8]} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
-                if "conv" in n:
+                if "conv" in n or "rowgemm" in n:
                     conv_us += (r[2] - r[1]) / 1e3
                 nlaunch = nlaunch + 1 if "nlaunch" in dir() else 1
                 if "head_kernel" in n:
@@ -90,7 +90,7 @@ def main():
     write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
     sq = counters(os.path.join(sub("pmc_sq"), "r_results.db"))
     l2 = counters(os.path.join(sub("pmc_l2"), "r_results.db"))
-    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else k.startswith("conv"))]
+    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else k.startswith(("conv", "rowconv", "rowgemm")))]
     blits = {k: stats[k][0] for k in stats if "__amd_rocclr" in k}
     rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
     wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024
