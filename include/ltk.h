@@ -263,11 +263,16 @@ int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats)
  * knobs that shape a plan (weight pack order) only affect plans created afterwards. */
 int ltk_debug_set_knob(const char* name, int value);
 
-/* Conv-stack only (no gather/pack, no head): used by bench.py to time the
- * dominant kernel family with HIP events.  Returns average milliseconds per
- * pass over `iters` passes of `frames` frames, and the number of conv/convT
- * MACs one pass executes (27,788,599,296 x frames for wav2lip256). */
+/* The device side of one ltk_wav2lip_infer pass, exactly as that call enqueues it (mel pack, conv stack with the bank gather
+ * and the output head fused, replayed from the captured hipGraph under knob GRAPH), on dummy inputs, timed with HIP events
+ * on the engine's compute stream: used by bench.py for `roofline.achieved`.  Returns average milliseconds per pass over
+ * `iters` passes of `frames` frames, and the number of conv/convT MACs one pass executes (27,788,599,296 x frames for
+ * wav2lip256). */
 int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass);
+
+/* Number of frame counts whose pass currently runs from a captured hipGraph (knob GRAPH; a frame count is captured the
+ * second time ltk_wav2lip_infer sees it).  Tests and bench.py use it to prove that the graph path is the one that ran. */
+int ltk_wav2lip_graph_count(ltk_engine* e);
 
 /* Per-layer view of the same pass (tuning / profiling): layer names in execution order (state_dict prefixes), the time
  * of every layer inside a whole pass on one stream (HIP events between consecutive launches, so a layer sees the cache

@@ -107,7 +107,7 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 // wav2lip_avatar.py:138,145 on the fp32 accumulators and writes the 3 bytes of every pixel to its frame's own output.
 struct HeadArgs {
     const float* w;                  // [3][32] weights, then [3] bias (fp32)
-    OutPtrs outs;                    // per frame: uint8 [256][256][3]
+    const OutPtrs* outs;             // DEVICE table, per frame: uint8 [256][256][3]
 };
 
 template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0>
@@ -497,7 +497,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             const float s0 = 1.f / (1.f + __expf(-(t0 + b0)));
             const float s1 = 1.f / (1.f + __expf(-(t1 + b1)));
             const float s2 = 1.f / (1.f + __expf(-(t2 + b2)));
-            unsigned char* const o = ok ? hd->outs.p[n] : nullptr;
+            unsigned char* const o = ok ? hd->outs->p[n] : nullptr;
             if (o && hh == 0) {      // float32 * 255 then truncation toward zero, as numpy astype(uint8) on [0,255]
                 unsigned char* q = o + (size_t)opx * 3;
                 q[0] = (unsigned char)(unsigned)(s0 * 255.f);
@@ -939,24 +939,17 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
-    static thread_local std::vector<const void*> configured;
-    if (std::find(configured.begin(), configured.end(), (const void*)k) == configured.end()) {
-        HIPCHK3(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured.push_back((const void*)k);
-    }
+    HIPCHK3((hipError_t)ensure_dyn_lds((const void*)k, 160 * 1024));
     a.nitems = (int)nblk;
     const int persist_blocks = knob(K_CONV_PERSIST);      // 0: one block per item
     const long long grid = (persist_blocks > 0 && nblk > persist_blocks) ? persist_blocks : nblk;
     if (head) {
         typedef void (*k3_head_t)(const K3Args, const HeadArgs);
         const k3_head_t kh = PXW == 4 ? (k3_head_t)conv3_head_kernel<4> : (k3_head_t)conv3_head_kernel<2>;
-        if (std::find(configured.begin(), configured.end(), (const void*)kh) == configured.end()) {
-            HIPCHK3(hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured.push_back((const void*)kh);
-        }
+        HIPCHK3((hipError_t)ensure_dyn_lds((const void*)kh, 160 * 1024));
         HeadArgs h;
         h.w = io.head_w;
-        h.outs = *reinterpret_cast<const OutPtrs*>(io.head_outs);
+        h.outs = reinterpret_cast<const OutPtrs*>(io.head_outs);
         hipLaunchKernelGGL(kh, dim3((unsigned)grid), dim3(256), lds, stream, a, h);
         HIPCHK3(hipGetLastError());
         return 0;

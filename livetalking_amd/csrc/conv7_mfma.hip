@@ -47,7 +47,7 @@ struct C7Args {
 };
 
 template <bool BANK>
-__global__ __launch_bounds__(256, 2) void conv7_kernel(const C7Args a, const FacePtrs faces) {
+__global__ __launch_bounds__(256, 2) void conv7_kernel(const C7Args a, const FacePtrs* __restrict__ faces) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv7_kernel(const C7Args a, const Fac
         const int ty0 = (t >> 2) * C7_TH, tx0 = (t & 3) * C7_TW;
         if (tile != (int)blockIdx.x) __syncthreads();           // everyone is out of the previous patch
         // ---- stage the (TH+6) x (TW+6) input patch, zero outside the image
-        const uint8_t* __restrict__ bank = BANK ? faces.p[n] : nullptr;
+        const uint8_t* __restrict__ bank = BANK ? faces->p[n] : nullptr;
         // (all C7_PWP columns: the zero eighth tap of the second MFMA reads up to column 71; 0 x garbage could be NaN)
         for (int i = tid; i < C7_PH * C7_PWP; i += 256) {
             const int py = i / C7_PWP, px = i - py * C7_PWP;
@@ -168,7 +168,7 @@ void conv7_plan_destroy(Conv7Plan* p) {
     delete p;
 }
 
-// faces != nullptr: BANK mode (uint8 crops); else PACKED mode from x0 (fp16 [N][256][256][8]).
+// faces != nullptr: BANK mode (uint8 crops; `faces` is a DEVICE table); else PACKED mode from x0 (fp16 [N][256][256][8]).
 int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N, f16* y, int y_ld, int y_coff, hipStream_t stream,
                  std::string* err) {
     if (!p || N <= 0 || N > kPackMaxFrames || ((y_ld | y_coff) & 15)) { if (err) *err = "conv7: bad arguments"; return -1; }
@@ -177,11 +177,9 @@ int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N
     a.N = N; a.y_cbt = y_ld >> 4; a.y_cb0 = y_coff >> 4; a.ntiles = N * 64;
     const int grid = std::min(a.ntiles, 512);            // 2 resident blocks per CU (180 VGPRs) walk the tile list
     if (faces) {
-        hipLaunchKernelGGL(conv7_kernel<true>, dim3(grid), dim3(256), C7_LDS, stream, a, *faces);
+        hipLaunchKernelGGL(conv7_kernel<true>, dim3(grid), dim3(256), C7_LDS, stream, a, faces);
     } else {
-        FacePtrs none;
-        memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(conv7_kernel<false>, dim3(grid), dim3(256), C7_LDS, stream, a, none);
+        hipLaunchKernelGGL(conv7_kernel<false>, dim3(grid), dim3(256), C7_LDS, stream, a, (const FacePtrs*)nullptr);
     }
     if (hipGetLastError() != hipSuccess) { if (err) *err = "conv7: launch failed"; return -2; }
     return 0;

@@ -123,7 +123,7 @@ struct ConvIO {
     int force_pxw = 0, force_nbt = 0, force_ksplit = 0;   // conv3: per-layer tile / split choice of the caller's table (0 = rule)
     const float* head_w = nullptr;     // conv3, 3x3 stride-1 layers of 32 output channels only: fuse the Wav2Lip output head
     const void* head_outs = nullptr;   // (1x1 conv 32->3 + sigmoid + uint8 truncation; wav2lip_v2.py:90-91): device [3][32]+[3]
-                                       // weights and an OutPtrs (misc_kernels.h) of per-frame uint8 [256][256][3] outputs; `y` unused
+                                       // weights and a DEVICE table (OutPtrs, misc_kernels.h) of per-frame uint8 [256][256][3] outputs; `y` unused
     float* partial = nullptr;      // split-K scratch (fp32 slabs) and its capacity in bytes; conv3 splits the
     size_t partial_cap = 0;        // channel loop of under-filled launches only when this is large enough
 };

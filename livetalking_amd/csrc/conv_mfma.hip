@@ -821,11 +821,7 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     if (!k) { if (err) *err = "no kernel instantiation for this launch"; return -1; }
     const long long nblk = (long long)p.nphase * a.tiles_n * a.tiles_y * a.tiles_x * a.n_ntiles;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
-    static thread_local std::vector<const void*> configured;
-    if (std::find(configured.begin(), configured.end(), (const void*)k) == configured.end()) {
-        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-        configured.push_back((const void*)k);
-    }
+    HIPCHK((hipError_t)ensure_dyn_lds((const void*)k, kLdsLimit));
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, stream, a);
     HIPCHK(hipGetLastError());
     return 0;

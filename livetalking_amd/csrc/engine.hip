@@ -248,6 +248,13 @@ struct ltk_engine {
     float* d_head = nullptr;          // 96 weights + 3 bias
     Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
     double macs_per_frame = 0;
+    DevTables* d_tab = nullptr;       // per-frame pointer tables of the pass being enqueued (misc_kernels.h), filled on the compute stream
+    // captured passes (knob GRAPH): one executable graph per frame count of the product configuration (bank crops in, fused head out);
+    // a frame count is captured the second time it is seen, the least recently used graph goes when the table is full
+    struct PassGraph { hipGraphExec_t exec = nullptr; int seen = 0; unsigned long stamp = 0; };
+    std::map<int, PassGraph> graphs;
+    unsigned graph_epoch = 0;         // knob_epoch() the graphs were captured under
+    unsigned long graph_clock = 0;
     // debug capture
     bool capture = false;
     std::map<std::string, std::vector<float>> taps;
@@ -344,7 +351,7 @@ const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& n
 // k x k map to 1x1 (face_encoder_blocks.7.0) is run as a 1x1 conv over the map viewed as ONE pixel of
 // k*k*cin channels (a channel-blocked k x k map is contiguous per channel block).
 // `map_w` > 0: the input map is map_w x map_w (face encoder / decoder): 3x3 layers whose OUTPUT map is at most 8 x 8 also get a rowconv plan.
-int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0) {
+int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw, int flat_ld, int map_w) {
     const std::string p = d.prefix;
     const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
     const float* w = find_tensor(sd, n, p + ".conv_block.0.weight", wcount);
@@ -398,7 +405,9 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
                               sc.data(), sf.data(), &err, hint_hw);
     }
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
-    // one pixel per frame on both sides: a plain GEMM with as many rows as frames (rowgemm.hip, used for launches of <= 32 frames)
+    // one pixel per frame on both sides: a plain GEMM with as many rows as frames (rowgemm.hip, used for launches of <= 32 frames).
+    // Not built (45 MB of duplicated weights) when the process starts with the paths switched off.
+    const bool want_rowgemm = knob(K_ROWGEMM) && knob(K_SPLITK), want_rowconv = knob(K_ROWCONV) > 0 && knob(K_SPLITK);
     {
         std::vector<float> we, se, fe;
         int J = 0, K = 0;
@@ -426,11 +435,13 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
                 se[j] = sc[co]; fe[j] = sf[co];
             }
         }
-        if (J > 0) {
+        if (J > 0 && !want_rowgemm) {
+            // conv3 + split-K finish serves the layer
+        } else if (J > 0) {
             rc = rowgemm_plan_create(&L->rg, we.data(), J, K, se.data(), fe.data(), &err);
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rg_y_ld = (d.transposed ? J : 0);
-        } else if (flat_ld == 0 && map_w > 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) &&
+        } else if (want_rowconv && flat_ld == 0 && map_w > 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) &&
                    map_w % d.sh == 0 && map_w / d.sh <= 8 && (d.cin == 256 || d.cin == 512) && d.cout % 256 == 0) {
             // 3x3 conv whose output map is at most 8 x 8: W_eff[j][tap * Cin + c], tap = ky * 3 + kx (`w` carries the folded identity
             // of a residual layer, exactly as the conv3 plan above does)
@@ -456,11 +467,27 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
 }
 
 
+// A Layer is pushed into e->layers only after it is complete: on a failure the device plans built so far go here (a failed load
+// that is retried would otherwise leak the packed weights each time)
+int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0) {
+    const int rc = build_layer_impl(e, d, sd, n, L, hint_hw, flat_ld, map_w);
+    if (rc) { conv_plan_destroy(&L->plan); rowgemm_plan_destroy(&L->rg); }
+    return rc;
+}
+
 void bump(size_t* cur, size_t v) { if (v > *cur) *cur = v; }
 
 // Everything ltk_wav2lip_load creates (layer plans, head weights, first-layer plan, activation arena): a failed load leaves
 // the engine as it found it, and can be retried.
+void drop_graphs(ltk_engine* e) {
+    for (auto& kv : e->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    e->graphs.clear();
+}
+
 void wav2lip_unload(ltk_engine* e) {
+    drop_graphs(e);
+    if (e->d_tab) { (void)hipFree(e->d_tab); e->d_tab = nullptr; }
     for (Layer& L : e->layers) { conv_plan_destroy(&L.plan); rowgemm_plan_destroy(&L.rg); }
     e->layers.clear();
     for (int i = 0; i < B_COUNT; ++i)
@@ -588,15 +615,17 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // Enqueue the 54 conv/convT layers for frames [0, nf) of the arena on `s`.  The audio encoder has no
 // dependency on the face encoder until decoder block 0 (wav2lip_v2.py:132-142): its 13 small launches run on
 // the aux stream beside the face encoder instead of in front of it.
-// `head_outs` != nullptr: the last layer (output_block.0) also applies the 1x1 head + sigmoid and writes the uint8 frames
-// (one launch and one 4 MB/frame round trip of the 32-channel map less); the caller then skips launch_head.
+// `head_outs` != nullptr (a DEVICE table): the last layer (output_block.0) also applies the 1x1 head + sigmoid and writes the
+// uint8 frames (one launch and one 4 MB/frame round trip of the 32-channel map less); the caller then skips launch_head.
 // `evs` != nullptr (measurement): everything on `s`, one event in front of every layer and one behind the last.
-// `faces` != nullptr: the first layer reads the uint8 bank crops itself (the caller then skips launch_pack_faces).
+// `faces` != nullptr (a DEVICE table): the first layer reads the uint8 bank crops itself (the caller then skips launch_pack_faces).
+// Knob DF_FRAMES > 0: the decoder blocks >= DF_BLOCK and the output conv run depth-first over sub-batches of that many frames
+// (all their layers for frames [f0, f0 + df), then the next sub-batch), so that a producer's output is still in the 256 MiB
+// Infinity Cache when its consumer reads it; every layer sees the same frames with the same weights, only the launch size changes.
 int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr,
               const FacePtrs* faces = nullptr) {
     std::string err;
     const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM) && !evs;
-    const int bucket = frame_bucket(nf);
     size_t evi = 0;
     bool joined = !fork;
     if (fork) {
@@ -617,50 +646,69 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
     } else {
         for (Layer& L : e->layers) order.push_back(&L);
     }
-    for (Layer* Lp : order) {
-        Layer& L = *Lp;
+    // one layer on frames [f0, f0 + n) of the arena
+    auto launch_layer = [&](Layer& L, int f0, int n, bool on_aux) -> int {
+        const int bucket = frame_bucket(n);
+        ConvIO io;
+        io.x = e->buf[L.in_buf] + (size_t)f0 * L.in_ld * L.H * L.W; io.N = n; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
+        io.y = e->buf[L.out_buf] + (size_t)f0 * L.out_ld * L.Ho * L.Wo; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
+        io.res = (L.residual && !L.res_folded) ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
+        io.relu = 1;
+        io.partial = on_aux ? e->d_partial_aux : e->d_partial;
+        io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;
+        if (head_outs && &L == &e->layers.back()) { io.head_w = e->d_head; io.head_outs = reinterpret_cast<const uint8_t* const*>(head_outs) + f0; }
+        if (knob(K_TILE_TABLE)) { io.force_pxw = L.tile[bucket].pxw; io.force_nbt = L.tile[bucket].nbt; io.force_ksplit = L.tile[bucket].ks; }
+        int rc;
+        if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
+            rc = conv7_launch(e->c7, faces ? reinterpret_cast<const FacePtrs*>(reinterpret_cast<const uint8_t* const*>(faces) + f0) : nullptr,
+                              e->buf[B_X0] + (size_t)f0 * 65536 * 8, n, io.y, L.out_ld, L.out_coff, s, &err);
+        // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
+        // output element whatever the launch's frame count (larger launches run these layers on conv3)
+        else if (L.rowconv && L.rg.d_w && (long long)n * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK)) {
+            // 3x3 layers on the 4x4 / 8x8 maps: the same weight-streaming GEMM over gathered im2col rows (same LTK_SPLITK=0 rule)
+            RowConvIO rio;
+            rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;
+            rio.y = io.y; rio.y_ld = L.out_ld; rio.y_coff = L.out_coff; rio.Ho = L.Ho; rio.Wo = L.Wo;
+            rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
+            rio.N = n; rio.KW = 3; rio.stride = L.rc_stride; rio.pad = 1; rio.relu = 1;
+            rc = rowconv_launch(L.rg, rio, on_aux ? e->aux : s, &err);
+        } else if (!L.rowconv && L.rg.d_w && n <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK) &&
+                   // the k x k expansion of a one-pixel map writes k*k*Cout contiguous columns per frame: only into a dense output
+                   // (a CAT buffer's skip channels would be overwritten)
+                   (L.rg_y_ld == 0 || (L.out_coff == 0 && L.out_ld * L.Ho * L.Wo == L.rg_y_ld)))
+            rc = rowgemm_launch(L.rg, io.x, L.in_ld, L.in_coff, io.y, L.rg_y_ld ? L.rg_y_ld : L.out_ld, L.out_coff, n, 1,
+                                on_aux ? e->aux : s, &err);
+        else
+            rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
+        if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
+        return 0;
+    };
+    // depth-first region: [df_first, end) of `order`
+    const int df = (!e->capture && !evs && nf >= std::max(1, knob(K_DF_MIN))) ? knob(K_DF_FRAMES) : 0;
+    size_t df_first = order.size();
+    if (df > 0 && df < nf) {
+        const std::string first_name = "face_decoder_blocks." + std::to_string(std::max(1, std::min(7, knob(K_DF_BLOCK)))) + ".0";
+        for (size_t i = 0; i < order.size(); ++i)
+            if (order[i]->name == first_name) { df_first = i; break; }
+    }
+    for (size_t oi = 0; oi < df_first; ++oi) {
+        Layer& L = *order[oi];
         const bool on_aux = fork && L.audio;
         if (!on_aux && !joined && !L.audio && L.in_buf >= B_AT0 && L.in_buf <= B_AT1 && L.name.rfind("face_decoder", 0) == 0) {
             CHK(hipEventRecord(e->ev_join, e->aux));
             CHK(hipStreamWaitEvent(s, e->ev_join, 0));
             joined = true;
         }
-        ConvIO io;
-        io.x = e->buf[L.in_buf]; io.N = nf; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
-        io.y = e->buf[L.out_buf]; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
-        io.res = (L.residual && !L.res_folded) ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
-        io.relu = 1;
-        io.partial = on_aux ? e->d_partial_aux : e->d_partial;
-        io.partial_cap = on_aux ? e->partial_aux_cap : e->partial_cap;
-        if (head_outs && Lp == &e->layers.back()) { io.head_w = e->d_head; io.head_outs = head_outs; }
-        if (knob(K_TILE_TABLE)) { io.force_pxw = L.tile[bucket].pxw; io.force_nbt = L.tile[bucket].nbt; io.force_ksplit = L.tile[bucket].ks; }
         if (evs) CHK(hipEventRecord((*evs)[evi++], s));
-        int rc;
-        if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
-            rc = conv7_launch(e->c7, faces, e->buf[B_X0], nf, e->buf[L.out_buf], L.out_ld, L.out_coff, s, &err);
-        // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
-        // output element whatever the launch's frame count (larger launches run these layers on conv3)
-        else if (L.rowconv && L.rg.d_w && (long long)nf * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK)) {
-            // 3x3 layers on the 4x4 / 8x8 maps: the same weight-streaming GEMM over gathered im2col rows (same LTK_SPLITK=0 rule)
-            RowConvIO rio;
-            rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;
-            rio.y = io.y; rio.y_ld = L.out_ld; rio.y_coff = L.out_coff; rio.Ho = L.Ho; rio.Wo = L.Wo;
-            rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
-            rio.N = nf; rio.KW = 3; rio.stride = L.rc_stride; rio.pad = 1; rio.relu = 1;
-            rc = rowconv_launch(L.rg, rio, on_aux ? e->aux : s, &err);
-        } else if (!L.rowconv && L.rg.d_w && nf <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK))
-            rc = rowgemm_launch(L.rg, e->buf[L.in_buf], L.in_ld, L.in_coff, e->buf[L.out_buf], L.rg_y_ld ? L.rg_y_ld : L.out_ld, L.out_coff, nf, 1,
-                                on_aux ? e->aux : s, &err);
-        else
-            rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
-        if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
+        const int rc = launch_layer(L, 0, nf, on_aux);
+        if (rc) return rc;
         if (e->capture) {
             const int C = L.plan.Cout;
             std::vector<float>& t = e->taps[L.name];
             t.resize((size_t)nf * C * L.Ho * L.Wo);
             float* d_tmp = nullptr;
             CHK(hipMalloc((void**)&d_tmp, t.size() * sizeof(float)));
-            launch_nhwc_to_nchw_f32(io.y, nf, L.Ho, L.Wo, L.out_ld, L.out_coff, C, d_tmp, s);
+            launch_nhwc_to_nchw_f32(e->buf[L.out_buf], nf, L.Ho, L.Wo, L.out_ld, L.out_coff, C, d_tmp, s);
             CHK(hipStreamSynchronize(s));
             CHK(hipMemcpy(t.data(), d_tmp, t.size() * sizeof(float), hipMemcpyDeviceToHost));
             CHK(hipFree(d_tmp));
@@ -671,6 +719,11 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         CHK(hipEventRecord(e->ev_join, e->aux));
         CHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
+    for (int f0 = 0; df_first < order.size() && f0 < nf; f0 += df)
+        for (size_t oi = df_first; oi < order.size(); ++oi) {
+            const int rc = launch_layer(*order[oi], f0, std::min(df, nf - f0), false);
+            if (rc) return rc;
+        }
     if (evs) CHK(hipEventRecord((*evs)[evi++], s));
     return 0;
 }
@@ -800,6 +853,8 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
         e->micro_batch = knob(K_MICROBATCH);
         if (e->micro_batch <= 0 || e->micro_batch > max_frames) e->micro_batch = max_frames;
         e->max_frames = max_frames;
+        if (hipMalloc((void**)&e->d_tab, sizeof(DevTables)) != hipSuccess) return fail(LTK_E_NOMEM, "pointer table allocation failed");
+        CHK(hipMemset(e->d_tab, 0, sizeof(DevTables)));
         const int arena_frames = e->micro_batch;
         for (int i = 0; i < B_COUNT; ++i) {
             if (!e->buf_halfs[i]) continue;
@@ -877,21 +932,76 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
     return LTK_OK;
 }
 
-static int infer_locked(ltk_engine* e, const FacePtrs* faces, const MelPtrs* mels, const float* d_face6, int nf,
-                        const OutPtrs* outs, float* d_pred_f32) {
-    hipStream_t s = e->compute;
-    const bool pack_fused = faces && e->c7 && knob(K_CONV7);     // the first layer reads the bank crops itself
-    if (faces) { if (!pack_fused) launch_pack_faces(*faces, nf, e->buf[B_X0], s); }
+// One pass over frames [0, nf) of the arena on `s`; the per-frame pointer tables are already in e->d_tab.
+// bank_faces: the faces table holds uint8 bank crops (else `d_face6`: float32 NCHW test input); have_outs: the outs table holds
+// the uint8 frame destinations; d_pred_f32 (test hook): float32 NCHW sigmoid output.
+static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool fused, bool have_outs,
+                        float* d_pred_f32) {
+    const FacePtrs* d_faces = &e->d_tab->faces;
+    const OutPtrs* d_outs = &e->d_tab->outs;
+    const bool pack_fused = bank_faces && e->c7 && knob(K_CONV7);     // the first layer reads the bank crops itself
+    if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
-    launch_pack_mel(*mels, nf, e->buf[B_MEL], s);
-    // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
-    const bool fused = outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
-    int rc = run_convs(e, nf, s, fused ? outs : nullptr, nullptr, pack_fused ? faces : nullptr);
+    launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);
+    const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, pack_fused ? d_faces : nullptr);
     if (rc) return rc;
     if (!fused) {
-        launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, outs, d_pred_f32, s);
+        launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, have_outs ? d_outs : nullptr, d_pred_f32, s);
         CHK(hipGetLastError());
     }
+    return 0;
+}
+
+constexpr size_t kMaxPassGraphs = 48;
+
+// enqueue_pass, replayed from a captured hipGraph where the pass has no per-call arguments: the product configuration (bank crops
+// in, fused head out) on the engine's own streams.  A frame count runs eagerly the first time it is seen (which also sets every
+// kernel's dynamic-LDS attribute) and is captured the second time; a dependent launch costs ~3.1 us on a stream and ~2.0 us inside a
+// graph (profiles/r03_ubench_launch_chain.txt), and the host issues one launch instead of ~70.  The audio-encoder branch on the aux
+// stream becomes a branch of the graph (its fork / join events are captured as dependencies).
+static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32) {
+    // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
+    const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
+    const bool graphable = knob(K_GRAPH) && bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
+    if (!graphable) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    if (e->graph_epoch != knob_epoch()) {           // a knob changed (tests, tuners): the captured launch sequences are stale
+        CHK(hipStreamSynchronize(s));
+        drop_graphs(e);
+        e->graph_epoch = knob_epoch();
+    }
+    ltk_engine::PassGraph& g = e->graphs[nf];
+    g.stamp = ++e->graph_clock;
+    if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); return 0; }
+    if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    size_t live = 0;
+    for (auto& kv : e->graphs) live += kv.second.exec ? 1 : 0;
+    if (live >= kMaxPassGraphs) {                       // least recently used out
+        auto victim = e->graphs.end();
+        for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
+            if (it->second.exec && (victim == e->graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
+        if (victim != e->graphs.end()) {
+            CHK(hipStreamSynchronize(s));               // it may still be running for the previous call
+            (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = ce;
+    if (ce == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess || !exec) {
+        // the pass still runs, launch by launch; say so once per frame count instead of failing the call
+        (void)hipGetLastError();
+        g.seen = -1;
+        fprintf(stderr, "ltk: hipGraph capture of the %d-frame pass failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
+        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    }
+    g.exec = exec;
+    CHK(hipGraphLaunch(exec, s));
     return 0;
 }
 
@@ -927,6 +1037,9 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
     const hipEvent_t done = done_ev.e;
     int rc = 0;
     {
+        // Calls of several host threads are serialised HERE only for the enqueue (stream order then keeps them apart on the GPU: one
+        // arena, one table); the lock is released before the wait, so the next call's launches queue up behind this one's kernels
+        // instead of behind this thread's wake-up (scheduler.py keeps two calls in flight).
         std::lock_guard<std::mutex> g(e->mu);
         if (stream) {  // inputs were produced on the caller's stream
             Ev ready;
@@ -939,7 +1052,9 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
             for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; op.p[i] = optr[f0 + i]; }
-            rc = infer_locked(e, &fp, &mp, nullptr, nf, &op, nullptr);
+            launch_upload_tables(&fp, &mp, &op, nf, e->d_tab, e->compute);
+            if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "pointer table upload failed");
+            else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr);
         }
         if (!rc) {
             if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
@@ -1045,7 +1160,9 @@ int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6
         for (int i = 0; i < nf; ++i) mp.p[i] = (float*)d_mel.p + (size_t)i * 1280;
         {
             std::lock_guard<std::mutex> g(e->mu);
-            const int rc = infer_locked(e, nullptr, &mp, (const float*)d_face.p, nf, nullptr, (float*)d_pred.p);
+            launch_upload_tables(nullptr, &mp, nullptr, nf, e->d_tab, e->compute);
+            CHK(hipGetLastError());
+            const int rc = launch_pass(e, nf, e->compute, false, (const float*)d_face.p, false, (float*)d_pred.p);
             if (rc) return rc;
             CHK(hipStreamSynchronize(e->compute));
         }
@@ -1077,6 +1194,26 @@ int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats)
     return LTK_OK;
 }
 
+// Dummy inputs of the timing hooks: every frame reads one zero bank crop and one zero mel window and writes its own scratch frame, so
+// that the hooks run the pass exactly as ltk_wav2lip_infer does (bank crops in, fused head out, captured graph included).
+namespace {
+struct TimingIO {
+    DevBuf face, mel, frames;
+    int setup(ltk_engine* e, int nf) {
+        CHK(hipMalloc(&face.p, 65536 * 3));
+        CHK(hipMemset(face.p, 0, 65536 * 3));
+        CHK(hipMalloc(&mel.p, 1280 * sizeof(float)));
+        CHK(hipMemset(mel.p, 0, 1280 * sizeof(float)));
+        CHK(hipMalloc(&frames.p, (size_t)nf * 65536 * 3));
+        FacePtrs fp; MelPtrs mp; OutPtrs op;
+        for (int i = 0; i < nf; ++i) { fp.p[i] = (const uint8_t*)face.p; mp.p[i] = (const float*)mel.p; op.p[i] = (uint8_t*)frames.p + (size_t)i * 65536 * 3; }
+        launch_upload_tables(&fp, &mp, &op, nf, e->d_tab, e->compute);
+        CHK(hipGetLastError());
+        return 0;
+    }
+};
+}  // namespace
+
 int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_pass, double* macs_per_pass) {
     if (!e || frames <= 0 || iters <= 0 || !ms_per_pass) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
@@ -1087,22 +1224,19 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
     CHK(hipEventCreate(&t1));
-    // the conv stack as ltk_wav2lip_infer runs it: with the output head fused into the last conv (knob HEAD_FUSED), frames
-    // going to a scratch buffer
+    // the pass as ltk_wav2lip_infer runs it (pack_mel + conv stack with the bank gather and the output head fused, knobs CONV7 /
+    // HEAD_FUSED; replayed from the captured graph under knob GRAPH), same micro-batch schedule, frames going to a scratch buffer
     const int mbs = std::min(e->micro_batch, kPackMaxFrames);
-    uint8_t* d_frames = nullptr;
-    OutPtrs op;
-    const bool fused = knob(K_HEAD_FUSED) != 0;
-    if (fused) {
-        CHK(hipMalloc((void**)&d_frames, (size_t)std::min(mbs, frames) * 65536 * 3));
-        for (int i = 0; i < kPackMaxFrames; ++i) op.p[i] = i < std::min(mbs, frames) ? d_frames + (size_t)i * 65536 * 3 : nullptr;
-    }
-    auto pass = [&]() -> int {   // the same micro-batch schedule ltk_wav2lip_infer uses
-        int rc = 0;
-        for (int f0 = 0; f0 < frames && !rc; f0 += mbs) rc = run_convs(e, std::min(mbs, frames - f0), e->compute, fused ? &op : nullptr);
-        return rc;
+    TimingIO tio;
+    int rc = tio.setup(e, std::min(mbs, frames));
+    if (rc) return rc;
+    auto pass = [&]() -> int {
+        int prc = 0;
+        for (int f0 = 0; f0 < frames && !prc; f0 += mbs) prc = launch_pass(e, std::min(mbs, frames - f0), e->compute, true, nullptr, true, nullptr);
+        return prc;
     };
-    int rc = pass();  // warm
+    rc = pass();              // warm (eager)
+    if (!rc) rc = pass();     // warm (captures the graph under knob GRAPH)
     if (rc) return rc;
     CHK(hipEventRecord(t0, e->compute));
     for (int i = 0; i < iters && !rc; ++i) rc = pass();
@@ -1112,10 +1246,17 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     float ms = 0.f;
     CHK(hipEventElapsedTime(&ms, t0, t1));
     *ms_per_pass = ms / iters;
-    if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - (fused ? 0.0 : 32.0 * 3 * 65536)) * frames;
+    if (macs_per_pass) *macs_per_pass = (e->macs_per_frame - (knob(K_HEAD_FUSED) ? 0.0 : 32.0 * 3 * 65536)) * frames;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    if (d_frames) (void)hipFree(d_frames);
     return LTK_OK;
+}
+
+int ltk_wav2lip_graph_count(ltk_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    int n = 0;
+    for (auto& kv : e->graphs) n += kv.second.exec ? 1 : 0;
+    return n;
 }
 
 int ltk_wav2lip_layer_count(ltk_engine* e) {
@@ -1134,6 +1275,9 @@ int ltk_wav2lip_set_layer_tile(ltk_engine* e, int layer, int bucket, int pxw, in
     std::lock_guard<std::mutex> g(e->mu);
     Layer::Tile& t = e->layers[layer].tile[bucket];
     t.pxw = (signed char)pxw; t.nbt = (signed char)nbt; t.ks = (signed char)ksplit;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->compute);
+    drop_graphs(e);                    // captured passes carry the old tile choice
     return LTK_OK;
 }
 
@@ -1147,17 +1291,16 @@ int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     std::vector<hipEvent_t> evs(e->layers.size() + 1);
     for (auto& ev : evs) CHK(hipEventCreate(&ev));
-    uint8_t* d_frames = nullptr;
-    OutPtrs op;
     const bool fused = knob(K_HEAD_FUSED) != 0;
-    if (fused) {
-        CHK(hipMalloc((void**)&d_frames, (size_t)frames * 65536 * 3));
-        for (int i = 0; i < kPackMaxFrames; ++i) op.p[i] = i < frames ? d_frames + (size_t)i * 65536 * 3 : nullptr;
-    }
+    TimingIO tio;
+    int rc = tio.setup(e, frames);
+    if (rc) return rc;
+    const OutPtrs* d_outs = fused ? &e->d_tab->outs : nullptr;
+    const FacePtrs* d_faces = (e->c7 && knob(K_CONV7)) ? &e->d_tab->faces : nullptr;
     std::vector<double> acc(e->layers.size(), 0.0);
-    int rc = run_convs(e, frames, e->compute, fused ? &op : nullptr);     // warm
+    rc = run_convs(e, frames, e->compute, d_outs, nullptr, d_faces);     // warm
     for (int it = 0; it < iters && !rc; ++it) {
-        rc = run_convs(e, frames, e->compute, fused ? &op : nullptr, &evs);
+        rc = run_convs(e, frames, e->compute, d_outs, &evs, d_faces);
         if (rc) break;
         CHK(hipEventSynchronize(evs.back()));
         for (size_t i = 0; i < e->layers.size(); ++i) {
@@ -1167,7 +1310,6 @@ int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_
         }
     }
     for (auto& ev : evs) (void)hipEventDestroy(ev);
-    if (d_frames) (void)hipFree(d_frames);
     if (rc) return rc;
     for (size_t i = 0; i < e->layers.size(); ++i) ms_per_layer[i] = (float)(acc[i] / iters);
     return LTK_OK;

@@ -10,22 +10,26 @@ typedef _Float16 f16;
 
 constexpr int kPackMaxFrames = 256;
 
-// Pointers to the bank face crops of the frames of one launch (kernel argument,
-// 2 KB): avoids a host->device table copy per call.
+// Per-frame pointer tables of one launch: the bank face crop, the mel window and the output frame of every frame.  They live in
+// DEVICE memory (ltk_engine::d_tab) so that the launch sequence of a pass has no per-call kernel arguments and can be replayed as a
+// captured hipGraph; launch_upload_tables fills them from the host copies with one small launch (two above 128 frames) in front of
+// the pass, on the pass's own stream (no host->device copy engine round trip).
 struct FacePtrs {
     const uint8_t* p[kPackMaxFrames];
 };
 
 // wav2lip_avatar.py:125-134: face u8 BGR [256][256][3] -> fp16 [256][256][8] (pixel-major, one 16-byte item per pixel)
 // = {masked b,g,r (rows >= 128 zero), b,g,r, 0, 0} / 255.
-void launch_pack_faces(const FacePtrs& faces, int nframes, f16* x0, hipStream_t s);
+// `faces` is a DEVICE pointer
+void launch_pack_faces(const FacePtrs* faces, int nframes, f16* x0, hipStream_t s);
 
 struct MelPtrs {
     const float* p[kPackMaxFrames];   // per frame: float32 [80][16]
 };
 
 // mel float32 [80][16] per frame -> fp16 [B][80][16][8] (pixel-major, channel 0 = value).
-void launch_pack_mel(const MelPtrs& mel, int nframes, f16* out, hipStream_t s);
+// `mel` is a DEVICE pointer
+void launch_pack_mel(const MelPtrs* mel, int nframes, f16* out, hipStream_t s);
 
 // face6 float32 NCHW [B][6][256][256] -> fp16 [B][256][256][8] (test hook).
 void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_t s);
@@ -36,8 +40,18 @@ void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_
 struct OutPtrs {
     uint8_t* p[kPackMaxFrames];       // per frame: uint8 [256][256][3] (null = skip)
 };
+// `out_u8` is a DEVICE pointer (or null)
 void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s);
+
+// The three tables of one pass, contiguous in device memory.
+struct DevTables {
+    FacePtrs faces;
+    MelPtrs mels;
+    OutPtrs outs;
+};
+// host tables (any of them may be null: that table is left alone) -> *d_tab, entries [0, nframes), on stream s
+void launch_upload_tables(const FacePtrs* faces, const MelPtrs* mels, const OutPtrs* outs, int nframes, DevTables* d_tab, hipStream_t s);
 
 // fp16 CB16 (or [N][H][W][8] when ld <= 8) channel range (ld, coff, C) -> float32 NCHW (debug capture).
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s);

@@ -13,10 +13,10 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 // input pack: wav2lip_avatar.py:119-134
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_faces_kernel(const FacePtrs faces, f16* __restrict__ x0) {
+__global__ __launch_bounds__(256) void pack_faces_kernel(const FacePtrs* __restrict__ faces, f16* __restrict__ x0) {
     const int f = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;  // 0..65535
-    const uint8_t* __restrict__ src = faces.p[f] + pix * 3;
+    const uint8_t* __restrict__ src = faces->p[f] + pix * 3;
     const float k = 1.0f / 255.0f;
     const float b = src[0] * k, g = src[1] * k, r = src[2] * k;
     const bool keep = (pix >> 8) < 128;  // img_masked[:, 128:] = 0  (rows)
@@ -26,22 +26,22 @@ __global__ __launch_bounds__(256) void pack_faces_kernel(const FacePtrs faces, f
     *reinterpret_cast<f16x8*>(x0 + ((size_t)f * 65536 + pix) * 8) = o;
 }
 
-void launch_pack_faces(const FacePtrs& faces, int nframes, f16* x0, hipStream_t s) {
+void launch_pack_faces(const FacePtrs* faces, int nframes, f16* x0, hipStream_t s) {
     hipLaunchKernelGGL(pack_faces_kernel, dim3(256, nframes), dim3(256), 0, s, faces, x0);
 }
 
-__global__ __launch_bounds__(256) void pack_mel_kernel(const MelPtrs mel, f16* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack_mel_kernel(const MelPtrs* __restrict__ mel, f16* __restrict__ out) {
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;  // 0..1279
     if (i >= 1280) return;
     f16x8 o;
 #pragma unroll
     for (int j = 1; j < 8; ++j) o[j] = (f16)0.f;
-    o[0] = (f16)mel.p[f][i];
+    o[0] = (f16)mel->p[f][i];
     *reinterpret_cast<f16x8*>(out + ((size_t)f * 1280 + i) * 8) = o;
 }
 
-void launch_pack_mel(const MelPtrs& mel, int nframes, f16* out, hipStream_t s) {
+void launch_pack_mel(const MelPtrs* mel, int nframes, f16* out, hipStream_t s) {
     hipLaunchKernelGGL(pack_mel_kernel, dim3(5, nframes), dim3(256), 0, s, mel, out);
 }
 
@@ -66,7 +66,7 @@ void launch_pack_face6_nchw(const float* face6, int nframes, f16* x0, hipStream_
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, int x_cbt,
                                                     const float* __restrict__ w, const float* __restrict__ b,
-                                                    const OutPtrs outs, int have_u8, float* __restrict__ out_f32) {
+                                                    const OutPtrs* __restrict__ outs, float* __restrict__ out_f32) {
     constexpr int hw = 65536;
     __shared__ float sw[3 * 32 + 3];
     __shared__ unsigned obytes[192];          // 256 pixels x 3 bytes
@@ -101,16 +101,46 @@ __global__ __launch_bounds__(256) void head_kernel(const f16* __restrict__ x, in
     ob[1] = (unsigned char)(unsigned)(s1 * 255.f);
     ob[2] = (unsigned char)(unsigned)(s2 * 255.f);
     __syncthreads();
-    if (have_u8 && outs.p[f] && threadIdx.x < 192)
-        reinterpret_cast<unsigned*>(outs.p[f] + (size_t)blockIdx.x * 768)[threadIdx.x] = obytes[threadIdx.x];
+    uint8_t* const of = outs ? outs->p[f] : nullptr;
+    if (of && threadIdx.x < 192)
+        reinterpret_cast<unsigned*>(of + (size_t)blockIdx.x * 768)[threadIdx.x] = obytes[threadIdx.x];
 }
 
 void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s) {
-    OutPtrs none;
-    if (!out_u8) for (int i = 0; i < nframes; ++i) none.p[i] = nullptr;
-    hipLaunchKernelGGL(head_kernel, dim3(256, nframes), dim3(256), 0, s, x32, x_ld >> 4, w3x32, b3,
-                       out_u8 ? *out_u8 : none, out_u8 ? 1 : 0, out_f32_nchw);
+    hipLaunchKernelGGL(head_kernel, dim3(256, nframes), dim3(256), 0, s, x32, x_ld >> 4, w3x32, b3, out_u8, out_f32_nchw);
+}
+
+// ---------------------------------------------------------------------------------------
+// per-call pointer tables -> device memory.  One launch carries up to 128 entries of each table as kernel arguments (3 KB: HIP
+// guarantees 4 KB of kernel arguments), so a 256-frame pass needs two.
+// ---------------------------------------------------------------------------------------
+constexpr int kTabChunk = 128;
+struct TabChunk {
+    const void* p[3][kTabChunk];
+};
+__global__ __launch_bounds__(kTabChunk) void upload_tables_kernel(const TabChunk c, int mask, int first, int n, DevTables* __restrict__ t) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    if (mask & 1) t->faces.p[first + i] = (const uint8_t*)c.p[0][i];
+    if (mask & 2) t->mels.p[first + i] = (const float*)c.p[1][i];
+    if (mask & 4) t->outs.p[first + i] = (uint8_t*)c.p[2][i];
+}
+
+void launch_upload_tables(const FacePtrs* faces, const MelPtrs* mels, const OutPtrs* outs, int nframes, DevTables* d_tab, hipStream_t s) {
+    const int mask = (faces ? 1 : 0) | (mels ? 2 : 0) | (outs ? 4 : 0);
+    if (!mask) return;
+    for (int f0 = 0; f0 < nframes; f0 += kTabChunk) {
+        const int n = nframes - f0 < kTabChunk ? nframes - f0 : kTabChunk;
+        TabChunk c;
+        for (int i = 0; i < n; ++i) {
+            c.p[0][i] = faces ? faces->p[f0 + i] : nullptr;
+            c.p[1][i] = mels ? mels->p[f0 + i] : nullptr;
+            c.p[2][i] = outs ? outs->p[f0 + i] : nullptr;
+        }
+        for (int i = n; i < kTabChunk; ++i) c.p[0][i] = c.p[1][i] = c.p[2][i] = nullptr;
+        hipLaunchKernelGGL(upload_tables_kernel, dim3(1), dim3(kTabChunk), 0, s, c, mask, f0, n, d_tab);
+    }
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, int N, int HW, int ld, int coff, int C,

@@ -281,6 +281,7 @@ int rowgemm_launch(const RowGemmPlan& p, const f16* x, int x_ld, int x_coff, f16
                    hipStream_t stream, std::string* err) {
     if (!p.d_w || M <= 0 || M > kRowGemmMaxFrames) { if (err) *err = "rowgemm: no plan, or more frames than it is built for"; return -1; }
     if (((x_ld | x_coff) & 7) || ((y_ld | y_coff) & 3)) { if (err) *err = "rowgemm: operand pitch / offset alignment"; return -1; }
+    if (x_coff < 0 || y_coff < 0 || x_coff + p.K > x_ld || y_coff + p.J > y_ld) { if (err) *err = "rowgemm: channel range outside the row pitch"; return -1; }
     RowGemmArgs a{x, x_ld, x_coff, y, y_ld, y_coff, p.d_w, p.d_scale, p.d_shift, M, p.K, p.J, relu};
     if (M <= 16) hipLaunchKernelGGL(rowgemm_kernel<1>, dim3((unsigned)(p.J / 16)), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL(rowgemm_kernel<2>, dim3((unsigned)(p.J / 16)), dim3(512), 0, stream, a);

@@ -37,10 +37,23 @@ enum Knob {
     K_ROWCONV,            // LTK_ROWCONV        the 3x3 layers on the 4x4 / 8x8 maps as weight-streaming GEMMs over gathered rows (rowgemm.hip rowconv) when the
                           //                    launch has at most this many output pixels (frames x Ho x Wo); 0 = never
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
+    K_GRAPH,              // LTK_GRAPH          1: a Wav2Lip pass of a given frame count is captured once as a hipGraph and replayed (the per-call
+                          //                    pointer tables live in device memory, filled by one small launch in front of the graph)
+    K_DF_FRAMES,          // LTK_DF_FRAMES      > 0: the decoder blocks >= LTK_DF_BLOCK and the output conv run depth-first over sub-batches of this
+                          //                    many frames (producer -> consumer tensors stay in the 256 MiB Infinity Cache); 0 = layer by layer
+    K_DF_BLOCK,           // LTK_DF_BLOCK       first decoder block of the depth-first region (6: the 128^2 and 256^2 levels)
+    K_DF_MIN,             // LTK_DF_MIN         depth-first only for launches of at least this many frames
     K_COUNT
 };
 
 int knob(Knob k);
+// bumped by every knob_set: cached launch plans (captured graphs) are keyed by it
+unsigned knob_epoch();
+// hipFuncAttributeMaxDynamicSharedMemorySize = `bytes` for `func` on the CURRENT device, once per (device, function) and process
+// (a launch path may run on any host thread, also inside a stream capture: the attribute is set by the first eager pass).
+// Returns the hipError_t of the attribute call (0 = ok).
+int ensure_dyn_lds(const void* func, int bytes);
+
 // returns 0, or -1 when `name` (without the LTK_ prefix or with it) is not a knob
 int knob_set(const char* name, int value);
 

@@ -4,8 +4,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <hip/hip_runtime.h>
+
 #include <atomic>
 #include <mutex>
+#include <set>
+#include <utility>
 
 namespace ltk {
 namespace {
@@ -21,9 +25,14 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_ROWGEMM", 1},
     {"LTK_ROWCONV", 1024},
     {"LTK_ABLATE", 0},
+    {"LTK_GRAPH", 1},
+    {"LTK_DF_FRAMES", 0},
+    {"LTK_DF_BLOCK", 6},
+    {"LTK_DF_MIN", 32},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
+std::atomic<unsigned> g_epoch{0};
 std::once_flag g_once;
 
 void init() {
@@ -48,11 +57,29 @@ int knob(Knob k) {
     return g_val[k].load(std::memory_order_relaxed);
 }
 
+int ensure_dyn_lds(const void* func, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, func})) return 0;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, func});
+    return (int)e;
+}
+
+unsigned knob_epoch() { return g_epoch.load(std::memory_order_relaxed); }
+
 int knob_set(const char* name, int value) {
     std::call_once(g_once, init);
     if (!name) return -1;
     for (int i = 0; i < K_COUNT; ++i)
-        if (!strcmp(name, kDefs[i].name) || !strcmp(name, kDefs[i].name + 4)) { g_val[i].store(value, std::memory_order_relaxed); return 0; }
+        if (!strcmp(name, kDefs[i].name) || !strcmp(name, kDefs[i].name + 4)) {
+            g_val[i].store(value, std::memory_order_relaxed);
+            g_epoch.fetch_add(1, std::memory_order_relaxed);
+            return 0;
+        }
     return -1;
 }
 

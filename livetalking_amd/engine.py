@@ -359,6 +359,10 @@ class Engine:
         _lib.check(self._lib.ltk_wav2lip_time_layers(self._h, int(frames), int(iters), ms, n))
         return np.array(ms[:], dtype=np.float64)
 
+    def graph_count(self) -> int:
+        """Frame counts whose Wav2Lip pass currently replays from a captured hipGraph (include/ltk.h)."""
+        return int(self._lib.ltk_wav2lip_graph_count(self._h))
+
     def time_convs(self, frames: int, iters: int):
         ms = C.c_float()
         macs = C.c_double()

@@ -168,33 +168,47 @@ def test_fused_head_vs_separate_head(engine, golden_dir):
 
 
 @pytest.mark.gpu
-def test_rowconv_and_rowgemm_vs_conv3(engine, golden_dir):
+def test_rowconv_and_rowgemm_vs_conv3(golden_dir):
     """The small-map layers as weight-streaming GEMMs (csrc/rowgemm.hip: rowgemm for the one-pixel maps, rowconv for the 3x3 convs
     on the 4x4 / 8x8 maps - knobs ROWGEMM / ROWCONV, both on by default) against the same layers on conv3 + split-K finish: another
     summation order of the same fp16 products, so frames differ by at most 1 LSB, rarely, and are no further from the
-    reference's golden frames."""
+    reference's golden frames.  Launch sizes 1, 5, 17, 32 and 64 frames: rowgemm_kernel<1> (<= 16 frames), <2> (17..32), the
+    live[] masking of an odd remainder, rowconv on 16 / 80 / 272 / 512 / 1024 rows of the 4x4 maps and the conv3 hand-over
+    above 32 frames / 1024 rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
     from livetalking_amd.engine import Engine
     g, frames, faces, coords, feats = _golden_inputs(golden_dir)
-    B, index = int(g["batch"]), int(g["index"])
-    aid = engine.register_avatar(faces, frames, coords)
-    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
-    out = {}
+    B0, index = int(g["batch"]), int(g["index"])
+    eng = Engine(0)
     try:
-        for on in (1, 0):
-            Engine.set_knob("ROWCONV", 1024 if on else 0)
-            Engine.set_knob("ROWGEMM", on)
-            pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
-            engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
-            out[on] = pred.cpu().numpy()
+        eng.load_wav2lip(synth.wav2lip_state_dict(int(g["weight_seed"])), max_frames=64)
+        aid = eng.register_avatar(faces, frames, coords)
+        for nf in (B0, 1, 5, 17, 32, 64):
+            # requests of at most 16 frames each (a session's batch), the last one carries the odd remainder
+            sizes = [16] * (nf // 16) + ([nf % 16] if nf % 16 else [])
+            mels = [torch.from_numpy(np.stack([feats[(i + 3 * r) % len(feats)] for i in range(b)]).astype(np.float32)).cuda()
+                    for r, b in enumerate(sizes)]
+            out = {}
+            try:
+                for on in (1, 0):
+                    Engine.set_knob("ROWCONV", 1024 if on else 0)
+                    Engine.set_knob("ROWGEMM", on)
+                    preds = [torch.zeros(b, 256, 256, 3, dtype=torch.uint8, device="cuda") for b in sizes]
+                    eng.wav2lip_infer([(aid, index + 2 * r, b, mels[r].data_ptr(), preds[r].data_ptr()) for r, b in enumerate(sizes)])
+                    out[on] = np.concatenate([p.cpu().numpy() for p in preds])
+            finally:
+                Engine.set_knob("ROWCONV", 1024)
+                Engine.set_knob("ROWGEMM", 1)
+            d = np.abs(out[1].astype(np.int32) - out[0].astype(np.int32))
+            print(f"[rowconv/rowgemm vs conv3] {nf} frames: max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
+            assert d.max() <= 1 and float((d != 0).mean()) < 0.10, nf
+            if nf == B0:
+                ref = g["ref_pred_u8"]
+                assert psnr_u8(out[1], ref) >= psnr_u8(out[0], ref) - 0.2
+        eng.release_avatar(aid)
     finally:
-        Engine.set_knob("ROWCONV", 1024)
-        Engine.set_knob("ROWGEMM", 1)
-    d = np.abs(out[1].astype(np.int32) - out[0].astype(np.int32))
-    print(f"[rowconv/rowgemm vs conv3] max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
-    assert d.max() <= 1 and float((d != 0).mean()) < 0.10
-    ref = g["ref_pred_u8"]
-    assert psnr_u8(out[1], ref) >= psnr_u8(out[0], ref) - 0.2
-    engine.release_avatar(aid)
+        eng.close()
 
 
 @pytest.mark.gpu
@@ -367,4 +381,36 @@ def test_coalesced_256_frames_vs_oracle(golden_dir):
             assert p >= 40.0 and dmax <= 6 and frac2 >= 0.99
     finally:
         Engine.set_knob("MICROBATCH", 0)
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_coalesced_32_and_24_frames_vs_oracle(golden_dir):
+    """Two sessions coalesced into one call - what the default scheduler produces whenever two sessions' inference threads meet
+    (livetalking_amd/scheduler.py) - on the bench bank: ONE 32-frame call (2 x 16 frames: rowgemm_kernel<2>, rowconv on the 512
+    rows of the 4x4 maps, conv3 + split-K on the 8x8 maps) and ONE 24-frame call (16 + 8: the odd-remainder masking of the
+    two-frame-tile rowgemm), each session at its own bank position with its own audio windows, BOTH sessions of both calls against
+    the ORACLE (reference semantics: wav2lip_avatar.py:116-139 per session; wav2lip_v2.py:36-39,60-66 are the layers that change
+    kernel with the launch size)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    g, gm, frames, faces, coords = _bench_inputs(golden_dir)
+    chunks = gm["ref_chunks"]                                             # (3,16,80,16): three MelASR steps of the reference
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(int(g["weight_seed"])).items()}
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(int(g["weight_seed"])), max_frames=32)
+        aid = eng.register_avatar(faces, frames, coords)
+        for sizes in ((16, 16), (16, 8)):
+            index = [243, 61]                                            # session 0 walks over the ping-pong turn of the bank
+            sess_feats = [[chunks[(s + 1) % 3][(i + 7 * s) % 16] for i in range(b)] for s, b in enumerate(sizes)]
+            mels = [torch.from_numpy(np.asarray(f, dtype=np.float32)).cuda() for f in sess_feats]
+            preds = [torch.zeros(b, 256, 256, 3, dtype=torch.uint8, device="cuda") for b in sizes]
+            eng.wav2lip_infer([(aid, index[s], b, mels[s].data_ptr(), preds[s].data_ptr()) for s, b in enumerate(sizes)])
+            for s, b in enumerate(sizes):
+                ref = plugin_oracle.inference_batch(sd, faces, index[s], b, sess_feats[s])
+                p, dmax, frac2 = _frame_report(f"{sum(sizes)}-frame call, session {s} ({b} frames)", preds[s].cpu().numpy(), ref)
+                assert p >= 40.0 and dmax <= 6 and frac2 >= 0.99
+    finally:
         eng.close()
