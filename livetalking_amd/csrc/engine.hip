@@ -1125,9 +1125,11 @@ int ltk_paste_back_batch(ltk_engine* e, int avatar_id, const int32_t* idx, const
         }
         launch_paste_batch(pb, m, a.H, a.W, (const uint8_t*)d_pred + (size_t)i0 * 256 * 256 * 3, (uint8_t*)sc.s.d + (size_t)i0 * bytes, bytes, sl.s);
     }
-    CHK(hipGetLastError());
-    CHK(hipMemcpyAsync(out, sc.s.d, bytes * n, hipMemcpyDeviceToHost, sl.s));
-    CHK(hipStreamSynchronize(sl.s));
+    // an error past this point must not hand the scratch back to the pool while earlier launches may still be writing it
+    hipError_t pe = hipGetLastError();
+    if (pe == hipSuccess) pe = hipMemcpyAsync(out, sc.s.d, bytes * n, hipMemcpyDeviceToHost, sl.s);
+    const hipError_t se = hipStreamSynchronize(sl.s);
+    if (pe != hipSuccess || se != hipSuccess) return fail(LTK_E_HIP, std::string("paste_back_batch: ") + hipGetErrorString(pe != hipSuccess ? pe : se));
     return LTK_OK;
 }
 
@@ -1792,9 +1794,11 @@ int ltk_egress_batch(ltk_engine* e, ltk_egress* s, int source, int avatar, const
     // watermark + format conversion of all n composites in one launch
     launch_egress_batch(comp, bytes, n, s->d_wm, s->wm_x, s->wm_y, s->wm_w, s->wm_h, s->wm_b, s->wm_g, s->wm_r, conv, out_bytes, H, W,
                         format == LTK_FMT_I420, chroma, sl.s);
-    CHK(hipGetLastError());
-    CHK(hipMemcpyAsync(h_out, conv, out_bytes * n, hipMemcpyDeviceToHost, sl.s));
-    CHK(hipStreamSynchronize(sl.s));
+    // an error past this point must not hand the scratch back to the pool while earlier launches may still be writing it
+    hipError_t pe = hipGetLastError();
+    if (pe == hipSuccess) pe = hipMemcpyAsync(h_out, conv, out_bytes * n, hipMemcpyDeviceToHost, sl.s);
+    const hipError_t se = hipStreamSynchronize(sl.s);
+    if (pe != hipSuccess || se != hipSuccess) return fail(LTK_E_HIP, std::string("egress_batch: ") + hipGetErrorString(pe != hipSuccess ? pe : se));
     return LTK_OK;
 }
 

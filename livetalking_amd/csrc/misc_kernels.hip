@@ -297,7 +297,8 @@ __device__ __forceinline__ void paste_body(const uint8_t* __restrict__ full, int
         }
         word |= v << (8 * k);
     }
-    if (nb == 4) {
+    // (frame f of a batched launch starts at out0 + f * H*W*3: dword-aligned only when H*W*3 is a multiple of 4)
+    if (nb == 4 && (reinterpret_cast<uintptr_t>(out + b0) & 3) == 0) {
         *reinterpret_cast<unsigned*>(out + b0) = word;
     } else {
         for (int k = 0; k < nb; ++k) out[b0 + k] = (uint8_t)(word >> (8 * k));
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(256) void paste_blend_kernel(const uint8_t* __restr
         }
         word |= v << (8 * k);
     }
-    if (nb == 4) {
+    // (frame f of a batched launch starts at out0 + f * H*W*3: dword-aligned only when H*W*3 is a multiple of 4)
+    if (nb == 4 && (reinterpret_cast<uintptr_t>(out + b0) & 3) == 0) {
         *reinterpret_cast<unsigned*>(out + b0) = word;
     } else {
         for (int k = 0; k < nb; ++k) out[b0 + k] = (uint8_t)(word >> (8 * k));

@@ -43,6 +43,12 @@ class Engine:
         straggling paste) reaches the C ABI with a null engine and gets LTK_E_INVALID instead of touching freed memory."""
         if not self._closed:
             self._closed = True
+            for sched in list(self.__dict__.get("_ltk_schedulers", {}).values()):     # scheduler.get_scheduler: stop the worker threads
+                try:
+                    sched.close()
+                except Exception:
+                    pass
+            self.__dict__.pop("_ltk_schedulers", None)
             for sess in list(self._egress_open):
                 try:
                     self.egress_close(sess)

@@ -13,7 +13,9 @@ scheduler batches them instead (continuous batching):
   batch open for LTK_COALESCE_AUTO_US (default 200 us, 0.03 % of a 640-ms step; 0 / 200 / 500 us measured with 16 free-running
   session threads: 200 >= 0 > 500, profiles/r02_scheduler_window.txt) so that sessions woken by the same clock
   tick ride one launch sequence instead of "one alone, then the rest"; a lone session never waits;
-* LTK_COALESCE_MS > 0 holds every batch open for that long after its first request (fixed window).
+* LTK_COALESCE_MS > 0 holds every batch open for that long after its first request (fixed window);
+* up to LTK_INFLIGHT (default 2) calls are in flight: the next batch is issued shortly before the running call is expected to
+  end, so its launches queue behind the running kernels and the GPU does not idle through the host turn-around.
 
 A session's frames keep their order: a request is one contiguous (index .. index+batch) span, a session has at most
 one request in flight (its inference thread blocks in `infer()`), and every request's frames land in its own output
@@ -37,6 +39,16 @@ class _Req:
 
 
 class BatchingScheduler:
+    """Continuous batching with up to LTK_INFLIGHT (default 2) engine calls in flight.
+
+    The engine serialises calls on one stream and releases its enqueue lock before it waits (csrc/engine.hip,
+    ltk_wav2lip_infer), so a second call issued while the first still runs queues its launches right behind the first
+    call's kernels: the GPU does not idle through the host turn-around between two calls (completion wake-up, Python,
+    ctypes, launch: ~75 us of a 1.3-ms step, ~1 ms of a 16-ms 256-frame step with 16 session threads).  To keep batches
+    as large as they are with one call in flight, the second call is not issued when the first request arrives but
+    LTK_INFLIGHT_LEAD_US (default 300) before the running call is EXPECTED to end - from a running seconds-per-frame
+    estimate of the calls' device time - and takes everything queued by then."""
+
     def __init__(self, engine, kind: str = "wav2lip", window_ms: float = 0.0, max_frames: int = 0):
         self.engine = engine
         self.kind = kind
@@ -45,13 +57,19 @@ class BatchingScheduler:
         self._max_frames = int(max_frames)
         self._cv = threading.Condition()
         self._pending = collections.deque()
-        self._busy = False
-        self._handoff = False
+        self._inflight = 0                 # engine calls issued and not yet returned (leaders + workers)
+        self._max_inflight = max(1, int(os.environ.get("LTK_INFLIGHT", "2")))
+        self._lead = max(0.0, float(os.environ.get("LTK_INFLIGHT_LEAD_US", "300"))) * 1e-6
+        self._spf = None                   # seconds per frame of a call that had the engine to itself (EWMA)
+        self._busy_until = 0.0             # perf_counter() at which the calls in flight are expected to be done
+        self._last_done = 0.0              # perf_counter() of the latest completion (calls complete in issue order: one stream)
+        self._leader_hold = False          # a leader is holding its batch open (window): workers leave the queue alone
         self._closed = False
-        self._worker = None
+        self._workers = []
+        self._idle_exit = max(0.05, float(os.environ.get("LTK_WORKER_IDLE_S", "5")))
         self._auto_window = max(0.0, float(os.environ.get("LTK_COALESCE_AUTO_US", "200"))) * 1e-6
         self._last_multi = -1e9            # perf_counter() of the last batch that carried more than one request
-        self.stats = {"calls": 0, "requests": 0, "frames": 0, "max_requests_per_call": 0}
+        self.stats = {"calls": 0, "requests": 0, "frames": 0, "max_requests_per_call": 0, "overlapped_calls": 0}
 
     def _limit(self) -> int:
         if self._max_frames > 0:
@@ -64,28 +82,31 @@ class BatchingScheduler:
         r = _Req((aid, index, batch, in_ptr, out_ptr), int(batch))
         with self._cv:
             self._pending.append(r)
-            leader = not self._busy
+            leader = self._inflight == 0 and len(self._pending) == 1
             if leader:
-                self._busy = True
+                self._inflight += 1
+                self._leader_hold = True
+            else:
+                self._ensure_workers()
+                self._cv.notify_all()
         if leader:
-            # idle engine: run the call in this thread (no hop); whatever queued up meanwhile goes to the worker
+            # idle engine: run the call in this thread (no hop); whatever queues up meanwhile is the workers' business
             if self.window > 0.0:
                 time.sleep(self.window)
             elif self._auto_window > 0.0 and time.perf_counter() - self._last_multi < 2.0:
                 time.sleep(self._auto_window)          # other sessions are active: let the ones due now join this launch
-            self._run_one_batch()
-            with self._cv:
-                if self._pending:
-                    self._handoff = True
-                    if self._worker is None:
-                        self._worker = threading.Thread(target=self._work, name="ltk-batch", daemon=True)
-                        self._worker.start()
-                    self._cv.notify_all()
-                else:
-                    self._busy = False
+            self._run_one_batch(alone=True)
         r.done.wait()
         if r.err is not None:
             raise r.err
+
+    def _ensure_workers(self):
+        """Under the lock."""
+        self._workers = [w for w in self._workers if w.is_alive()]
+        while len(self._workers) < self._max_inflight:
+            w = threading.Thread(target=self._work, name="ltk-batch", daemon=True)
+            self._workers.append(w)
+            w.start()
 
     def _take_batch(self):
         """Under the lock: the queued requests that fit one engine call (FIFO)."""
@@ -96,76 +117,110 @@ class BatchingScheduler:
             frames += q.batch
         return group, frames
 
-    def _run_one_batch(self):
+    def _run_one_batch(self, alone: bool):
+        """The caller holds one in-flight slot (self._inflight already counts it); released here."""
         with self._cv:
+            if alone:
+                self._leader_hold = False
             group, frames = self._take_batch()
-        if not group:
-            return
+            now = time.perf_counter()
+            if self._spf is not None:
+                self._busy_until = max(now, self._busy_until) + frames * self._spf
+            if not alone:
+                self.stats["overlapped_calls"] += 1
+        t0 = time.perf_counter()
         errs = [None] * len(group)
-        try:
-            self._call([q.args for q in group])
-        except Exception as ex:  # noqa: BLE001
-            if len(group) == 1:
-                errs[0] = ex
-            else:
-                # One bad request (released avatar, bad pointer, oversize batch) must not kill the inference threads of the
-                # sessions it happened to be batched with (base_avatar.py:366 has no try/except): the engine validates a
-                # call before it launches anything, so the requests are re-issued one by one and only the offender raises.
-                for i, q in enumerate(group):
-                    try:
-                        self._call([q.args])
-                    except Exception as ex_i:  # noqa: BLE001
-                        errs[i] = ex_i
+        if group:
+            try:
+                self._call([q.args for q in group])
+            except Exception as ex:  # noqa: BLE001
+                if len(group) == 1:
+                    errs[0] = ex
+                else:
+                    # One bad request (released avatar, bad pointer, oversize batch) must not kill the inference threads of the
+                    # sessions it happened to be batched with (base_avatar.py:366 has no try/except): the engine validates a
+                    # call before it launches anything, so the requests are re-issued one by one and only the offender raises.
+                    for i, q in enumerate(group):
+                        try:
+                            self._call([q.args])
+                        except Exception as ex_i:  # noqa: BLE001
+                            errs[i] = ex_i
+        t1 = time.perf_counter()
         with self._cv:
-            self.stats["calls"] += 1
-            self.stats["requests"] += len(group)
-            self.stats["frames"] += frames
-            self.stats["max_requests_per_call"] = max(self.stats["max_requests_per_call"], len(group))
-            if len(group) > 1:
-                self._last_multi = time.perf_counter()
+            self._inflight -= 1
+            if group:
+                self.stats["calls"] += 1
+                self.stats["requests"] += len(group)
+                self.stats["frames"] += frames
+                self.stats["max_requests_per_call"] = max(self.stats["max_requests_per_call"], len(group))
+                if len(group) > 1:
+                    self._last_multi = t1
+                if frames > 0 and all(e is None for e in errs):
+                    # the engine runs calls in issue order: this one had the GPU from its issue or from the previous completion on
+                    spf = (t1 - max(t0, self._last_done)) / frames
+                    self._spf = spf if self._spf is None else 0.75 * self._spf + 0.25 * spf
+            self._last_done = t1
+            if self._inflight == 0:
+                self._busy_until = t1
+            if self._pending:
+                self._ensure_workers()
+            self._cv.notify_all()
         for q, err in zip(group, errs):
             q.err = err
             q.done.set()
 
     def _work(self):
-        """Worker: owns the engine between a leader's hand-off and the moment the queue runs empty."""
+        """Worker: issues a call whenever requests are queued and either nothing is in flight, or a slot is free and the calls in
+        flight are about to end.  Exits after LTK_WORKER_IDLE_S idle seconds (a later request starts a new one), so an unused
+        scheduler does not pin its engine for the life of the process."""
+        me = threading.current_thread()
         while True:
             with self._cv:
-                while not self._handoff and not self._closed:
-                    self._cv.wait()
-                if self._closed and not self._handoff:
-                    self._worker = None
-                    return
-                self._handoff = False
-            while True:
-                with self._cv:
-                    if not self._pending:
-                        self._busy = False
-                        break
-                self._run_one_batch()
+                idle_since = time.perf_counter()
+                while True:
+                    if self._closed:
+                        if me in self._workers:
+                            self._workers.remove(me)
+                        return
+                    now = time.perf_counter()
+                    if self._pending and not self._leader_hold:
+                        if self._inflight == 0:
+                            break
+                        if self._inflight < self._max_inflight and self._spf is not None:
+                            wait_t = self._busy_until - self._lead - now
+                            if wait_t <= 0.0:
+                                break
+                            self._cv.wait(timeout=wait_t)
+                            continue
+                        self._cv.wait()                 # a completion (or close) wakes us
+                        idle_since = time.perf_counter()
+                        continue
+                    if now - idle_since >= self._idle_exit:
+                        if me in self._workers:
+                            self._workers.remove(me)
+                        return
+                    self._cv.wait(timeout=self._idle_exit)
+                alone = self._inflight == 0
+                self._inflight += 1
+            self._run_one_batch(alone=alone)
 
     def close(self):
-        """Stop the worker.  Requests already queued are failed (their callers raise) instead of being left blocked; a later
-        infer() still works: it runs as a leader and starts a new worker when it needs one."""
+        """Stop the workers.  Requests still queued are failed (their callers raise) instead of being left blocked; a later
+        infer() still works: it runs as a leader and starts new workers when it needs them."""
         with self._cv:
             self._closed = True
-            dropped = []
-            if not self._busy or self._handoff:           # nobody is about to drain the queue
-                dropped = list(self._pending)
-                self._pending.clear()
-                if self._handoff:
-                    self._handoff = False
-                    self._busy = False
+            dropped = list(self._pending)
+            self._pending.clear()
+            workers = list(self._workers)
             self._cv.notify_all()
         for q in dropped:
             q.err = RuntimeError("scheduler closed")
             q.done.set()
-        w = self._worker
-        if w is not None and w is not threading.current_thread():
-            w.join(timeout=5.0)
+        for w in workers:
+            if w is not threading.current_thread():
+                w.join(timeout=5.0)
         with self._cv:
-            if self._worker is not None and not self._worker.is_alive():
-                self._worker = None
+            self._workers = [w for w in self._workers if w.is_alive()]
             self._closed = False
 
 
@@ -174,8 +229,8 @@ class CoalescingScheduler(BatchingScheduler):
         super().__init__(engine, kind, window_ms)
 
 
-# one scheduler per (engine, kind), held on the engine object itself: it goes away with the engine (a registry keyed by
-# id(engine) kept every engine - and its GPU weights - alive for the life of the process)
+# one scheduler per (engine, kind), held on the engine object itself (a registry keyed by id(engine) kept every engine - and its
+# GPU weights - alive for the life of the process).  Engine.close() closes them; their worker threads also exit when idle.
 _LOCK = threading.Lock()
 
 

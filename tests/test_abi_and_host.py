@@ -154,6 +154,102 @@ def test_continuous_batching_without_a_window():
     sch.close()
 
 
+def test_two_calls_in_flight_keep_order_and_batch_size(monkeypatch):
+    """Up to LTK_INFLIGHT = 2 engine calls in flight (the engine serialises them on one stream and waits outside its enqueue lock):
+    the next batch goes down shortly BEFORE the running call is expected to end, so it still carries everything that queued up
+    meanwhile.  Eight free-running session threads against an engine that needs 1 ms per frame and serialises like the real one:
+    every request is served exactly once and in its session's order, never more than two calls are inside the engine, calls do
+    overlap, and batches stay multi-request.  LTK_INFLIGHT=1 restores one call at a time."""
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+
+    class SerialEngine(FakeEngine):
+        def __init__(self):
+            super().__init__()
+            self.gpu = threading.Lock()          # "the stream": one call's device work at a time, in issue order
+            self.inside = 0
+            self.peak = 0
+
+        def wav2lip_infer(self, reqs, stream=0):
+            with self.lock:
+                self.inside += 1
+                self.peak = max(self.peak, self.inside)
+                self.infer_calls.append(list(reqs))
+            with self.gpu:
+                time.sleep(1e-3 * sum(r[2] for r in reqs))
+            with self.lock:
+                self.inside -= 1
+
+    def run(inflight):
+        monkeypatch.setenv("LTK_INFLIGHT", str(inflight))
+        eng = SerialEngine()
+        sch = scheduler.BatchingScheduler(eng, "wav2lip")
+        S, R = 8, 6
+        served = [[] for _ in range(S)]
+
+        def session(sid):
+            for k in range(R):
+                sch.infer(sid + 1, 16 * k, 16, 1000 + sid, 2000 + sid)
+                served[sid].append(k)
+                time.sleep(0.002)                # the session's own work between two steps
+
+        ts = [threading.Thread(target=session, args=(sid,)) for sid in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=30)
+            assert not t.is_alive()
+        sch.close()
+        per_session = {}
+        for call in eng.infer_calls:
+            for aid, index, batch, _, _ in call:
+                per_session.setdefault(aid, []).append(index)
+        assert all(v == [16 * k for k in range(R)] for v in per_session.values()) and len(per_session) == S
+        assert all(v == list(range(R)) for v in served)
+        return eng, sch
+
+    eng2, sch2 = run(2)
+    assert eng2.peak == 2 and sch2.stats["overlapped_calls"] > 0
+    assert sch2.stats["requests"] == 48 and sch2.stats["max_requests_per_call"] >= 3
+    eng1, sch1 = run(1)
+    assert eng1.peak == 1 and sch1.stats["overlapped_calls"] == 0 and sch1.stats["requests"] == 48
+
+
+def test_idle_workers_exit_and_engine_close_closes_schedulers(monkeypatch):
+    """A scheduler must not pin its engine for the life of the process: worker threads leave after LTK_WORKER_IDLE_S idle seconds
+    (a later request starts new ones), and Engine.close() closes the schedulers stored on the engine."""
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+    monkeypatch.setenv("LTK_WORKER_IDLE_S", "0.1")
+
+    class SlowEngine(FakeEngine):
+        def wav2lip_infer(self, reqs, stream=0):
+            time.sleep(0.05)
+            super().wav2lip_infer(reqs, stream)
+
+    eng = SlowEngine()
+    sch = scheduler.get_scheduler(eng)
+    ts = [threading.Thread(target=sch.infer, args=(1, 16 * i, 16, 1, 2)) for i in range(3)]
+    for t in ts:
+        t.start()
+        time.sleep(0.01)
+    for t in ts:
+        t.join(timeout=10)
+    assert any(w.is_alive() for w in sch._workers)           # the queued requests were served by workers
+    time.sleep(0.5)
+    assert not any(w.is_alive() for w in sch._workers)       # ... which left when idle
+    sch.infer(1, 64, 16, 1, 2)                               # still usable
+    from livetalking_amd.engine import Engine
+    closed = []
+    dummy = Engine.__new__(Engine)                           # Engine.close() without a GPU: only the scheduler part runs
+    dummy._closed, dummy._egress_open, dummy._h = False, set(), None
+    dummy._lib = types.SimpleNamespace(ltk_engine_destroy=lambda h: closed.append(h))
+    s2 = scheduler.get_scheduler(dummy) if hasattr(dummy, "wav2lip_infer") else None
+    assert s2 is not None and "_ltk_schedulers" in dummy.__dict__
+    dummy.close()
+    assert "_ltk_schedulers" not in dummy.__dict__ and closed == [None]
+
+
 def test_poisoned_request_fails_alone_and_close_unblocks():
     """One bad request inside a 3-request batch raises only in its own caller (the reference's inference thread has no
     try/except, base_avatar.py:366: an error delivered to every co-batched session would kill all of their threads); close()
