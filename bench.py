@@ -295,10 +295,12 @@ def run_wav2lip(args, ranks: Ranks):
                 "note": "one session thread: host mel in, inference_batch, then paste_back_frame for each of the B frames "
                         "(B composites on the device, one pinned device-to-host copy per batch); not `value`"}
     drv.close()
-    # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass, the head fused into the last):
-    # HIP events on the engine's own streams around the conv stack only (no gather/pack), averaged over 10 passes of the
-    # same workload.  One "launch" below = one pass of the conv stack over min(frames_per_step, 256) frames.
+    # dominant kernel family (conv3_kernel / conv_mfma_kernel: the 54 conv layers of one pass, the bank gather fused into the first,
+    # the head into the last): HIP events on the engine's compute stream around the device side of one ltk_wav2lip_infer pass exactly
+    # as that call enqueues it (mel pack + conv stack, replayed from the captured hipGraph under knob GRAPH), averaged over 10 passes
+    # of the same workload.  One "launch" below = one pass over min(frames_per_step, 256) frames.
     nf_pass = min(frames_per_step, 256)
+    graphs_timed_run = eng.graph_count()            # > 0: the timed inference_batch calls above ran from captured graphs
     conv_ms, conv_macs = eng.time_convs(nf_pass, 10)
     achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
     out = None
@@ -313,7 +315,8 @@ def run_wav2lip(args, ranks: Ranks):
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
                          "kernel": "conv3_kernel + conv_mfma_kernel + rowgemm / rowconv_kernel (the 54 conv/convT layers + fused head = one pass)",
-                         "conv_stack_ms": round(conv_ms, 4), "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass},
+                         "conv_stack_ms": round(conv_ms, 4), "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass,
+                         "hipgraph": bool(graphs_timed_run), "graphs_captured_in_timed_run": graphs_timed_run},
             "per_rank_fps": [round(args.steps * frames_per_step / t, 1) for t in per_rank],
             "scheduler": sched,
         }
@@ -692,7 +695,7 @@ def measure_traffic(sub, extra, passes, conv_only):
             v += float(val)
         tot[counter] = v
         shutil.rmtree(d, ignore_errors=True)
-    n = passes + 1
+    n = passes + (2 if sub == "convpasses" else 1)        # warm passes of the profiled body (sub_convpasses / sub_mtpasses)
     rd = tot["FETCH_SIZE"] * 1024.0 * 2.0 / n
     wr = tot["WRITE_SIZE"] * 1024.0 / n
     return rd + wr, {"read_bytes": rd, "write_bytes": wr, "passes_profiled": n,
@@ -706,8 +709,9 @@ def sub_convpasses(args):
     from livetalking_amd.engine import Engine
     nf = min(args.sessions * args.batch, 256)
     eng = Engine(0)
+    Engine.set_knob("GRAPH", 0)             # counters per kernel dispatch: the same launches, issued one by one
     eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=nf)
-    eng.time_convs(nf, args.steps)          # = 1 warm pass + `steps` passes
+    eng.time_convs(nf, args.steps)          # = 2 warm passes + `steps` passes
     eng.close()
 
 

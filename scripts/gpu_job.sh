@@ -9,6 +9,8 @@
 #   ab-lib <tag> <a.so> <b.so> ... in-job A/B of several builds of libltk_hip.so (LTK_LIB), two interleaved rounds (MT=0 skips MuseTalk)
 #   ablate [small|big]             conv3 ablation masks per layer (needs ab_libs/libltk_hip_ablate.so: scripts/build_variant.sh ablate -DLTK_ABLATE_BUILD=1)
 #   pmc-layer                      SQ counters of single-layer launches (conv_ablate.py under rocprofv3 --pmc)
+#   clock [layers...]              scripts/conv_clock.py: the real conv3 kernel on random / constant / zero operands, un-profiled (HIP events) and under
+#                                  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_* (one run per fill) -> gpurun_out/clock_report.txt
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out; mkdir -p $O; cd $R
 MODE=$1; shift
@@ -29,10 +31,13 @@ profile)
   prof() {   # prof <name> <bench args...>: kernel trace + FETCH / WRITE / SQ / L2 counter passes, each its own run
     local n=$1; shift; want $n || return 0; local CMD="python $R/bench.py $* --no-cpu-baseline --no-also --no-traffic"
     timeout 400 rocprofv3 --kernel-trace --stats -d $P/${n}_trace -o r -- $CMD > $P/${n}_trace.log 2>&1
+    # counter passes: the same launches issued one by one (LTK_GRAPH=0), so every dispatch is a plain kernel packet for the profiler
+    export LTK_GRAPH=0
     timeout 400 rocprofv3 --pmc FETCH_SIZE -d $P/${n}_pmc_fetch -o r -- $CMD > $P/${n}_pmc_fetch.log 2>&1
     timeout 400 rocprofv3 --pmc WRITE_SIZE -d $P/${n}_pmc_write -o r -- $CMD > $P/${n}_pmc_write.log 2>&1
     timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $P/${n}_pmc_sq -o r -- $CMD > $P/${n}_pmc_sq.log 2>&1
     timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $P/${n}_pmc_l2 -o r -- $CMD > $P/${n}_pmc_l2.log 2>&1
+    unset LTK_GRAPH
   }
   # MuseTalk twice: the weight upload of the model load shows up as ~1100 __amd_rocclr_copyBuffer / ~470 fillBufferAligned launches
   # whatever the number of passes (mt: 3 passes, mt12: 12 passes) - they are not part of a pass
@@ -72,5 +77,15 @@ pmc-layer)
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_MISC -d $P/b -o r -- $CMD > $P/b.log 2>&1
   rocprofv3 --kernel-trace -d $P/t -o r -- $CMD > $P/t.log 2>&1
   tail -3 $P/b.log ;;
+clock)
+  P=$O/clock; rm -rf $P; mkdir -p $P; LAYERS=${*:-c256@64 c64@256}
+  for L in $LAYERS; do for F in random constant zeros random; do timeout 120 python scripts/conv_clock.py $F $L 200 2>&1 | grep "^\[clock\]" >> $P/unprofiled.log; done; done
+  cd /tmp; export TMPDIR=/tmp
+  for L in $LAYERS; do for F in random constant zeros; do
+    timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 \
+      -d $P/${L}_$F -o r -- python $R/scripts/conv_clock.py $F $L 200 > $P/${L}_$F.log 2>&1
+  done; done
+  cd $R; python scripts/clock_report.py $P > $O/clock_report.txt 2>&1; cat $P/unprofiled.log; cat $O/clock_report.txt
+  find $P -name "*.db" -size +20M -delete ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
