@@ -17,7 +17,7 @@ MODE=$1; shift
 case $MODE in
 tests)
   ARGS=${*:-tests}
-  timeout 1500 python -m pytest $ARGS -m gpu -x -q -s 2>&1 | grep -E "^\.*\[|passed|failed|Error|error|FAIL|assert" | grep -v "^\[layer\]\|^\[mt\] [a-z_]*\.[a-z_0-9.]* " > $O/pytest_${TAG:-gpu}.log
+  timeout 1500 python -m pytest $ARGS -m gpu ${MAXFAIL:--x} -q -s 2>&1 | grep -E "^\.*\[|passed|failed|Error|error|FAIL|assert" | grep -v "^\[layer\]\|^\[mt\] [a-z_]*\.[a-z_0-9.]* " > $O/pytest_${TAG:-gpu}.log
   tail -40 $O/pytest_${TAG:-gpu}.log ;;
 bench)
   timeout 600 python bench.py "$@" > $O/bench_${TAG:-default}.json 2> $O/bench_${TAG:-default}.err; tail -c 1500 $O/bench_${TAG:-default}.json ;;
@@ -87,5 +87,21 @@ clock)
   done; done
   cd $R; python scripts/clock_report.py $P > $O/clock_report.txt 2>&1; cat $P/unprofiled.log; cat $O/clock_report.txt
   find $P -name "*.db" -size +20M -delete ;;
+r4a)  # round-4 job A: full GPU suite, graph / depth-first A/B, clock experiment, short bench lines, scheduler in-flight A/B
+  TAG=r4a bash $0 tests tests > /dev/null 2>&1; tail -5 $O/pytest_r4a.log
+  ROUNDS=3 timeout 600 python scripts/layer_times.py "GRAPH=0" "GRAPH=1" "GRAPH=1,DF_FRAMES=4,DF_MIN=1" "GRAPH=1,DF_FRAMES=8,DF_MIN=1" "GRAPH=1,DF_FRAMES=16,DF_MIN=1" \
+      "GRAPH=1,DF_FRAMES=4,DF_MIN=1,DF_BLOCK=7" "GRAPH=1,DF_FRAMES=8,DF_MIN=1,DF_BLOCK=5" -- 16 64 256 2>&1 | grep -E "^====|^sum|^conv stack" > $O/r4a_graph_df_ab.txt; cat $O/r4a_graph_df_ab.txt
+  bash $0 clock c256@64 c64@256 > $O/r4a_clock.log 2>&1; cat $O/clock_report.txt
+  timeout 400 python bench.py --steps 50 --warmup 5 --no-also --no-cpu-baseline > $O/r4a_bench_s1.json 2> $O/r4a_bench_s1.err; head -c 1200 $O/r4a_bench_s1.json; echo
+  for IF in 1 2 1 2; do LTK_INFLIGHT=$IF timeout 300 python bench.py --sessions 16 --steps 10 --warmup 3 --no-also --no-cpu-baseline --no-traffic > $O/r4a_bench_s16_if$IF.json 2>> $O/r4a_bench_s16.err
+    python -c "import json,sys; d=json.load(open('$O/r4a_bench_s16_if$IF.json')); print('inflight $IF', d['value'], d['ms_per_step'], d['roofline']['frac'], d['scheduler'])"; done ;;
+r4b)  # round-4 job B: paste diagnostic, the whole GPU suite (no stop at the first failure), depth-first / stagger / rowconv A/Bs, graph A/B of the timed line
+  timeout 200 python scripts/paste_diag.py 2>&1 | grep "paste-diag" > $O/r4b_paste_diag.txt; cat $O/r4b_paste_diag.txt
+  TAG=r4b MAXFAIL=--maxfail=20 bash $0 tests tests > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4b.log | tail -12
+  ROUNDS=7 timeout 500 python scripts/pass_ab.py "DF_FRAMES=0" "DF_FRAMES=16,DF_MIN=1" "DF_FRAMES=12,DF_MIN=1" "DF_FRAMES=24,DF_MIN=1" "DF_FRAMES=32,DF_MIN=1" "DF_FRAMES=16,DF_MIN=1,DF_BLOCK=5" "DF_FRAMES=16,DF_MIN=1,DF_BLOCK=7" "DF_FRAMES=16,DF_MIN=1,DF_BLOCK=4" -- 32 48 64 128 256 > $O/r4b_df_ab.txt 2>&1; cat $O/r4b_df_ab.txt
+  ROUNDS=7 timeout 500 python scripts/pass_ab.py "STAGGER=0" "STAGGER=3000" "STAGGER=8000" "STAGGER=16000" "STAGGER=30000" "STAGGER=8000,STAGGER_MODE=1" "STAGGER=16000,STAGGER_MODE=1" -- 16 64 256 > $O/r4b_stagger_ab.txt 2>&1; cat $O/r4b_stagger_ab.txt
+  ROUNDS=7 timeout 300 python scripts/pass_ab.py "ROWCONV=1024" "ROWCONV=2048" "ROWCONV=0" -- 16 32 > $O/r4b_rowconv_ab.txt 2>&1; cat $O/r4b_rowconv_ab.txt
+  for G in 0 1 0 1; do LTK_GRAPH=$G timeout 300 python bench.py --steps 100 --warmup 5 --no-also --no-cpu-baseline --no-traffic > $O/r4b_bench_g$G.json 2>> $O/r4b_bench.err
+    python -c "import json; d=json.load(open('$O/r4b_bench_g$G.json')); print('graph $G', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], d['roofline']['hipgraph'], d['pcie_inclusive']['value'])"; done ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

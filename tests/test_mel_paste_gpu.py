@@ -60,7 +60,10 @@ def test_paste_bit_exact(engine, golden_dir):
                                                  box=int(gw["avatar_box"]), seed=int(gw["avatar_seed"]))
     aid = engine.register_avatar(faces, frames, coords)
     B, index = int(gw["batch"]), int(gw["index"])
-    pred_u8 = np.stack([faces[(i + 1) % len(faces)] for i in range(B)])      # oracle/gen_golden.py paste_pred: deterministic bytes
+    # oracle/gen_golden.py paste_pred: deterministic bytes.  (The synthetic crops are transposed VIEWS and np.stack keeps their
+    # memory order: without the explicit C-contiguous copy the device would receive a transposed image.)
+    pred_u8 = np.ascontiguousarray(np.stack([faces[(i + 1) % len(faces)] for i in range(B)]))
+    assert pred_u8.flags["C_CONTIGUOUS"] and pred_u8[0].flags["C_CONTIGUOUS"]
     for i in range(B):
         idx = paste_oracle.mirror_index(len(frames), index + i)
         d_pred = torch.from_numpy(pred_u8[i]).cuda()
