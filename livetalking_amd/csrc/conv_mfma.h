@@ -162,6 +162,9 @@ struct RowConvIO {
     int N = 0, KW = 3, stride = 1, pad = 1, relu = 1;
 };
 int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream, std::string* err);
+// ConvTranspose2d(k3, s2, p1, op1) on a source map of <= 8 x 8 pixels: four per-phase plans p[py * 2 + px] over
+// W_eff[j][(dy * (1 + px) + dx) * C + c] = w[c][j][py + 1 - 2 dy][px + 1 - 2 dx], one launch; io.H x io.W source, io.Ho x io.Wo = 2H x 2W output
+int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t stream, std::string* err);
 
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;

@@ -133,6 +133,7 @@ struct Layer {
     int rg_y_ld = 0;               // output row pitch of that GEMM (the 1x1-expand layer writes k*k*Cout contiguous channels)
     bool rowconv = false;          // `rg` is a rowconv plan instead: 3x3 conv on a map of <= 8 x 8 output pixels (rowgemm.hip)
     int rc_stride = 1;
+    RowGemmPlan rgT[4];            // ConvTranspose2d(k3,s2,p1,op1) on a source map of <= 8 x 8 pixels: one plan per output phase (rowconvT_launch)
     int cin_real = 0;
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
     int out_buf = 0, out_ld = 0, out_coff = 0, Ho = 0, Wo = 0;
@@ -454,6 +455,24 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rowconv = true;
             L->rc_stride = d.sh;
+        } else if (want_rowconv && map_w > 0 && map_w <= 8 && d.transposed && d.k == 3 && d.sh == 2 && d.sw == 2 && d.pad == 1 && d.out_pad == 1 &&
+                   (d.cin == 256 || d.cin == 512 || d.cin == 1024) && d.cout % 256 == 0) {
+            // stride-2 transposed conv on the 4x4 / 8x8 maps: output pixel (2y + py, 2x + px) = sum over (dy, dx) of x[y + dy][x + dx] * w[:, :, ky, kx]
+            // with ky = py + 1 - 2 dy, kx = px + 1 - 2 dx (torch ConvTranspose2d: oy = 2 iy - 1 + ky; weight layout [cin][cout][kh][kw])
+            for (int gph = 0; gph < 4; ++gph) {
+                const int py = gph >> 1, px = gph & 1, ny = 1 + py, nx = 1 + px;
+                J = d.cout; K = ny * nx * d.cin;
+                we.assign((size_t)J * K, 0.f);
+                for (int dy = 0; dy < ny; ++dy)
+                    for (int dx = 0; dx < nx; ++dx) {
+                        const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx, t = dy * nx + dx;
+                        for (int co = 0; co < d.cout; ++co)
+                            for (int ci = 0; ci < d.cin; ++ci)
+                                we[(size_t)co * K + (size_t)t * d.cin + ci] = w[((size_t)ci * d.cout + co) * 9 + ky * 3 + kx];
+                    }
+                rc = rowgemm_plan_create(&L->rgT[gph], we.data(), J, K, sc.data(), sf.data(), &err);
+                if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+            }
         }
     }
     if (!d.transposed && d.k == 7 && d.cin == 6 && d.cout == 16 && d.sh == 1 && d.pad == 3 && knob(K_CONV7) && !e->c7) {
@@ -471,7 +490,10 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
 // that is retried would otherwise leak the packed weights each time)
 int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0) {
     const int rc = build_layer_impl(e, d, sd, n, L, hint_hw, flat_ld, map_w);
-    if (rc) { conv_plan_destroy(&L->plan); rowgemm_plan_destroy(&L->rg); }
+    if (rc) {
+        conv_plan_destroy(&L->plan); rowgemm_plan_destroy(&L->rg);
+        for (RowGemmPlan& q : L->rgT) rowgemm_plan_destroy(&q);
+    }
     return rc;
 }
 
@@ -488,7 +510,10 @@ void drop_graphs(ltk_engine* e) {
 void wav2lip_unload(ltk_engine* e) {
     drop_graphs(e);
     if (e->d_tab) { (void)hipFree(e->d_tab); e->d_tab = nullptr; }
-    for (Layer& L : e->layers) { conv_plan_destroy(&L.plan); rowgemm_plan_destroy(&L.rg); }
+    for (Layer& L : e->layers) {
+        conv_plan_destroy(&L.plan); rowgemm_plan_destroy(&L.rg);
+        for (RowGemmPlan& q : L.rgT) rowgemm_plan_destroy(&q);
+    }
     e->layers.clear();
     for (int i = 0; i < B_COUNT; ++i)
         if (e->buf[i]) { (void)hipFree(e->buf[i]); e->buf[i] = nullptr; }
@@ -672,6 +697,13 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
             rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
             rio.N = n; rio.KW = 3; rio.stride = L.rc_stride; rio.pad = 1; rio.relu = 1;
             rc = rowconv_launch(L.rg, rio, on_aux ? e->aux : s, &err);
+        } else if (L.rgT[0].d_w && (long long)n * L.H * L.W <= std::min(knob(K_ROWCONVT), kRowConvMaxRows) && knob(K_ROWCONV) > 0 && knob(K_SPLITK)) {
+            // stride-2 transposed convs on the 4x4 / 8x8 maps: four per-phase weight-streaming GEMMs in one launch (no split-K finish)
+            RowConvIO rio;
+            rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;
+            rio.y = io.y; rio.y_ld = L.out_ld; rio.y_coff = L.out_coff; rio.Ho = L.Ho; rio.Wo = L.Wo;
+            rio.N = n; rio.relu = 1;
+            rc = rowconvT_launch(L.rgT, rio, on_aux ? e->aux : s, &err);
         } else if (!L.rowconv && L.rg.d_w && n <= kRowGemmMaxFrames && knob(K_ROWGEMM) && knob(K_SPLITK) &&
                    // the k x k expansion of a one-pixel map writes k*k*Cout contiguous columns per frame: only into a dense output
                    // (a CAT buffer's skip channels would be overwritten)

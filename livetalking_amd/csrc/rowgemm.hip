@@ -124,6 +124,12 @@ struct RowConvArgs {
     int M;                                // rows: N * Ho * Wo
     int NR;                               // row groups (16 * FT rows each)
     int relu;
+    // Sub-pixel phases of a stride-2 transposed conv (nph = 4, gridDim.y = phase; nph = 1: a plain conv, the fields above).  Rows are
+    // SOURCE pixels (n, y, x) of the H x W = Ho x Wo map; phase (py, px) owns output pixel (2y + py, 2x + px) of the 2H x 2W map and
+    // contracts its own 1 / 2 / 2 / 4 taps (dy, dx) = (t / kw, t % kw) of the source window at (y + dy, x + dx).
+    int nph;
+    int Wout, HWout;                      // output map row pitch and plane size used for addressing (= Wo, Ho * Wo when nph == 1)
+    struct Phase { const f16* w; const float* scale; const float* shift; int KT, KW, oy_add, ox_add; } ph[4];
 };
 
 // FT: 16-row tiles per block; UB: k-steps in flight per trip.  Measured (profiles/r03_rowconv_ab.txt): deeper trips (9 / 6 steps), 32-row
@@ -138,11 +144,18 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
     // XCD-aware order: hardware block b runs on XCD b & 7; all row groups of a channel pair share their weights through that XCD's L2
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int jb = xcd + 8 * (slot / a.NR), rg = slot % a.NR;  // host: (J / 32) % 8 == 0
-    const int per = (a.KT + 7) >> 3;
-    const int k0 = wave * per, k1 = min(a.KT, k0 + per);
+    const bool phased = a.nph > 1;
+    const int pz = phased ? (int)blockIdx.y : 0;
+    const int KT = phased ? a.ph[pz].KT : a.KT, KW = phased ? a.ph[pz].KW : a.KW;
+    const f16* const wbase = phased ? a.ph[pz].w : a.w;
+    const float* const scale = phased ? a.ph[pz].scale : a.scale;
+    const float* const shift = phased ? a.ph[pz].shift : a.shift;
+    const int omul = phased ? 2 : 1, oy_add = phased ? a.ph[pz].oy_add : 0, ox_add = phased ? a.ph[pz].ox_add : 0;
+    const int per = (KT + 7) >> 3;
+    const int k0 = wave * per, k1 = min(KT, k0 + per);
     const int i16 = lane & 15, g = lane >> 4;
-    const f16x8* wp = reinterpret_cast<const f16x8*>(a.w) + ((size_t)(jb * JT) * a.KT) * 64 + lane;
-    const size_t wj = (size_t)a.KT * 64;                       // fragments between the block's two 16-channel slabs
+    const f16x8* wp = reinterpret_cast<const f16x8*>(wbase) + ((size_t)(jb * JT) * KT) * 64 + lane;
+    const size_t wj = (size_t)KT * 64;                         // fragments between the block's two 16-channel slabs
     const int HWi = a.H * a.W, HWo = a.Ho * a.Wo;
     // this lane's row of each 16-row tile: frame, top-left input pixel of its window
     int iy0[FT], ix0[FT];
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
     // operand of k-step k for row tile ft: tap = k >> cpt_log2 (wave-uniform), 32 channels from (k & cmask) * 32
     auto xload = [&](int k, int ft) -> f16x8 {
         const int tap = k >> a.cpt_log2, cc = k & cmask;
-        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+        const int ky = tap / KW, kx = tap - ky * KW;
         const int iy = iy0[ft] + ky, ix = ix0[ft] + kx;
         const bool ok = live[ft] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         return ok ? *reinterpret_cast<const f16x8*>(xn[ft] + ((size_t)(cc * 2) * HWi + iy * a.W + ix) * 16) : zero;
@@ -221,15 +234,17 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
             // D layout of the 16x16 MFMA: lane holds output channels 4g .. 4g+3 of row i16
             const int r = (rg * FT + ft) * 16 + i16;
             if (r < a.M) {
-                const int n = r / HWo, pix = r - n * HWo;
+                const int n = r / HWo, rpix = r - n * HWo;
+                const int ry = rpix / a.Wo, rx = rpix - ry * a.Wo;
+                const int pix = (ry * omul + oy_add) * a.Wout + rx * omul + ox_add;      // output pixel inside its plane
                 const int cb = jb * JT + jt;                   // 16-channel block of the output
                 const int j0 = cb * 16 + 4 * g;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + j0), sf = *reinterpret_cast<const f32x4*>(a.shift + j0);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + j0), sf = *reinterpret_cast<const f32x4*>(shift + j0);
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = s[q] * sc[q] + sf[q];
                 if (a.res) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4*>(a.res + (((size_t)n * a.res_cbt + a.res_cb0 + cb) * HWo + pix) * 16 + 4 * g);
+                    const f16x4 rv = *reinterpret_cast<const f16x4*>(a.res + (((size_t)n * a.res_cbt + a.res_cb0 + cb) * a.HWout + pix) * 16 + 4 * g);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] += (float)rv[q];
                 }
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     o[q] = (f16)(a.relu ? __builtin_amdgcn_fmed3f(v[q], 0.f, 65504.f) : __builtin_amdgcn_fmed3f(v[q], -65504.f, 65504.f));
-                *reinterpret_cast<f16x4*>(a.y + (((size_t)n * a.y_cbt + a.y_cb0 + cb) * HWo + pix) * 16 + 4 * g) = o;
+                *reinterpret_cast<f16x4*>(a.y + (((size_t)n * a.y_cbt + a.y_cb0 + cb) * a.HWout + pix) * 16 + 4 * g) = o;
             }
         }
     }
@@ -308,6 +323,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift;
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.pad = io.pad; a.KW = io.KW;
     a.cpt_log2 = cl; a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
+    a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
     const int tiles = (int)((M + 15) / 16);
     const int FT = tiles * (p.J / 32) <= 512 ? 2 : 4;          // ~2 blocks per CU's worth of row groups before the tiles grow
     a.NR = (tiles + FT - 1) / FT;
@@ -315,6 +331,45 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     if (FT == 2) hipLaunchKernelGGL((rowconv_kernel<2, 6>), dim3(grid), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((rowconv_kernel<4, 4>), dim3(grid), dim3(512), 0, stream, a);
     if (hipGetLastError() != hipSuccess) { if (err) *err = "rowconv: launch failed"; return -2; }
+    return 0;
+}
+
+// ConvTranspose2d(k3, s2, p1, op1) on a map of <= 8 x 8 pixels as four weight-streaming GEMMs, one per output sub-pixel phase, in ONE
+// launch (gridDim.y = phase): phase (py, px) has ny * nx taps, ny = 1 + py, nx = 1 + px (wav2lip_v2.py:63,65: face_decoder_blocks.2.0 /
+// 3.0; conv3 ran them as 192..256 merged-phase items behind a split-K finish launch).  `p[g]`, g = py * 2 + px: plan over
+// W_eff[j][t * C + c], t = dy * nx + dx.  io.H x io.W is the source map, io.Ho x io.Wo = 2H x 2W the output map.
+int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t stream, std::string* err) {
+    if (!p || !p[0].d_w || io.N <= 0 || io.Ho != 2 * io.H || io.Wo != 2 * io.W) { if (err) *err = "rowconvT: no plan / bad geometry"; return -1; }
+    const int C = p[0].K, J = p[0].J;                         // phase 0 has one tap
+    int cl = 0;
+    while ((32 << cl) < C) ++cl;
+    if ((32 << cl) != C || J % 256) { if (err) *err = "rowconvT: channels must be 32 * 2^n, output channels a multiple of 256"; return -1; }
+    if (((io.x_ld | io.x_coff | io.y_ld | io.y_coff) & 15) || io.x_coff + C > io.x_ld || io.y_coff + J > io.y_ld) {
+        if (err) *err = "rowconvT: channel pitch / offset"; return -1;
+    }
+    const long long M = (long long)io.N * io.H * io.W;
+    if (M > kRowConvMaxRows) { if (err) *err = "rowconvT: more rows than it is built for"; return -1; }
+    RowConvArgs a;
+    a.x = io.x; a.x_cbt = io.x_ld >> 4; a.x_cb0 = io.x_coff >> 4;
+    a.y = io.y; a.y_cbt = io.y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
+    a.res = nullptr; a.res_cbt = 0; a.res_cb0 = 0;
+    a.w = p[0].d_w; a.scale = p[0].d_scale; a.shift = p[0].d_shift;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
+    a.cpt_log2 = cl; a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
+    a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
+    for (int g = 0; g < 4; ++g) {
+        const int py = g >> 1, px = g & 1;
+        if (!p[g].d_w || p[g].J != J || p[g].K != (1 + py) * (1 + px) * C) { if (err) *err = "rowconvT: phase plan mismatch"; return -1; }
+        a.ph[g].w = p[g].d_w; a.ph[g].scale = p[g].d_scale; a.ph[g].shift = p[g].d_shift;
+        a.ph[g].KT = p[g].K / 32; a.ph[g].KW = 1 + px; a.ph[g].oy_add = py; a.ph[g].ox_add = px;
+    }
+    const int tiles = (int)((M + 15) / 16);
+    const int FT = tiles * (J / 32) <= 512 ? 2 : 4;
+    a.NR = (tiles + FT - 1) / FT;
+    const dim3 grid((unsigned)((J / 32) * a.NR), 4u);
+    if (FT == 2) hipLaunchKernelGGL((rowconv_kernel<2, 6>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((rowconv_kernel<4, 4>), grid, dim3(512), 0, stream, a);
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "rowconvT: launch failed"; return -2; }
     return 0;
 }
 

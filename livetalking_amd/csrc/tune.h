@@ -43,6 +43,9 @@ enum Knob {
                           //                    many frames (producer -> consumer tensors stay in the 256 MiB Infinity Cache); 0 = layer by layer
     K_DF_BLOCK,           // LTK_DF_BLOCK       first decoder block of the depth-first region (6: the 128^2 and 256^2 levels)
     K_DF_MIN,             // LTK_DF_MIN         depth-first only for launches of at least this many frames
+    K_ROWCONVT,           // LTK_ROWCONVT       the stride-2 transposed convs on the 4x4 / 8x8 maps as per-phase weight-streaming GEMMs (rowconvT_launch)
+                          //                    when the launch has at most this many SOURCE pixels (frames x H x W), instead of conv3's merged-phase
+                          //                    items + split-K finish; 0 = never.  512: measured (profiles/r04_rowconvT_ab.txt) - 256 rows -7.5 us, 1024 rows +-0
     K_COUNT
 };
 

@@ -29,6 +29,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_DF_FRAMES", 0},
     {"LTK_DF_BLOCK", 6},
     {"LTK_DF_MIN", 32},
+    {"LTK_ROWCONVT", 512},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

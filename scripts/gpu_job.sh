@@ -103,5 +103,9 @@ r4b)  # round-4 job B: paste diagnostic, the whole GPU suite (no stop at the fir
   ROUNDS=7 timeout 300 python scripts/pass_ab.py "ROWCONV=1024" "ROWCONV=2048" "ROWCONV=0" -- 16 32 > $O/r4b_rowconv_ab.txt 2>&1; cat $O/r4b_rowconv_ab.txt
   for G in 0 1 0 1; do LTK_GRAPH=$G timeout 300 python bench.py --steps 100 --warmup 5 --no-also --no-cpu-baseline --no-traffic > $O/r4b_bench_g$G.json 2>> $O/r4b_bench.err
     python -c "import json; d=json.load(open('$O/r4b_bench_g$G.json')); print('graph $G', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], d['roofline']['hipgraph'], d['pcie_inclusive']['value'])"; done ;;
+r4c)  # round-4 job C: per-phase rowconv for the small-map transposed convs
+  TAG=r4c MAXFAIL=--maxfail=20 bash $0 tests tests/test_wav2lip_gpu.py tests/test_mel_paste_gpu.py tests/test_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rowconv" $O/pytest_r4c.log | tail -16
+  ROUNDS=9 timeout 300 python scripts/pass_ab.py "ROWCONVT=0" "ROWCONVT=1" -- 16 8 4 > $O/r4c_rowconvT_ab.txt 2>&1; cat $O/r4c_rowconvT_ab.txt
+  ROUNDS=3 timeout 300 python scripts/layer_times.py "ROWCONVT=0" "ROWCONVT=1" -- 16 2>&1 | grep -E "^====|face_decoder_blocks.[123]|^sum|^conv stack" > $O/r4c_rowconvT_layers.txt; cat $O/r4c_rowconvT_layers.txt ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
