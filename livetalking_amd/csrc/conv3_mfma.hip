@@ -25,6 +25,11 @@
 // line, which is what pixel-interleaved NHWC costs a 16-channel chunk).
 // A-patch image in LDS, per channel block: [patch pixel][2 x 16 B], the two halves swapped where bit 3 of the
 // pixel slot is set, so the 16-lane groups of ds_read_b128 (32-B lane stride) hit 16 distinct 16-B slots.
+// Stride-2 convolutions (S = 2) read every OTHER patch pixel (64-B lane stride: lanes i and i + 4 of a 16-lane group would share a
+// bank, a 4-way conflict - SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles of this instantiation in round 3).  Their image permutes the
+// four 16-B units of every aligned pixel PAIR instead: unit q = 2 * (column & 1) + half sits at q ^ ((column >> 3) & 3), so the four
+// 256-B windows a 16-lane group touches use four different unit slots.  The permutation stays inside 64 B of a row, so the LDS-DMA
+// still moves whole lines; the patch row pitch is even for S = 2.
 #include "conv_mfma.h"
 #include "misc_kernels.h"
 #include "tune.h"
@@ -151,9 +156,10 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // ---- zero both A stages once: halo slots outside the image are never written by the DMA
     if (!ABL(a, 32)) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const bool two = c_end - c_begin > 1;               // a one-chunk item (16-channel layers) never touches the second stage
         for (int i = tid * 16; i < A_BYTES; i += 256 * 16) {
             *reinterpret_cast<uint4*>(smem + i) = z;
-            *reinterpret_cast<uint4*>(smem + STAGE + i) = z;
+            if (two) *reinterpret_cast<uint4*>(smem + STAGE + i) = z;
         }
     }
 
@@ -181,8 +187,15 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int rem = pix - b * PHW;
         const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
         const int px = rem - py * a.PW;
-        const int half = (slot & 1) ^ ((px >> 3) & 1);      // the two 16-B halves swap where bit 3 of the patch COLUMN is set
-        const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
+        int half, pxs = px;                                 // source column / half that this LDS slot holds
+        if constexpr (S == 2) {
+            const int q = (2 * (px & 1) + (slot & 1)) ^ ((px >> 3) & 3);      // self-inverse: slot unit -> source unit
+            pxs = (px & ~1) | (q >> 1);
+            half = q & 1;
+        } else {
+            half = (slot & 1) ^ ((px >> 3) & 1);            // the two 16-B halves swap where bit 3 of the patch COLUMN is set
+        }
+        const int n = n0 + b, iy = iy0 + py, ix = ix0 + pxs;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
         a_goff[k] = ok ? (unsigned)((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) * 2u : ~0u;
@@ -235,8 +248,15 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int prow = in ? (b * a.PH + ty * S) * a.PW : 0;
         const int pcol = in ? tx * S : 0;
 #pragma unroll
-        for (int dx = 0; dx < DXN; ++dx)
-            aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ (Q == 2 ? 0 : hh)) << 4);     // Q = 2 reads both halves
+        for (int dx = 0; dx < DXN; ++dx) {
+            if constexpr (S == 2) {
+                const int pc = pcol + dx;
+                const int q = (2 * (pc & 1) + hh) ^ ((pc >> 3) & 3);
+                aj[j][dx] = (prow + ((pc & ~1) | (q >> 1))) * 32 + ((q & 1) << 4);
+            } else {
+                aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ (Q == 2 ? 0 : hh)) << 4);     // Q = 2 reads both halves
+            }
+        }
     }
 
     f32x16 acc[G][NBT][PXW];
@@ -857,6 +877,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         NB = M >> (l2w + l2h);
         NB = std::max(1, std::min(NB, io.N));
         PH = ((1 << l2h) - 1) * S + 1 + ext; PW = ((1 << l2w) - 1) * S + 1 + ext;
+        if (S == 2) PW = (PW + 1) & ~1;                      // the stride-2 LDS image permutes units inside aligned pixel pairs of a row
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
         while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S, T) * 256) --NB;
         npix = NB * PH * PW;

@@ -571,11 +571,12 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
 
     if (v3_on && !p->v3 && !transposed && Cin % 16 == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 &&
         ((ph == 1 && pw == 1 && out_pad == 0) || (ph == 0 && pw == 0 && out_pad == 1)) && knob(K_CONV_V3_S2) &&
-        // measured (scripts/conv_sweep.py, 16 frames): the 2x-strided LDS operand reads make conv3 slower than the
-        // register-staged kernel on the wide, shallow downsamples (16->32 @256^2: 29 vs 18 us); it wins where the
-        // K loop is deep and split-K fills the chip (256->512 @16^2: 18 vs 27 us, 512->512 @8^2: 19 vs 46 us).
-        // The asymmetric-pad form exists only in conv3.
-        (Cin >= 256 || out_pad == 1 || knob(K_CONV_V3_S2) == 2)) {
+        // measured in the pass (profiles/r04_s2_conflict_free.txt; conv3's stride-2 LDS image is bank-conflict free since round 4), register-
+        // staged kernel -> conv3, 16 / 256 frames: 64->128 @64^2 16.9 -> 16.4 / 127 -> 94 us, 128->256 @32^2 20.4 -> 17.2 / 93 -> 69 us: conv3 from
+        // 64 input channels on.  The wide, shallow ones stay register-staged: 16->32 @256^2 22.7 -> 30.5 / 249 -> 389 us (one 16-channel chunk per
+        // item: 18 MFMAs per wave behind a 36-KB patch copy), 32->64 @128^2 15.0 -> 16.9 at 16 frames (-52 us at 256: a per-launch choice would
+        // need both weight packs).  The asymmetric-pad form exists only in conv3.
+        (Cin >= 64 || out_pad == 1 || knob(K_CONV_V3_S2) == 2)) {
         p->v3 = true; p->v3_G = 1; p->v3_T = 9; p->v3_S = 2;
     }
     if (v3_on && !p->v3 && Cin % 16 == 0 && lsh == 1 && lsw == 1) {

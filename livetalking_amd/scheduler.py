@@ -58,6 +58,8 @@ class BatchingScheduler:
         self._cv = threading.Condition()
         self._pending = collections.deque()
         self._inflight = 0                 # engine calls issued and not yet returned (leaders + workers)
+        self._inflight_frames = 0          # frames of those calls
+        self._lead_frac = max(0.0, float(os.environ.get("LTK_INFLIGHT_LEAD_FRAC", "0.1")))
         self._max_inflight = max(1, int(os.environ.get("LTK_INFLIGHT", "2")))
         self._lead = max(0.0, float(os.environ.get("LTK_INFLIGHT_LEAD_US", "300"))) * 1e-6
         self._spf = None                   # seconds per frame of a call that had the engine to itself (EWMA)
@@ -124,6 +126,7 @@ class BatchingScheduler:
                 self._leader_hold = False
             group, frames = self._take_batch()
             now = time.perf_counter()
+            self._inflight_frames += frames
             if self._spf is not None:
                 self._busy_until = max(now, self._busy_until) + frames * self._spf
             if not alone:
@@ -160,8 +163,9 @@ class BatchingScheduler:
                     spf = (t1 - max(t0, self._last_done)) / frames
                     self._spf = spf if self._spf is None else 0.75 * self._spf + 0.25 * spf
             self._last_done = t1
-            if self._inflight == 0:
-                self._busy_until = t1
+            self._inflight_frames -= frames
+            # re-anchor the prediction at every completion (calls complete in issue order): what is still in flight starts now
+            self._busy_until = t1 + (self._inflight_frames * self._spf if self._spf is not None else 0.0)
             if self._pending:
                 self._ensure_workers()
             self._cv.notify_all()
@@ -187,7 +191,10 @@ class BatchingScheduler:
                         if self._inflight == 0:
                             break
                         if self._inflight < self._max_inflight and self._spf is not None:
-                            wait_t = self._busy_until - self._lead - now
+                            # lead: the fixed floor, or a tenth of what is in flight (thread wake-ups under 16 session threads are not
+                            # 300-us precise; the requests of the sessions that are not in flight have all arrived long before)
+                            lead = max(self._lead, self._lead_frac * self._inflight_frames * self._spf)
+                            wait_t = self._busy_until - lead - now
                             if wait_t <= 0.0:
                                 break
                             self._cv.wait(timeout=wait_t)

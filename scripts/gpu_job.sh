@@ -107,5 +107,14 @@ r4c)  # round-4 job C: per-phase rowconv for the small-map transposed convs
   TAG=r4c MAXFAIL=--maxfail=20 bash $0 tests tests/test_wav2lip_gpu.py tests/test_mel_paste_gpu.py tests/test_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rowconv" $O/pytest_r4c.log | tail -16
   ROUNDS=9 timeout 300 python scripts/pass_ab.py "ROWCONVT=0" "ROWCONVT=1" -- 16 8 4 > $O/r4c_rowconvT_ab.txt 2>&1; cat $O/r4c_rowconvT_ab.txt
   ROUNDS=3 timeout 300 python scripts/layer_times.py "ROWCONVT=0" "ROWCONVT=1" -- 16 2>&1 | grep -E "^====|face_decoder_blocks.[123]|^sum|^conv stack" > $O/r4c_rowconvT_layers.txt; cat $O/r4c_rowconvT_layers.txt ;;
+r4d)  # round-4 job D: conv3 stride-2 with the conflict-free LDS image (default routing and LTK_CONV_V3_S2=2 = every stride-2 3x3 layer on conv3); scheduler in-flight A/B
+  TAG=r4d MAXFAIL=--maxfail=20 bash $0 tests tests/test_conv_gpu.py tests/test_wav2lip_gpu.py tests/test_musetalk_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4d.log | tail -8
+  LTK_CONV_V3_S2=2 TAG=r4d_s2all MAXFAIL=--maxfail=20 bash $0 tests tests/test_conv_gpu.py tests/test_wav2lip_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4d_s2all.log | tail -8
+  for rnd in 1 2; do for V in 1 2; do
+    echo "######## round $rnd LTK_CONV_V3_S2=$V" >> $O/r4d_s2_layers.txt
+    LTK_CONV_V3_S2=$V ROUNDS=3 timeout 300 python scripts/layer_times.py "GRAPH=1" -- 16 256 2>&1 | grep -E "^====|face_encoder_blocks.[1-6].0|^sum|^conv stack" >> $O/r4d_s2_layers.txt
+  done; done; cat $O/r4d_s2_layers.txt
+  for IF in 1 2 1 2 1 2; do LTK_INFLIGHT=$IF timeout 300 python bench.py --sessions 16 --steps 12 --warmup 3 --no-also --no-cpu-baseline --no-traffic > $O/r4d_bench_s16_if$IF.json 2>> $O/r4d_bench_s16.err
+    python -c "import json,sys; d=json.load(open('$O/r4d_bench_s16_if$IF.json')); print('inflight $IF', d['value'], d['ms_per_step'], d['roofline']['frac'], d['scheduler'])" | tee -a $O/r4d_inflight.txt; done ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
