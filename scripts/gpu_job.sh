@@ -116,5 +116,14 @@ r4d)  # round-4 job D: conv3 stride-2 with the conflict-free LDS image (default 
   done; done; cat $O/r4d_s2_layers.txt
   for IF in 1 2 1 2 1 2; do LTK_INFLIGHT=$IF timeout 300 python bench.py --sessions 16 --steps 12 --warmup 3 --no-also --no-cpu-baseline --no-traffic > $O/r4d_bench_s16_if$IF.json 2>> $O/r4d_bench_s16.err
     python -c "import json,sys; d=json.load(open('$O/r4d_bench_s16_if$IF.json')); print('inflight $IF', d['value'], d['ms_per_step'], d['roofline']['frac'], d['scheduler'])" | tee -a $O/r4d_inflight.txt; done ;;
+r4e)  # round-4 job E: concurrency test, delivered capacity with / without the graph path, the MuseTalk sub-bench with its measured delivered run
+  TAG=r4e MAXFAIL=--maxfail=20 bash $0 tests tests/test_plugin_gpu.py tests/test_mel_paste_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|in flight" $O/pytest_r4e.log | tail -8
+  for G in 0 1 0 1; do LTK_GRAPH=$G timeout 400 python bench.py --sub delivered-capacity --batch 16 --delivered-sessions 384,448,512 > $O/r4e_delivered_g$G.json 2>> $O/r4e_delivered.err
+    python -c "
+import json; d=json.load(open('$O/r4e_delivered_g$G.json'))
+for f in ('bgr24','i420'): print('graph $G', f, [(t['sessions'], t.get('latency_ms_max'), t.get('sustained')) for t in d[f]['tested']])" | tee -a $O/r4e_delivered.txt; done
+  timeout 900 python bench.py --sub musetalk-both --batch 16 > $O/r4e_musetalk_both.json 2> $O/r4e_musetalk_both.err; python -c "
+import json; d=json.load(open('$O/r4e_musetalk_both.json'))
+for o in d: print(o.get('value'), o.get('roofline',{}).get('frac'), o.get('sessions_25fps'), json.dumps(o.get('delivered'))[:900])" ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

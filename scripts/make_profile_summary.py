@@ -51,7 +51,12 @@ def main():
         a.dst_prefix = f"{a.dst_prefix}_{a.name}"
     os.makedirs(os.path.dirname(a.dst_prefix) or ".", exist_ok=True)
     db = sqlite3.connect(os.path.join(sub("trace"), "r_results.db"))
-    rows = db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, stream_id from kernels order by start").fetchall()
+    try:
+        rows = db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, stream_id, grid_y, workgroup_y "
+                          "from kernels order by start").fetchall()
+    except sqlite3.OperationalError:
+        rows = [r + (0, 1) for r in db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, stream_id "
+                                               "from kernels order by start").fetchall()]
     stats = collections.OrderedDict()
     for r in rows:
         s = stats.setdefault(short(r[0]), [0, 0.0, 1e30, 0.0, r[6], r[7]])
@@ -76,6 +81,10 @@ def main():
         f.write("# last inference pass of the profiled run: start_us dur_us stream grid lds_bytes kernel\n")
         if idx:
             t0 = rows[idx[-1]][1]
+            # pack_mel_kernel runs one grid row per frame: the frame count of THIS pass (a multi-session run coalesces calls of different sizes)
+            pm = rows[idx[-1]]
+            nfr = pm[9] // max(pm[10], 1) if pm[9] else 0
+            f.write(f"# frames in the listed pass: {nfr if nfr else 'unknown (no grid_y in the trace)'}\n")
             for r in rows[idx[-1]:]:
                 n = short(r[0])
                 f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{r[8]} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")

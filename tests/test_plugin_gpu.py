@@ -203,3 +203,54 @@ def test_paste_back_batch_equals_per_frame_and_frames_stay_valid():
     finally:
         for e in model.engines:
             e.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_sessions_two_calls_in_flight_bit_identical():
+    """The defaults of round 4 together on ONE engine: continuous batching with up to two engine calls in flight (scheduler.py) over
+    passes replayed from captured hipGraphs (knob GRAPH).  Six session threads run five steps each, free-running, each at its own
+    bank position with its own mel windows; whatever they were batched with and whether their call was issued while another was
+    still running, every session gets byte for byte the frames it gets alone (LTK_SPLITK=0: one summation order per output element
+    whatever the launch's frame count), and the scheduler did overlap calls."""
+    import argparse
+    import threading
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd.engine import Engine
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    S, B, STEPS = 6, 4, 5
+    Engine.set_knob("SPLITK", 0)
+    model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=S * B, device=0)
+    try:
+        avatar = synth.wav2lip_avatar(n_frames=5, full_hw=(360, 640), box=160, seed=0)
+        sessions = [plugin.LipReal(argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=s), model, avatar) for s in range(S)]
+        rng = np.random.default_rng(11)
+        feats = [torch.from_numpy(rng.standard_normal((B, 80, 16)).astype(np.float32)).cuda() for _ in range(S)]
+        alone = []
+        for s in range(S):                                   # reference: every session on its own, one call at a time
+            alone.append([torch.stack(sessions[s].inference_batch(3 * s + step * B, feats[s])).cpu() for step in range(STEPS)])
+        together = [[None] * STEPS for _ in range(S)]
+        go = threading.Barrier(S)
+
+        def run(s):
+            go.wait()
+            for step in range(STEPS):
+                together[s][step] = torch.stack(sessions[s].inference_batch(3 * s + step * B, feats[s])).cpu()
+
+        ts = [threading.Thread(target=run, args=(s,)) for s in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+            assert not t.is_alive()
+        for s in range(S):
+            for step in range(STEPS):
+                assert torch.equal(together[s][step], alone[s][step]), (s, step)
+        st = sessions[0]._sched.stats
+        print(f"[in flight] {st}; graphs captured: {model.engine.graph_count()}")
+        assert st["requests"] == S * STEPS * 2 and st["max_requests_per_call"] >= 2
+        assert model.engine.graph_count() >= 1
+    finally:
+        Engine.set_knob("SPLITK", 1)
+        for e in model.engines:
+            e.close()
