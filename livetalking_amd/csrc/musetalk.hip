@@ -75,6 +75,9 @@ struct MtOp {
     std::string name;
     MtTensor x, y, r, k, v;     // r: residual; attention: x = q, k, v
     int plan = -1;
+    int rplan = -1;             // index into MtGraph::rplans: the same layer as a weight-streaming GEMM over gathered rows (rowgemm.hip rowconv)
+    int ksz = 1;                // its kernel size (1 or 3)
+    bool unet3x3 = false;       // 3x3 stride-1 fp16 conv of the U-Net (maps of <= 32 x 32): measured per-level tile choice (mt_graph_run)
     int act = 0, ups = 0;
     int gamma = -1, beta = -1;  // indices into MtGraph::vecs
     int groups = 32, silu = 0;
@@ -87,6 +90,7 @@ struct MtGraph {
     std::vector<size_t> buf_halfs;           // per frame
     std::vector<f16*> bufs;
     std::vector<ConvPlan> plans;
+    std::vector<RowGemmPlan> rplans;         // small-map layers (<= 64 pixels / tokens per frame) also as rowconv plans (add_conv2)
     std::vector<float*> vecs;                // device fp32 vectors (norm affine)
     std::vector<MtOp> ops;
     std::map<std::string, MtTensor> named;
@@ -173,6 +177,33 @@ struct MtGraph {
         plans.push_back(p);
         MtOp op;
         op.type = OP_CONV; op.name = name; op.x = x; op.y = y; op.plan = (int)plans.size() - 1; op.act = act; op.ups = ups;
+        op.unet3x3 = !x.q8 && !ups && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && pad_br == 0 && x.P() <= 1024 && Cin >= 320 &&
+                     name.rfind("decoder.", 0) != 0 && name.rfind("encoder.", 0) != 0;
+        // The 1x1 / linear layers on maps of <= 64 pixels or tokens per frame (the U-Net's 8x8 and 4x4 levels: projections of the transformer
+        // blocks, resnet shortcuts, the 50-token context projections; 1..13 MB of weights each behind 1024 / 256 rows of a 16-frame pass) also get
+        // a rowconv plan: conv3 runs them as ~160 items of 40..160 chunks each behind a two-stage DMA pipe (30 us for a 1280 x 1280 linear layer
+        // whose weights stream in 0.5 us); the weight-streaming GEMM over gathered rows pays one round trip per trip instead (mt_graph_run picks
+        // it by the launch's row count).
+        // Only the 1x1 / linear layers with <= 2560 outputs: a row block re-gathers its rows for every 32-output slab and every weight slab is
+        // re-read by every row group, so the 3x3 layers (K = 11 520..23 040: ~1.4 GB of L2 -> CU traffic per layer at 1024 rows) and the
+        // 10 240-output GEGLU projection would lose to conv3.
+        if (knob(K_MT_ROWCONV) > 0 && !x.q8 && !ups && act == 0 && sh == 1 && sw == 1 && kh == 1 && kw == 1 && ph == 0 && pw == 0 && pad_br == 0 &&
+            Cin % 32 == 0 && Cin <= 5120 && CoutP % 256 == 0 && CoutP <= 2560 && x.P() <= 64 && x.P() == y.P()) {
+            const size_t K = (size_t)kk * Cin;
+            std::vector<float> we((size_t)CoutP * K);
+            for (int co = 0; co < CoutP; ++co) {
+                const float* src = wuse + (size_t)co * Cin * kk;
+                float* dst = we.data() + (size_t)co * K;
+                for (int t = 0; t < kk; ++t)
+                    for (int ci = 0; ci < Cin; ++ci) dst[(size_t)t * Cin + ci] = src[(size_t)ci * kk + t];
+            }
+            RowGemmPlan rg;
+            rc = rowgemm_plan_create(&rg, we.data(), CoutP, (int)K, sc.data(), sf.data(), &e);
+            if (rc) { err = name + ": " + e; return -1; }
+            rplans.push_back(rg);
+            op.rplan = (int)rplans.size() - 1;
+            op.ksz = kh;
+        }
         if (res) op.r = *res;
         if (up16(Cin) != x.C || CoutP != y.C) { err = name + ": channel mismatch (" + std::to_string(Cin) + "->" + std::to_string(Cout) + ")"; return -1; }
         ops.push_back(op);
@@ -740,10 +771,11 @@ int mt_graph_alloc(MtGraph& g, int frames) {
 void mt_graph_free(MtGraph& g) {
     for (f16* b : g.bufs) if (b) (void)hipFree(b);
     for (ConvPlan& p : g.plans) conv_plan_destroy(&p);
+    for (RowGemmPlan& p : g.rplans) rowgemm_plan_destroy(&p);
     for (float* v : g.vecs) if (v) (void)hipFree(v);
     if (g.gn_partial) (void)hipFree(g.gn_partial);
     if (g.vt) (void)hipFree(g.vt);
-    g.bufs.clear(); g.plans.clear(); g.vecs.clear();
+    g.bufs.clear(); g.plans.clear(); g.rplans.clear(); g.vecs.clear();
 }
 
 f16* mt_ptr(const MtGraph& g, const MtTensor& t) { return g.bufs[t.buf]; }
@@ -765,8 +797,24 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                 io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
                 io.relu = 0; io.act = op.act; io.ups = op.ups;
                 io.partial = partial; io.partial_cap = partial_cap;
+                // U-Net resnet convs of a <= 16-frame pass: conv3's items-per-CU rule settles on tiles that re-read weights (8x8, 32x32 levels) or
+                // under-fill the chip (16x16 level); measured per level with the tile forced for every 3x3 launch (profiles/r02_mt_tile_force_ab.txt:
+                // 8x8 1280..2560 ch 116 -> 89 us at 256-px tiles, 16x16 640 ch 67 -> 49 us at 128-px tiles, 32x32 320 ch 55 -> 44 us at 256-px tiles).
+                // The VAE decoder keeps the rule (it wants its 512-px tiles).
+                // (The 4x4 level keeps the rule: forced 256-px tiles measured 31 -> 37 us there, profiles/r04_mt_rowconv_tile_ab.txt.)
+                if (op.unet3x3 && nf <= 16 && knob(K_MT_TILE_TABLE) && op.x.P() >= 64) io.force_pxw = op.x.P() == 256 ? 1 : 2;
                 std::string e;
-                const int rc = conv_launch(g.plans[op.plan], io, s, &e);
+                int rc;
+                if (op.rplan >= 0 && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
+                    RowConvIO rio;
+                    rio.x = io.x; rio.x_ld = op.x.ld; rio.x_coff = op.x.coff; rio.H = op.x.H; rio.W = op.x.W;
+                    rio.y = io.y; rio.y_ld = op.y.ld; rio.y_coff = op.y.coff; rio.Ho = op.y.H; rio.Wo = op.y.W;
+                    rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
+                    rio.N = nf; rio.KW = op.ksz; rio.stride = 1; rio.pad = op.ksz / 2; rio.relu = 0;
+                    rc = rowconv_launch(g.rplans[op.rplan], rio, s, &e);
+                } else {
+                    rc = conv_launch(g.plans[op.plan], io, s, &e);
+                }
                 if (rc) { g.err = op.name + ": " + e; return rc; }
                 break;
             }

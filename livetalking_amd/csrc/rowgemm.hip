@@ -119,7 +119,8 @@ struct RowConvArgs {
     const f16* w;                         // packed [J/16][K/32][64][8], K = taps * C ordered (tap, channel)
     const float* scale; const float* shift;
     int N, H, W, Ho, Wo, S, pad, KW;      // KW: kernel width (taps = KW * KW)
-    int cpt_log2;                         // log2(C / 32): k-steps per tap
+    int cpt;                              // C / 32: k-steps per tap (any C % 32 == 0)
+    unsigned cmagic;                      // ceil(2^32 / cpt): tap = umulhi(k, cmagic) for cpt > 1
     int KT;                               // k-steps: taps * C / 32
     int M;                                // rows: N * Ho * Wo
     int NR;                               // row groups (16 * FT rows each)
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) acc[jt][ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int cmask = (1 << a.cpt_log2) - 1;
-    // operand of k-step k for row tile ft: tap = k >> cpt_log2 (wave-uniform), 32 channels from (k & cmask) * 32
+    // operand of k-step k for row tile ft: tap = k / cpt (wave-uniform), 32 channels from (k - tap * cpt) * 32
     auto xload = [&](int k, int ft) -> f16x8 {
-        const int tap = k >> a.cpt_log2, cc = k & cmask;
+        const int tap = a.cpt == 1 ? k : (int)__umulhi((unsigned)k, a.cmagic);
+        const int cc = k - tap * a.cpt;
         const int ky = tap / KW, kx = tap - ky * KW;
         const int iy = iy0[ft] + ky, ix = ix0[ft] + kx;
         const bool ok = live[ft] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -308,9 +309,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     const int taps = io.KW * io.KW;
     if (!p.d_w || io.N <= 0 || taps <= 0 || p.K % taps) { if (err) *err = "rowconv: no plan / bad tap count"; return -1; }
     const int C = p.K / taps;
-    int cl = 0;
-    while ((32 << cl) < C) ++cl;
-    if ((32 << cl) != C || p.J % 256) { if (err) *err = "rowconv: channels must be 32 * 2^n, output channels a multiple of 256"; return -1; }
+    if (C % 32 || p.J % 256) { if (err) *err = "rowconv: channels must be a multiple of 32, output channels a multiple of 256"; return -1; }
     if (((io.x_ld | io.x_coff | io.y_ld | io.y_coff | io.res_ld | io.res_coff) & 15) || io.x_coff + C > io.x_ld || io.y_coff + p.J > io.y_ld) {
         if (err) *err = "rowconv: channel pitch / offset"; return -1;
     }
@@ -322,7 +321,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     a.res = io.res; a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
     a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift;
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.pad = io.pad; a.KW = io.KW;
-    a.cpt_log2 = cl; a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
+    a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
     const int tiles = (int)((M + 15) / 16);
     const int FT = tiles * (p.J / 32) <= 512 ? 2 : 4;          // ~2 blocks per CU's worth of row groups before the tiles grow
@@ -341,9 +340,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
 int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t stream, std::string* err) {
     if (!p || !p[0].d_w || io.N <= 0 || io.Ho != 2 * io.H || io.Wo != 2 * io.W) { if (err) *err = "rowconvT: no plan / bad geometry"; return -1; }
     const int C = p[0].K, J = p[0].J;                         // phase 0 has one tap
-    int cl = 0;
-    while ((32 << cl) < C) ++cl;
-    if ((32 << cl) != C || J % 256) { if (err) *err = "rowconvT: channels must be 32 * 2^n, output channels a multiple of 256"; return -1; }
+    if (C % 32 || J % 256) { if (err) *err = "rowconvT: channels must be a multiple of 32, output channels a multiple of 256"; return -1; }
     if (((io.x_ld | io.x_coff | io.y_ld | io.y_coff) & 15) || io.x_coff + C > io.x_ld || io.y_coff + J > io.y_ld) {
         if (err) *err = "rowconvT: channel pitch / offset"; return -1;
     }
@@ -355,7 +352,7 @@ int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t strea
     a.res = nullptr; a.res_cbt = 0; a.res_cb0 = 0;
     a.w = p[0].d_w; a.scale = p[0].d_scale; a.shift = p[0].d_shift;
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
-    a.cpt_log2 = cl; a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
+    a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
     for (int g = 0; g < 4; ++g) {
         const int py = g >> 1, px = g & 1;

@@ -46,6 +46,9 @@ enum Knob {
     K_ROWCONVT,           // LTK_ROWCONVT       the stride-2 transposed convs on the 4x4 / 8x8 maps as per-phase weight-streaming GEMMs (rowconvT_launch)
                           //                    when the launch has at most this many SOURCE pixels (frames x H x W), instead of conv3's merged-phase
                           //                    items + split-K finish; 0 = never.  512: measured (profiles/r04_rowconvT_ab.txt) - 256 rows -7.5 us, 1024 rows +-0
+    K_MT_ROWCONV,         // LTK_MT_ROWCONV     MuseTalk: the 1x1 / linear layers (<= 2560 outputs) on maps of <= 64 pixels / tokens as weight-streaming GEMMs over gathered rows
+                          //                    (rowconv) when the launch has at most this many rows (frames x pixels); 0 = never (and no plans are built)
+    K_MT_TILE_TABLE,      // LTK_MT_TILE_TABLE  1: measured per-level conv3 tile width for the U-Net's 3x3 convs in passes of <= 16 frames (musetalk.hip mt_graph_run)
     K_COUNT
 };
 

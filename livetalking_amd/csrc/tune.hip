@@ -30,6 +30,8 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_DF_BLOCK", 6},
     {"LTK_DF_MIN", 32},
     {"LTK_ROWCONVT", 512},
+    {"LTK_MT_ROWCONV", 1024},
+    {"LTK_MT_TILE_TABLE", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -125,5 +125,12 @@ for f in ('bgr24','i420'): print('graph $G', f, [(t['sessions'], t.get('latency_
   timeout 900 python bench.py --sub musetalk-both --batch 16 > $O/r4e_musetalk_both.json 2> $O/r4e_musetalk_both.err; python -c "
 import json; d=json.load(open('$O/r4e_musetalk_both.json'))
 for o in d: print(o.get('value'), o.get('roofline',{}).get('frac'), o.get('sessions_25fps'), json.dumps(o.get('delivered'))[:900])" ;;
+r4g)  # round-4 job G: MuseTalk small-map linear layers on rowconv
+  TAG=r4g MAXFAIL=--maxfail=20 bash $0 tests tests/test_musetalk_gpu.py tests/test_musetalk_plugin_gpu.py tests/test_fp8_gpu.py tests/test_wav2lip_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4g.log | tail -8
+  timeout 500 python scripts/mt_op_times.py 16 MT_ROWCONV=0,1024 2>&1 | grep -E "^====|conv/linear|GroupNorm|by block|->" > $O/r4g_mt_rowconv_ab.txt; head -60 $O/r4g_mt_rowconv_ab.txt
+  timeout 400 python scripts/mt_op_times.py 64 MT_ROWCONV=0,1024 2>&1 | grep -E "^====|conv/linear|->" > $O/r4g_mt_rowconv_ab64.txt; head -30 $O/r4g_mt_rowconv_ab64.txt ;;
+r4h)  # round-4 job H: MuseTalk per-level tile width of the U-Net's 3x3 convs
+  TAG=r4h MAXFAIL=--maxfail=20 bash $0 tests tests/test_musetalk_gpu.py tests/test_musetalk_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4h.log | tail -8
+  timeout 500 python scripts/mt_op_times.py 16 MT_TILE_TABLE=0,1 2>&1 | grep -E "^====|conv/linear|by block|->" > $O/r4h_mt_tile_ab.txt; grep -E "^====|->" $O/r4h_mt_tile_ab.txt | head -70 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

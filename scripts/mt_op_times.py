@@ -57,6 +57,12 @@ def main():
         top = np.argsort(-m)[:25]
         for i in top:
             print(f"    {m[i]:8.1f} us  {TYPES[ops[i][1]]:12s} {ops[i][0]}")
+        if os.environ.get("ALL_OPS"):          # every op in program order (ALL_OPS=<substring filter or 1>)
+            flt = os.environ["ALL_OPS"]
+            print("  ---- all ops in program order")
+            for i, (n, t) in enumerate(ops):
+                if flt == "1" or any(f in n for f in flt.split(",")):
+                    print(f"    {i:4d} {m[i]:8.1f} us  {TYPES[t]:12s} {n}")
     if ab is not None and len(med) == 2:
         d = med[1] - med[0]
         print(f"\n==== ops that moved > 5 % ({ab[0]}={ab[1][0]} -> {ab[1][1]}); total {med[0].sum():.0f} -> {med[1].sum():.0f} us")
