@@ -673,8 +673,8 @@ def delivered_capacity(args):
 
     custom = [int(v) for v in args.delivered_sessions.split(",")] if args.delivered_sessions else None
     out = {"period_ms": period * 1e3, "bank_frames": BANK_FRAMES,
-           "bgr24": run_format("", custom or [384, 448, 512, 576]),
-           "i420": run_format("i420", custom or [448, 512, 576]),
+           "bgr24": run_format("", custom or [384, 448, 512]),
+           "i420": run_format("i420", custom or [384, 448, 512]),
            "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 host frames (bgr24: paste_back_frame - "
                    "the batch's composites on the GPU, one pinned device-to-host copy; i420: the plugin's opt.egress path, + watermark + BGR->I420 "
                    "on the GPU); one Python thread per session; pinned pool warmed, period 0 excluded"}
@@ -863,7 +863,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
-    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default: bgr24 384,448,512,576; i420 448,512,576)")
+    ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default: 384,448,512 for both frame formats)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

@@ -918,7 +918,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
-    if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && blocks * (p.lCout / 128) >= 384 && (kn_nbt == 0 || kn_nbt == 4)) NBT = 4;
+    if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && ((blocks * (p.lCout / 128) >= 384 && kn_nbt == 0) || kn_nbt == 4)) NBT = 4;
     // (1x1 / linear layers on >= 1024 pixels: below one item per CU; MuseTalk's 640-channel projections on 4096 tokens are 10 %
     // faster as 320 items of 256 px x 32 ch than as 160 of 256 x 64)
     if (NBT == 2 && blocks * ((p.lCout + 63) / 64) < ((T == 1 && blocks >= 4) ? 256 : 128) && !(G == 1 && T == 9 && S == 1 && knob(K_TILE_RULE)) && !forced_tile) NBT = 1;
