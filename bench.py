@@ -505,6 +505,7 @@ def delivered_musetalk(args, shared, fp8, counts=(4, 16, 24, 32, 40)):
         e.close()
     best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
     return {"max_sessions_25fps_delivered": best, "period_ms": period * 1e3, "fp8": bool(fp8), "tested": results,
+            "largest_tested_count_sustained": bool(results and results[-1].get("sustained")),          # True: the list ended before the capacity did
             "note": "plugin level, measured: per session and 0.64-s period one Whisper feature step (host PCM in), one MuseReal.inference_batch "
                     "(16 frames) and 16 paste_back_frame composites (blend on the GPU, one pinned device-to-host copy per batch) = 16 host "
                     "720p BGR frames; one Python thread per session; period 0 excluded"}
@@ -669,6 +670,7 @@ def delivered_capacity(args):
                 break
         best = max([r["sessions"] for r in results if r.get("sustained")], default=0)
         return {"max_sessions_25fps_delivered": best, "frame_format": egress_fmt or "bgr24 (paste_back_frame)", "frame_bytes": frame_bytes,
+                "largest_tested_count_sustained": bool(results and results[-1].get("sustained")),      # True: the list ended before the capacity did
                 "tested": results}
 
     custom = [int(v) for v in args.delivered_sessions.split(",")] if args.delivered_sessions else None

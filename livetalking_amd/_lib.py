@@ -107,6 +107,14 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C livetalking_amd/csrc`). livetalking_amd has no CPU fallback.")
+    # PyTorch-ROCm first: it ships its own libamdhip64.so.7 / HSA runtime, the engine links against the system's by the same soname, and
+    # whichever is mapped first serves both.  With the system's mapped first (this library loaded before `import torch`, e.g. build() and
+    # smoke() in one process) the second runtime finds no device ("no ROCm-capable device is detected"); with torch's first everything -
+    # torch's allocator and the engine's streams - shares one runtime.  The plugin needs torch for its device buffers anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
