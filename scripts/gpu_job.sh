@@ -134,5 +134,8 @@ r4h)  # round-4 job H: MuseTalk per-level tile width of the U-Net's 3x3 convs
   timeout 500 python scripts/mt_op_times.py 16 MT_TILE_TABLE=0,1 2>&1 | grep -E "^====|conv/linear|by block|->" > $O/r4h_mt_tile_ab.txt; grep -E "^====|->" $O/r4h_mt_tile_ab.txt | head -70 ;;
 r4i)  # round-4 job I: 128-cout blocks + forced split-K for the small-map linear layers of MuseTalk (conv3 1x1), per-op response
   ALL_OPS=attentions,conv_shortcut timeout 500 python scripts/mt_op_times.py 16 MT_ROWCONV=1024,0,0+CONV3_NBT=0,4,4+KSPLIT=0,8,4 2>&1 | grep -E "^====| us  conv/linear" | grep -E "^====|down_blocks.2|mid_block|up_blocks.[01]" > $O/r4i_mt_nbt4_ops.txt; head -150 $O/r4i_mt_nbt4_ops.txt ;;
+r4m)  # round-4 job M: fused small-map GroupNorm (MuseTalk)
+  TAG=r4m MAXFAIL=--maxfail=20 bash $0 tests tests/test_musetalk_gpu.py tests/test_musetalk_plugin_gpu.py tests/test_fp8_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4m.log | tail -8
+  timeout 500 python scripts/mt_op_times.py 16 MT_GN_FUSED=0,1 2>&1 | grep -E "^====|GroupNorm|->" > $O/r4m_mt_gn_fused_ab.txt; grep -E "^====|GroupNorm " $O/r4m_mt_gn_fused_ab.txt | head; grep -E "\->" $O/r4m_mt_gn_fused_ab.txt | head -70 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
