@@ -29,7 +29,8 @@
 // bank, a 4-way conflict - SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles of this instantiation in round 3).  Their image permutes the
 // four 16-B units of every aligned pixel PAIR instead: unit q = 2 * (column & 1) + half sits at q ^ ((column >> 3) & 3), so the four
 // 256-B windows a 16-lane group touches use four different unit slots.  The permutation stays inside 64 B of a row, so the LDS-DMA
-// still moves whole lines; the patch row pitch is even for S = 2.
+// still moves whole lines; the patch row pitch is even for S = 2.  (Conflict-free when a lane group reads ONE patch row - 32-pixel-wide
+// tiles; on 16- / 8-pixel-wide tiles a group spans several rows whose offsets the key does not see and part of the conflicts remain.)
 #include "conv_mfma.h"
 #include "misc_kernels.h"
 #include "tune.h"
