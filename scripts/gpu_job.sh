@@ -137,5 +137,20 @@ r4i)  # round-4 job I: 128-cout blocks + forced split-K for the small-map linear
 r4m)  # round-4 job M: fused small-map GroupNorm (MuseTalk)
   TAG=r4m MAXFAIL=--maxfail=20 bash $0 tests tests/test_musetalk_gpu.py tests/test_musetalk_plugin_gpu.py tests/test_fp8_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4m.log | tail -8
   timeout 500 python scripts/mt_op_times.py 16 MT_GN_FUSED=0,1 2>&1 | grep -E "^====|GroupNorm|->" > $O/r4m_mt_gn_fused_ab.txt; grep -E "^====|GroupNorm " $O/r4m_mt_gn_fused_ab.txt | head; grep -E "\->" $O/r4m_mt_gn_fused_ab.txt | head -70 ;;
+r4vs3)  # the round-3 tree (build/r03tree: git archive 367ff43 + make) against this tree in ONE job, processes interleaved
+  L=$O/r4vs3.txt; : > $L
+  for rnd in 1 2 3; do for T in r03 r04; do
+    D=$R; [ $T = r03 ] && D=$R/build/r03tree
+    echo "######## round $rnd tree $T: conv stack / pass (scripts/layer_times.py, 3 rounds; us)" >> $L
+    (cd $D && ROUNDS=3 timeout 300 python scripts/layer_times.py "TILE_RULE=1" -- 16 256 2>&1 | grep -E "^====|^sum|^conv stack") >> $L
+    echo "######## round $rnd tree $T: timed line (bench.py --steps 100, 1 session x 16 frames)" >> $L
+    (cd $D && timeout 300 python bench.py --steps 100 --warmup 5 --no-also --no-cpu-baseline --no-traffic 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], d['roofline']['frac'])") >> $L
+  done; done
+  for rnd in 1 2; do for T in r03 r04; do
+    D=$R; [ $T = r03 ] && D=$R/build/r03tree
+    echo "######## round $rnd tree $T: MuseTalk 16-frame pass (scripts/mt_op_times.py 16)" >> $L
+    (cd $D && timeout 300 python scripts/mt_op_times.py 16 2>&1 | grep -E "^==== |conv/linear|GroupNorm ") >> $L
+  done; done
+  cat $L ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
