@@ -985,7 +985,6 @@ static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, c
 }
 
 constexpr size_t kMaxPassGraphs = 48;
-constexpr int kGraphAutoMinFrames = 48;       // knob GRAPH = 1: passes of at least this many frames (three 16-frame sessions coalesced) replay from a graph
 
 // enqueue_pass, replayed from a captured hipGraph where the pass has no per-call arguments: the product configuration (bank crops
 // in, fused head out) on the engine's own streams.  A frame count runs eagerly the first time it is seen (which also sets every
@@ -995,12 +994,12 @@ constexpr int kGraphAutoMinFrames = 48;       // knob GRAPH = 1: passes of at le
 static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32) {
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
     const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
-    // knob GRAPH: 0 never, 2 always, 1 (default) from kGraphAutoMinFrames frames per pass on.  In one job against the round-3 tree the replay of a
-    // 16-frame pass measured ~10 us (0.8 %) SLOWER on the device than the same launches issued one by one and no faster on the host side of a single
-    // session (profiles/r04_vs_r03_same_job.txt), equal from 64 frames on; what it buys - one host launch per pass instead of ~70 - matters when
-    // hundreds of sessions share a host (deliverable capacity 448 -> 512 sessions), and those passes are coalesced ones.
-    const int gk = knob(K_GRAPH);
-    const bool graphable = (gk >= 2 || (gk == 1 && nf >= kGraphAutoMinFrames)) && bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
+    // knob GRAPH: 0 never, non-zero (default 1) every eligible pass.  Measured (profiles/r04_vs_r03_same_job.txt, r04_graph_auto_ab.txt): the replay of a
+    // 16-frame pass is ~5-15 us (0.5-1 %) slower on the device than the same launches issued one by one (equal from 64 frames on), the host side is
+    // one launch instead of ~70: a single session's step is 0..1.8 % faster end to end depending on the box's host (three interleaved pairs on the
+    // last box: 1.3836 / 1.3904 / 1.3956 ms eager, 1.3619 / 1.3699 / 1.3596 ms replayed), and a host serving hundreds of sessions sustains 512 instead
+    // of 448 of them (profiles/r04_delivered_graph_ab.txt).
+    const bool graphable = knob(K_GRAPH) && bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
     if (!graphable) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
     if (e->graph_epoch != knob_epoch()) {           // a knob changed (tests, tuners): the captured launch sequences are stale
         CHK(hipStreamSynchronize(s));

@@ -37,9 +37,8 @@ enum Knob {
     K_ROWCONV,            // LTK_ROWCONV        the 3x3 layers on the 4x4 / 8x8 maps as weight-streaming GEMMs over gathered rows (rowgemm.hip rowconv) when the
                           //                    launch has at most this many output pixels (frames x Ho x Wo); 0 = never
     K_ABLATE,             // LTK_ABLATE         measurement builds only (make ABLATE=1): bit mask, see conv3_mfma.hip
-    K_GRAPH,              // LTK_GRAPH          a Wav2Lip pass of a given frame count captured once as a hipGraph and replayed (per-call pointer tables in device
-                          //                    memory, one small upload launch in front): 0 never, 1 (default) for passes of >= 48 frames (coalesced sessions:
-                          //                    where the host launch cost matters; a 16-frame replay measured 0.8 % slower on the device), 2 always
+    K_GRAPH,              // LTK_GRAPH          non-zero (default 1): a Wav2Lip pass of a given frame count is captured once as a hipGraph and replayed (the per-call
+                          //                    pointer tables live in device memory, filled by one small launch in front of the graph); 0: launch by launch
     K_DF_FRAMES,          // LTK_DF_FRAMES      > 0: the decoder blocks >= LTK_DF_BLOCK and the output conv run depth-first over sub-batches of this
                           //                    many frames (producer -> consumer tensors stay in the 256 MiB Infinity Cache); 0 = layer by layer
     K_DF_BLOCK,           // LTK_DF_BLOCK       first decoder block of the depth-first region (6: the 128^2 and 256^2 levels)

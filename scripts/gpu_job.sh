@@ -152,5 +152,10 @@ r4vs3)  # the round-3 tree (build/r03tree: git archive 367ff43 + make) against t
     (cd $D && timeout 300 python scripts/mt_op_times.py 16 2>&1 | grep -E "^==== |conv/linear|GroupNorm ") >> $L
   done; done
   cat $L ;;
+r4n)  # round-4 job N: the final default (GRAPH = 1: replay from 48 frames on) - tests that touch the graph path, timed line auto vs always, the default bench line
+  TAG=r4n MAXFAIL=--maxfail=20 bash $0 tests tests/test_wav2lip_gpu.py tests/test_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4n.log | tail -6
+  for G in 1 2 1 2 1 2; do LTK_GRAPH=$G timeout 300 python bench.py --steps 100 --warmup 5 --no-also --no-cpu-baseline --no-traffic > $O/r4n_bench_g$G.json 2>> $O/r4n_bench.err
+    python -c "import json; d=json.load(open('$O/r4n_bench_g$G.json')); print('GRAPH=$G', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], d['roofline']['frac'], d['roofline']['hipgraph'])" | tee -a $O/r4n_graph_auto_ab.txt; done
+  timeout 600 python bench.py > $O/r4n_bench_default.json 2> $O/r4n_bench_default.err; head -c 300 $O/r4n_bench_default.json ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

@@ -220,7 +220,6 @@ def test_concurrent_sessions_two_calls_in_flight_bit_identical():
         pytest.skip("no GPU")
     S, B, STEPS = 6, 4, 5
     Engine.set_knob("SPLITK", 0)
-    Engine.set_knob("GRAPH", 2)                          # always (the default replays passes of >= 48 frames only; these calls carry <= 24)
     model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=S * B, device=0)
     try:
         avatar = synth.wav2lip_avatar(n_frames=5, full_hw=(360, 640), box=160, seed=0)
@@ -253,6 +252,5 @@ def test_concurrent_sessions_two_calls_in_flight_bit_identical():
         assert model.engine.graph_count() >= 1
     finally:
         Engine.set_knob("SPLITK", 1)
-        Engine.set_knob("GRAPH", 1)
         for e in model.engines:
             e.close()

@@ -418,8 +418,8 @@ def test_coalesced_32_and_24_frames_vs_oracle(golden_dir):
 
 @pytest.mark.gpu
 def test_graph_replay_equals_eager_launches(engine, golden_dir):
-    """Knob GRAPH (2 = always; the default 1 applies it to passes of >= 48 frames): a pass of a given frame count is captured as a hipGraph
-    the second time it is seen and replayed from then on; the per-call pointers (bank crops, mel windows, output frames) travel through the device-resident tables, not through
+    """Knob GRAPH (default on): a pass of a given frame count is captured as a hipGraph the second time it is seen and replayed from
+    then on; the per-call pointers (bank crops, mel windows, output frames) travel through the device-resident tables, not through
     captured kernel arguments.  Five calls with DIFFERENT bank positions, mel buffers and output tensors each - eager, capture,
     three replays - must give byte for byte what the same calls give launch by launch (GRAPH=0): same kernels, same order, same
     fixed-order split-K sums.  Also through the depth-first sub-batch schedule of the 128^2 / 256^2 level (knob DF_FRAMES), which
@@ -443,7 +443,7 @@ def test_graph_replay_equals_eager_launches(engine, golden_dir):
         Engine.set_knob("GRAPH", 0)
         eager = run_all()
         assert engine.graph_count() == 0
-        Engine.set_knob("GRAPH", 2)                                # 2 = always (the default, 1, replays passes of >= 48 frames only)
+        Engine.set_knob("GRAPH", 1)
         replay = run_all()
         assert engine.graph_count() >= 1, "the 16-frame pass was not captured"
         for k in range(5):
