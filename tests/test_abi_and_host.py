@@ -250,6 +250,65 @@ def test_idle_workers_exit_and_engine_close_closes_schedulers(monkeypatch):
     assert "_ltk_schedulers" not in dummy.__dict__ and closed == [None]
 
 
+def test_scheduler_soak_random_arrivals(monkeypatch):
+    """Randomised soak of the scheduler (the render loop's inference threads block in infer(): a lost wake-up would hang a session for
+    good): 1..33 sessions with random think times, idle gaps long enough for the workers to exit and come back, 2 % poisoned requests,
+    against an engine that serialises device work like the real one.  Every request returns (or raises its own error), never more
+    calls are inside the engine than LTK_INFLIGHT allows, nothing hangs."""
+    pytest.importorskip("torch")
+    import random
+    from livetalking_amd import scheduler
+    monkeypatch.setenv("LTK_WORKER_IDLE_S", "0.05")
+
+    class Eng(FakeEngine):
+        def __init__(self):
+            super().__init__()
+            self.gpu = threading.Lock()
+            self.inside = self.peak = 0
+
+        def wav2lip_infer(self, reqs, stream=0):
+            with self.lock:
+                self.inside += 1
+                self.peak = max(self.peak, self.inside)
+            try:
+                if any(r[0] == 99 for r in reqs):
+                    raise RuntimeError("bad avatar")
+                with self.gpu:
+                    time.sleep(2e-5 * sum(r[2] for r in reqs))
+            finally:
+                with self.lock:
+                    self.inside -= 1
+
+    for seed, (S, inflight) in enumerate(((1, 2), (2, 2), (5, 2), (16, 2), (16, 1), (33, 2))):
+        monkeypatch.setenv("LTK_INFLIGHT", str(inflight))
+        eng, steps = Eng(), 20
+        sch = scheduler.BatchingScheduler(eng)
+        done, errs = [0] * S, []
+
+        def sess(i):
+            rnd = random.Random(seed * 100 + i)
+            for k in range(steps):
+                try:
+                    sch.infer(99 if rnd.random() < 0.02 else 1, k * 16, 16, 1, 2)
+                except RuntimeError as ex:
+                    if "bad avatar" not in str(ex):
+                        errs.append(str(ex))
+                done[i] += 1
+                if rnd.random() < 0.3:
+                    time.sleep(rnd.random() * 2e-3)
+                if rnd.random() < 0.02:
+                    time.sleep(0.08)                     # long enough for idle workers to leave
+
+        ts = [threading.Thread(target=sess, args=(i,), daemon=True) for i in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=60)
+            assert not t.is_alive(), f"session thread hung (S={S}, inflight={inflight}): pending {len(sch._pending)}, in flight {sch._inflight}"
+        sch.close()
+        assert not errs and all(d == steps for d in done) and eng.peak <= inflight, (errs, done, eng.peak)
+
+
 def test_poisoned_request_fails_alone_and_close_unblocks():
     """One bad request inside a 3-request batch raises only in its own caller (the reference's inference thread has no
     try/except, base_avatar.py:366: an error delivered to every co-batched session would kill all of their threads); close()
