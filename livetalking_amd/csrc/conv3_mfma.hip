@@ -25,6 +25,11 @@
 // line, which is what pixel-interleaved NHWC costs a 16-channel chunk).
 // A-patch image in LDS, per channel block: [patch pixel][2 x 16 B], the two halves swapped where bit 3 of the
 // pixel slot is set, so the 16-lane groups of ds_read_b128 (32-B lane stride) hit 16 distinct 16-B slots.
+// That holds when the 16 lanes of a group read ONE patch row (tile rows of 32 pixels).  On narrower maps (tile rows of 16, 8, 4 pixels) a group
+// spans 2-8 patch rows and the column key collides across rows: 8 / 14.7 / 16 LDS cycles per ds_read_b128 instead of 4 on 16- / 8- / 4-pixel-wide
+// tiles (a bank simulator over the guide's lane groups, tests/test_lds_layout.py; round 3's PMC shows it as 30 % conflict cycles on the 128-pixel-tile
+// instantiation).  There the halves swap by the parity of the patch ROW instead (and 8-pixel-wide tiles pad their row pitch to 12 pixels): 4 cycles
+// on 16- and 8-pixel rows, 8 on 4-pixel rows.  The key is a launch argument (swz_x / swz_row), chosen by the host from the tile width.
 // Stride-2 convolutions (S = 2) read every OTHER patch pixel (64-B lane stride: lanes i and i + 4 of a 16-lane group would share a
 // bank, a 4-way conflict - SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles of this instantiation in round 3).  Their image permutes the
 // four 16-B units of every aligned pixel PAIR instead: unit q = 2 * (column & 1) + half sits at q ^ ((column >> 3) & 3), so the four
@@ -81,6 +86,8 @@ struct K3Args {
     int ups;                         // 1: input is H/2 x W/2, read through a nearest 2x upsample
     int nitems;                      // work items (ksplit x pixel tiles x cout tiles); gridDim.x <= nitems
     int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
+    int swz_x, swz_row;              // stride-1 LDS image: the two 16-B halves of a patch pixel swap where bit 3 of its COLUMN is set (swz_x: tile rows of 32
+                                     // pixels) / where its patch ROW is odd (swz_row: narrower tiles, where a 16-lane read group spans several rows)
     int ablate;                      // measurement builds only (make ABLATE=1, knob LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA,
                                      // 8 no residual read, 16 no output store, 32 no LDS zero fill, 64 no epilogue, 128 epilogue math only
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
@@ -194,7 +201,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             pxs = (px & ~1) | (q >> 1);
             half = q & 1;
         } else {
-            half = (slot & 1) ^ ((px >> 3) & 1);            // the two 16-B halves swap where bit 3 of the patch COLUMN is set
+            half = (slot & 1) ^ (a.swz_x & (px >> 3) & 1) ^ (a.swz_row & (b * a.PH + py) & 1);   // column-bit-3 or row-parity key (header)
         }
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + pxs;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
@@ -255,7 +262,9 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 const int q = (2 * (pc & 1) + hh) ^ ((pc >> 3) & 3);
                 aj[j][dx] = (prow + ((pc & ~1) | (q >> 1))) * 32 + ((q & 1) << 4);
             } else {
-                aj[j][dx] = (prow + pcol + dx) * 32 + (((((pcol + dx) >> 3) & 1) ^ (Q == 2 ? 0 : hh)) << 4);     // Q = 2 reads both halves
+                // (row key: for tap row dy = 0; odd dy flips the half at the read, see arow())
+                const int key = (a.swz_x & ((pcol + dx) >> 3) & 1) ^ (a.swz_row & (in ? b * a.PH + ty * S : 0) & 1);
+                aj[j][dx] = (prow + pcol + dx) * 32 + ((key ^ (Q == 2 ? 0 : hh)) << 4);     // Q = 2 reads both halves
             }
         }
     }
@@ -272,6 +281,9 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
 
     const int PS = a.SLOTS * 16;
     const int rowB = a.PW * 32;            // bytes per patch row of a channel-block image
+    // operand offset of subtile j / column dx for tap row dy: aj is computed for dy = 0; under the row key an odd tap row reads the other half
+    const int rowflip = (S == 1) ? (a.swz_row << 4) : 0;      // wave-uniform
+    auto arow = [&](int v, int dy) -> int { return (dy & 1) ? (v ^ rowflip) : v; };
     auto compute = [&](int buf) {
         const unsigned char* Ab = smem + buf * STAGE;
         const unsigned char* Bb = Ab + A_BYTES;
@@ -298,8 +310,8 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
 #pragma unroll
                 for (int j = 0; j < PXW; ++j) {
-                    const i32x4 lo = *reinterpret_cast<const i32x4*>(Ar + aj[j][t % 3]);
-                    const i32x4 hi = *reinterpret_cast<const i32x4*>(Ar + (aj[j][t % 3] ^ 16));
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(Ar + arow(aj[j][t % 3], t / 3));
+                    const i32x4 hi = *reinterpret_cast<const i32x4*>(Ar + (arow(aj[j][t % 3], t / 3) ^ 16));
                     xa[sl][j] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             };
@@ -336,7 +348,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                     for (int i = 0; i < NBT; ++i)
                         wf[sl][i] = *reinterpret_cast<const f16x8*>(Bb + ((((i * T + t) * NC8 + plane) * 32) + l31) * 16);
 #pragma unroll
-                    for (int j = 0; j < PXW; ++j) xa[sl][j] = *reinterpret_cast<const f16x8*>(Ar + aj[j][(T == 9) ? t % 3 : 0]);
+                    for (int j = 0; j < PXW; ++j) xa[sl][j] = *reinterpret_cast<const f16x8*>(Ar + arow(aj[j][(T == 9) ? t % 3 : 0], (T == 9) ? t / 3 : 0));
                 };
                 load_tap(0, 0);
                 if (T > 1) __builtin_amdgcn_sched_group_barrier(0x100, NBT + PXW, 0);       // reads of tap 0
@@ -376,7 +388,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                     for (int dx = 0; dx < 3; ++dx) {
                         f16x8 xa[PXW];
 #pragma unroll
-                        for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + dy * rowB + aj[j][dx]);
+                        for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + dy * rowB + arow(aj[j][dx], dy));
 #pragma unroll
                         for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -416,7 +428,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
                 // offset (1,0): taps 6,7 -> phases 2,3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + aj[j][0]);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + arow(aj[j][0], 1));
                 {
                     const f16x8 w6 = wfrag(6), w7 = wfrag(7);
 #pragma unroll
@@ -427,7 +439,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                 }
                 // offset (1,1): tap 8 -> phase 3
 #pragma unroll
-                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + aj[j][G == 4 ? 1 : 0]);
+                for (int j = 0; j < PXW; ++j) xa[j] = *reinterpret_cast<const f16x8*>(Ap + rowB + arow(aj[j][G == 4 ? 1 : 0], 1));
                 {
                     const f16x8 w8 = wfrag(8);
 #pragma unroll
@@ -868,7 +880,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     if (kn_pxw == 2 || (kn_pxw == 1 && G == 1 && T == 9 && S == 1) || (kn_pxw == 4 && PXW == 4)) PXW = kn_pxw;
     if (kn_nbt == 1) NBT = 1;
     const bool forced_tile = io.force_pxw != 0 && io.force_nbt != 0;
-    int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0;
+    int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0, swz_x = 1, swz_row = 0;
     long long blocks = 0;
     auto geom = [&](int pxw) -> bool {
         const int M = 128 * pxw;
@@ -879,6 +891,12 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         NB = std::max(1, std::min(NB, io.N));
         PH = ((1 << l2h) - 1) * S + 1 + ext; PW = ((1 << l2w) - 1) * S + 1 + ext;
         if (S == 2) PW = (PW + 1) & ~1;                      // the stride-2 LDS image permutes units inside aligned pixel pairs of a row
+        // stride-1 images: column key on 32-pixel tile rows, row key below (header); 8-pixel rows with a halo need a row pitch of 12 pixels for it
+        swz_x = 1; swz_row = 0;
+        if (S == 1 && l2w <= 4 && knob(K_LDS_SWZ)) {
+            swz_x = 0; swz_row = 1;
+            if (l2w == 3 && ext > 0) PW = 12;
+        }
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
         while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S, T) * 256) --NB;
         npix = NB * PH * PW;
@@ -941,6 +959,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         a.ksplit = ksplit;
     }
     a.log2TW = l2w; a.log2TH = l2h; a.NB = NB; a.PH = PH; a.PW = PW; a.npix = npix; a.SLOTS = SLOTS;
+    a.swz_x = swz_x; a.swz_row = swz_row;
     a.magicPW = magic_u16_(PW); a.magicPHW = magic_u16_(PH * PW);
 
     if (ksplit > 1) a.partial = io.partial;

@@ -49,6 +49,8 @@ enum Knob {
     K_MT_ROWCONV,         // LTK_MT_ROWCONV     MuseTalk: the 1x1 / linear layers (<= 2560 outputs) on maps of <= 64 pixels / tokens as weight-streaming GEMMs over gathered rows
                           //                    (rowconv) when the launch has at most this many rows (frames x pixels); 0 = never (and no plans are built)
     K_MT_TILE_TABLE,      // LTK_MT_TILE_TABLE  1: measured per-level conv3 tile width for the U-Net's 3x3 convs in passes of <= 16 frames (musetalk.hip mt_graph_run)
+    K_LDS_SWZ,            // LTK_LDS_SWZ        1: conv3's stride-1 LDS image takes the row-parity key on tiles narrower than 32 pixels (conflict-free
+                          //                    ds_read_b128 on 16- / 8-pixel-wide maps); 0: column key everywhere (rounds 1-3)
     K_COUNT
 };
 

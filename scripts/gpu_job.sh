@@ -157,5 +157,12 @@ r4n)  # round-4 job N: the final default (GRAPH = 1: replay from 48 frames on) -
   for G in 1 2 1 2 1 2; do LTK_GRAPH=$G timeout 300 python bench.py --steps 100 --warmup 5 --no-also --no-cpu-baseline --no-traffic > $O/r4n_bench_g$G.json 2>> $O/r4n_bench.err
     python -c "import json; d=json.load(open('$O/r4n_bench_g$G.json')); print('GRAPH=$G', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], d['roofline']['frac'], d['roofline']['hipgraph'])" | tee -a $O/r4n_graph_auto_ab.txt; done
   timeout 600 python bench.py > $O/r4n_bench_default.json 2> $O/r4n_bench_default.err; head -c 300 $O/r4n_bench_default.json ;;
+r4p)  # round-4 job P: row-parity LDS key on tiles narrower than 32 pixels (conv3 stride 1): in-job A/B first, then the whole -m gpu suite, smoke, a bench line
+  L=$O/r4p_lds_swz_ab.txt; : > $L
+  ROUNDS=5 timeout 300 python scripts/pass_ab.py "LDS_SWZ=0" "LDS_SWZ=1" -- 16 64 256 2>&1 | grep -E "^settings|frames" >> $L
+  timeout 400 python scripts/mt_op_times.py 16 LDS_SWZ=0,1 2>&1 | grep -E "^====|conv/linear|->" > $O/r4p_mt_lds_swz_ab.txt; grep -E "^====|conv/linear " $O/r4p_mt_lds_swz_ab.txt | head -12 >> $L; cat $L
+  TAG=r4p MAXFAIL=--maxfail=20 bash $0 tests tests > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4p.log | tail -8
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
+  timeout 400 python bench.py --no-cpu-baseline > $O/r4p_bench.json 2> $O/r4p_bench.err; head -c 600 $O/r4p_bench.json ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
