@@ -164,5 +164,13 @@ r4p)  # round-4 job P: row-parity LDS key on tiles narrower than 32 pixels (conv
   TAG=r4p MAXFAIL=--maxfail=20 bash $0 tests tests > /dev/null 2>&1; grep -E "passed|failed|FAILED" $O/pytest_r4p.log | tail -8
   timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
   timeout 400 python bench.py --no-cpu-baseline > $O/r4p_bench.json 2> $O/r4p_bench.err; head -c 600 $O/r4p_bench.json ;;
+r4q)  # round-4 job Q: SQ_LDS_BANK_CONFLICT of the MuseTalk pass (then the 256-frame Wav2Lip pass) under the column key and the row key (separate --pmc runs, eager launches)
+  cd /tmp && export TMPDIR=/tmp; export LTK_GRAPH=0
+  for W in mt w2l256; do
+    [ $W = mt ] && A="--model musetalk --steps 2 --warmup 1" || A="--sessions 16 --steps 2 --warmup 1"
+    for K in 0 1; do LTK_LDS_SWZ=$K timeout 130 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/r4q/${W}_swz$K -o r -- python $R/bench.py $A --no-cpu-baseline --no-also --no-traffic > $O/r4q_${W}_swz$K.log 2>&1; done
+    python $R/scripts/lds_conflict_report.py column-key=$O/r4q/${W}_swz0 row-key=$O/r4q/${W}_swz1 > $O/r4q_lds_conflicts_$W.txt 2>&1; head -30 $O/r4q_lds_conflicts_$W.txt
+    rm -rf $O/r4q/${W}_swz0 $O/r4q/${W}_swz1
+  done ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
