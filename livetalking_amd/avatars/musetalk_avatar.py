@@ -24,7 +24,7 @@ import numpy as np
 
 from ..egress import SRC_MUSETALK, DeviceEgress, DeviceEgressMixin, FrameGroup
 from ..engine import Engine
-from ..hostshim import BaseAvatar, mirror_index, register
+from ..hostshim import BaseAvatar, mirror_index, register  # noqa: F401  (mirror_index: part of the reference module's namespace)
 from ..scheduler import get_scheduler
 from ..sharding import EnginePool, visible_devices
 from .audio_features.whisper import Audio2Feature, WhisperASR
@@ -203,10 +203,9 @@ class MuseReal(DeviceEgressMixin, BaseAvatar):
             raise ValueError(f"expected {B} whisper chunks, got {feat.shape[0]}")
         pred = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device=dev)
         self._sched.infer(self._aid, int(index), B, feat.data_ptr(), pred.data_ptr())
-        items = [pred[i] for i in range(B)]
+        items = list(pred.unbind(0))
         if hasattr(self.engine, "egress_batch"):        # opt.egress sessions convert the batch's frames in one go (egress.py)
-            n = len(self.frame_list_cycle)
-            FrameGroup.attach(items, pred, [mirror_index(n, int(index) + i) for i in range(B)])
+            FrameGroup.attach(items, pred, span=(len(self.frame_list_cycle), int(index), B))
         return items
 
     def paste_back_frame(self, pred_frame, idx: int):

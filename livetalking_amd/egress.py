@@ -41,19 +41,29 @@ def watermark_mask(H: int, W: int):
 class FrameGroup:
     """The B device predictions of ONE inference_batch call and the bank frame of each (shared by the B items the call returned):
     the process thread asks for them one by one, in order (base_avatar.py:429-433); the first request composites all B on the GPU
-    and moves them to the host in one copy."""
-    __slots__ = ("pred", "idx", "host", "eg_host", "eg_key", "lock")
+    and moves them to the host in one copy.  The bank indices are `mirror_index(n, index + i)`; they are worked out when the first
+    consumer asks (in ITS thread): the inference thread's time between two engine calls is time the GPU idles."""
+    __slots__ = ("pred", "_idx", "_span", "host", "eg_host", "eg_key", "lock")
 
-    def __init__(self, pred, idx):
+    def __init__(self, pred, idx=None, span=None):
         import threading
-        self.pred, self.idx = pred, idx
+        self.pred, self._idx, self._span = pred, idx, span      # span = (bank length, first index, count)
         self.host = None            # paste_back_frame path: numpy [B][H][W][3] over a pinned block
         self.eg_host, self.eg_key = None, None      # device-egress path: numpy over a pinned block of converted frames
         self.lock = threading.Lock()
 
+    @property
+    def idx(self):
+        ix = self._idx
+        if ix is None:
+            from .hostshim import mirror_index
+            n, first, count = self._span
+            ix = self._idx = [mirror_index(n, first + i) for i in range(count)]
+        return ix
+
     @staticmethod
-    def attach(items, pred, idx):
-        grp = FrameGroup(pred, idx)
+    def attach(items, pred, idx=None, span=None):
+        grp = FrameGroup(pred, idx, span)
         for i, it in enumerate(items):
             it._ltk_group, it._ltk_i = grp, i
         return grp

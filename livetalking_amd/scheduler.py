@@ -81,7 +81,21 @@ class BatchingScheduler:
 
     def infer(self, aid, index, batch, in_ptr, out_ptr):
         """Blocks until this request's frames are ready.  Raises what the engine raised for the call that carried it."""
-        r = _Req((aid, index, batch, in_ptr, out_ptr), int(batch))
+        batch = int(batch)
+        with self._cv:
+            # A lone session (nothing in flight, nothing queued, no window to hold, no multi-request batch lately): the call goes straight
+            # down in this thread with no request object, queue or event - the Python between two calls of a single session is time
+            # the GPU idles (scripts/host_overhead.py: 15 -> 5 us of the scheduler's share).
+            solo = (self._inflight == 0 and not self._pending and self.window <= 0.0 and
+                    (self._auto_window <= 0.0 or time.perf_counter() - self._last_multi >= 2.0))
+            if solo:
+                self._inflight += 1
+                self._inflight_frames += batch
+                if self._spf is not None:
+                    self._busy_until = time.perf_counter() + batch * self._spf
+        if solo:
+            return self._run_solo((aid, index, batch, in_ptr, out_ptr), batch)
+        r = _Req((aid, index, batch, in_ptr, out_ptr), batch)
         with self._cv:
             self._pending.append(r)
             leader = self._inflight == 0 and len(self._pending) == 1
@@ -101,6 +115,36 @@ class BatchingScheduler:
         r.done.wait()
         if r.err is not None:
             raise r.err
+
+    def _run_solo(self, args, frames):
+        """One request, one call, in the caller's thread; holds the in-flight slot infer() took.  Sessions that arrive meanwhile queue
+        up as usual (they see a call in flight) and the workers issue their batch - behind this call, or when it ends."""
+        t0 = time.perf_counter()
+        err = None
+        try:
+            self._call([args])
+        except Exception as ex:  # noqa: BLE001
+            err = ex
+        t1 = time.perf_counter()
+        with self._cv:
+            self._inflight -= 1
+            st = self.stats
+            st["calls"] += 1
+            st["requests"] += 1
+            st["frames"] += frames
+            if st["max_requests_per_call"] < 1:
+                st["max_requests_per_call"] = 1
+            if err is None and frames > 0:
+                spf = (t1 - max(t0, self._last_done)) / frames
+                self._spf = spf if self._spf is None else 0.75 * self._spf + 0.25 * spf
+            self._last_done = t1
+            self._inflight_frames -= frames
+            self._busy_until = t1 + (self._inflight_frames * self._spf if self._spf is not None else 0.0)
+            if self._pending:
+                self._ensure_workers()
+                self._cv.notify_all()
+        if err is not None:
+            raise err
 
     def _ensure_workers(self):
         """Under the lock."""

@@ -172,5 +172,9 @@ r4q)  # round-4 job Q: SQ_LDS_BANK_CONFLICT of the MuseTalk pass (then the 256-f
     python $R/scripts/lds_conflict_report.py column-key=$O/r4q/${W}_swz0 row-key=$O/r4q/${W}_swz1 > $O/r4q_lds_conflicts_$W.txt 2>&1; head -30 $O/r4q_lds_conflicts_$W.txt
     rm -rf $O/r4q/${W}_swz0 $O/r4q/${W}_swz1
   done ;;
+r4r)  # round-4 job R: host-path trims (unbind, lazy bank indices, scheduler solo path): the plugin-level GPU tests, then the timed line (gap = ms_per_step - device pass)
+  TAG=r4r MAXFAIL=--maxfail=20 timeout 120 bash $0 tests tests/test_plugin_gpu.py tests/test_egress_gpu.py tests/test_ref_loop.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rror" $O/pytest_r4r.log | tail -8
+  for i in 1 2; do timeout 40 python bench.py --steps 200 --warmup 10 --no-also --no-cpu-baseline --no-traffic 2>> $O/r4r_bench.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('timed line', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], round(1e3*(d['ms_per_step']-d['roofline']['conv_stack_ms']),1), 'us host gap')" | tee -a $O/r4r_host_gap.txt; done
+  TAG=r4r_mt MAXFAIL=--maxfail=20 timeout 100 bash $0 tests tests/test_musetalk_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rror" $O/pytest_r4r_mt.log | tail -4 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac

@@ -215,6 +215,63 @@ def test_two_calls_in_flight_keep_order_and_batch_size(monkeypatch):
     assert eng1.peak == 1 and sch1.stats["overlapped_calls"] == 0 and sch1.stats["requests"] == 48
 
 
+def test_lone_session_takes_the_direct_path_and_late_arrivals_still_batch(monkeypatch):
+    """A lone session's call goes down in its own thread without a request object (BatchingScheduler._run_solo: the Python between two
+    calls of one session is GPU idle time).  What must still hold: the in-flight accounting (a session arriving DURING a solo call
+    queues and is served - behind it or overlapped -, never more than LTK_INFLIGHT calls inside the engine), errors reach the caller,
+    and once multi-request batches form, the leader path with its window takes over again."""
+    pytest.importorskip("torch")
+    from livetalking_amd import scheduler
+
+    class SlowEngine(FakeEngine):
+        def __init__(self):
+            super().__init__()
+            self.inside, self.peak = 0, 0
+
+        def wav2lip_infer(self, reqs, stream=0):
+            with self.lock:
+                self.inside += 1
+                self.peak = max(self.peak, self.inside)
+                self.infer_calls.append(list(reqs))
+            if any(r[0] == 666 for r in reqs):
+                with self.lock:
+                    self.inside -= 1
+                raise RuntimeError("bad avatar")
+            time.sleep(0.02)
+            with self.lock:
+                self.inside -= 1
+
+    eng = SlowEngine()
+    sch = scheduler.BatchingScheduler(eng, "wav2lip")
+    solo_calls = []
+    orig = sch._run_solo
+    monkeypatch.setattr(sch, "_run_solo", lambda args, frames: (solo_calls.append(args[0]), orig(args, frames))[1])
+    for k in range(3):                                     # a lone session: every call direct, one request per call
+        sch.infer(1, 16 * k, 16, 10, 20)
+    assert solo_calls == [1, 1, 1] and sch.stats["calls"] == 3 and sch.stats["max_requests_per_call"] == 1
+    with pytest.raises(RuntimeError, match="bad avatar"):
+        sch.infer(666, 0, 16, 10, 20)
+    assert sch._inflight == 0 and sch._inflight_frames == 0
+    # sessions 2 and 3 arrive while session 1's solo call is inside the engine
+    done = []
+    t1 = threading.Thread(target=lambda: (sch.infer(1, 48, 16, 10, 20), done.append(1)))
+    t1.start()
+    time.sleep(0.005)
+    late = [threading.Thread(target=lambda sid=sid: (sch.infer(sid, 0, 16, 10, 20), done.append(sid))) for sid in (2, 3)]
+    for t in late:
+        t.start()
+    for t in [t1] + late:
+        t.join(timeout=10)
+        assert not t.is_alive()
+    assert sorted(done) == [1, 2, 3] and eng.peak <= 2
+    assert any(len(c) == 2 for c in eng.infer_calls)       # the two late sessions rode one call
+    assert sch._inflight == 0 and sch._inflight_frames == 0
+    n_solo = len(solo_calls)
+    sch.infer(1, 64, 16, 10, 20)                           # a multi-request batch formed < 2 s ago: leader path (window), not solo
+    assert len(solo_calls) == n_solo
+    sch.close()
+
+
 def test_idle_workers_exit_and_engine_close_closes_schedulers(monkeypatch):
     """A scheduler must not pin its engine for the life of the process: worker threads leave after LTK_WORKER_IDLE_S idle seconds
     (a later request starts new ones), and Engine.close() closes the schedulers stored on the engine."""
