@@ -176,5 +176,10 @@ r4r)  # round-4 job R: host-path trims (unbind, lazy bank indices, scheduler sol
   TAG=r4r MAXFAIL=--maxfail=20 timeout 120 bash $0 tests tests/test_plugin_gpu.py tests/test_egress_gpu.py tests/test_ref_loop.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rror" $O/pytest_r4r.log | tail -8
   for i in 1 2; do timeout 40 python bench.py --steps 200 --warmup 10 --no-also --no-cpu-baseline --no-traffic 2>> $O/r4r_bench.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('timed line', d['value'], d['ms_per_step'], d['roofline']['conv_stack_ms'], round(1e3*(d['ms_per_step']-d['roofline']['conv_stack_ms']),1), 'us host gap')" | tee -a $O/r4r_host_gap.txt; done
   TAG=r4r_mt MAXFAIL=--maxfail=20 timeout 100 bash $0 tests tests/test_musetalk_plugin_gpu.py > /dev/null 2>&1; grep -E "passed|failed|FAILED|rror" $O/pytest_r4r_mt.log | tail -4 ;;
+r4s)  # round-4 job S: host-path trims, in-job A/B of the Python trees (build/oldhost = git archive d39d0bc + the same libltk_hip.so), 16 sessions and 1 session
+  L=$O/r4s_host_ab.txt; : > $L
+  one() { (cd $1 && timeout 40 python bench.py --sessions $2 --steps $3 --warmup 5 --no-also --no-cpu-baseline --no-traffic 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$4 sessions=$2', d['value'], d['ms_per_step'])") | tee -a $L; }
+  for rnd in 1 2; do one $R/build/oldhost 16 40 old; one $R 16 40 new; done
+  one $R/build/oldhost 1 200 old; one $R 1 200 new ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
