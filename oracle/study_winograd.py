@@ -60,6 +60,22 @@ def block(x, sd, l, mode):
         return wo._block(x, sd, l), False
     if wino:
         y = wino_conv(x, w, "fp32" if mode == "wino" else "fp16") + b.view(1, -1, 1, 1)
+    elif mode in ("fold", "fold1") and l.kind == "conv":
+        # BN scale folded into the weights BEFORE their fp16 rounding (the accumulator then carries conv * scale, and a residual can be added to it
+        # as x * 1.0 by one more MFMA on the staged centre pixel - exact - instead of being read again in the epilogue)
+        sc = sd[l.prefix + ".conv_block.1.weight"] / torch.sqrt(sd[l.prefix + ".conv_block.1.running_var"] + wo.BN_EPS)
+        sh = sd[l.prefix + ".conv_block.1.bias"] + (b - sd[l.prefix + ".conv_block.1.running_mean"]) * sc
+        ws = w * sc.view(-1, 1, 1, 1)
+        if mode == "fold1" and l.residual:
+            # ... or with NO extra MFMA: the identity added to the centre tap of the scaled weights before their fp16 rounding (values near 1.0 there:
+            # absolute rounding error up to 2^-11 on those Cout weights instead of a relative one)
+            ws = ws.clone()
+            i = torch.arange(l.cout)
+            ws[i, i, l.k[0] // 2, l.k[1] // 2] += 1.0
+        y = F.conv2d(x, h(ws), None, stride=l.stride, padding=l.pad) + sh.view(1, -1, 1, 1)
+        if l.residual and mode == "fold":
+            y = y + x
+        return h(F.relu(y).clamp(max=65504.)), False
     elif l.kind == "conv":
         y = F.conv2d(x, h(w), b, stride=l.stride, padding=l.pad)
     else:
@@ -99,7 +115,7 @@ def forward(sd, mel, face, mode, taps):
         x = wo._block(x, sd, l)
     else:
         w, b = sd[l.prefix + ".conv_block.0.weight"], sd[l.prefix + ".conv_block.0.bias"]
-        y = (wino_conv(x, w, "fp32" if mode == "wino" else "fp16") if mode.startswith("wino") else F.conv2d(x, h(w), None, padding=1)) + b.view(1, -1, 1, 1)
+        y = (wino_conv(x, w, "fp32" if mode == "wino" else "fp16") if mode.startswith("wino") else F.conv2d(x, h(w), None, padding=1)) + b.view(1, -1, 1, 1)   # (fold: as direct)
         y = F.batch_norm(y, sd[l.prefix + ".conv_block.1.running_mean"], sd[l.prefix + ".conv_block.1.running_var"], sd[l.prefix + ".conv_block.1.weight"],
                          sd[l.prefix + ".conv_block.1.bias"], training=False, eps=wo.BN_EPS)
         x = F.relu(y)
@@ -117,7 +133,7 @@ def main():
     mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, [gm["ref_chunks"][int(g["mel_step"])][i] for i in range(B)])
     ref = g["ref_pred_u8"].astype(np.int32)
     taps = {}
-    for mode in ("fp32", "direct", "wino", "wino16"):
+    for mode in ("fp32", "direct", "fold", "fold1", "wino", "wino16"):
         taps[mode] = {}
         pred, nw = forward(sd, mel_t, img_t, mode, taps[mode])
         u8 = (pred.numpy().transpose(0, 2, 3, 1) * np.float32(255.)).astype(np.uint8).astype(np.int32)
@@ -126,13 +142,13 @@ def main():
         psnr = 10 * np.log10(255. ** 2 / mse) if mse > 0 else float("inf")
         print(f"{mode:8s} layers on Winograd {nw[0]:2d}/{nw[1]}   frames vs reference golden: PSNR {psnr:6.2f} dB, max {d.max()} LSB, "
               f"{100 * (d > 0).mean():.3f} % of bytes differ, {100 * (d > 1).mean():.4f} % by more than 1", flush=True)
-    print("\nper-layer relative L2 error against the fp32 walk (3x3 stride-1 layers):   direct    wino   wino16")
+    print("\nper-layer relative L2 error against the fp32 walk (3x3 stride-1 layers):   direct     fold    fold1     wino   wino16")
     for l in wo.all_block_layers():
         if not (l.kind == "conv" and l.k == (3, 3) and l.stride == (1, 1) and l.pad == (1, 1)) or l.prefix not in taps["fp32"]:
             continue
         r = taps["fp32"][l.prefix]
-        e = [float((taps[m][l.prefix] - r).norm() / (r.norm() + 1e-30)) for m in ("direct", "wino", "wino16")]
-        print(f"  {l.prefix:28s} {tuple(r.shape[1:])!s:18s} {e[0]:.2e} {e[1]:.2e} {e[2]:.2e}")
+        e = [float((taps[m][l.prefix] - r).norm() / (r.norm() + 1e-30)) for m in ("direct", "fold", "fold1", "wino", "wino16")]
+        print(f"  {l.prefix:28s} {tuple(r.shape[1:])!s:18s} {e[0]:.2e} {e[1]:.2e} {e[2]:.2e} {e[3]:.2e} {e[4]:.2e}")
 
 
 if __name__ == "__main__":
