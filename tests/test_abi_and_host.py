@@ -237,7 +237,7 @@ def test_lone_session_takes_the_direct_path_and_late_arrivals_still_batch(monkey
                 with self.lock:
                     self.inside -= 1
                 raise RuntimeError("bad avatar")
-            time.sleep(0.02)
+            time.sleep(0.05)
             with self.lock:
                 self.inside -= 1
 
