@@ -88,7 +88,6 @@ struct K3Args {
     int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
     int swz_x, swz_row;              // stride-1 LDS image: the two 16-B halves of a patch pixel swap where bit 3 of its COLUMN is set (swz_x: tile rows of 32
                                      // pixels) / where its patch ROW is odd (swz_row: narrower tiles, where a 16-lane read group spans several rows)
-    int ring;                        // 1x1 launches only (RING kernels): LDS stages of the chunk ring, >= 3 (0: the two-stage loop)
     int ablate;                      // measurement builds only (make ABLATE=1, knob LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA,
                                      // 8 no residual read, 16 no output store, 32 no LDS zero fill, 64 no epilogue, 128 epilogue math only
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
@@ -119,36 +118,14 @@ __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT
 // HEAD = 1 (output_block of the Wav2Lip generator, wav2lip_v2.py:89-91): the block's 32 output channels do not go to
 // memory; the epilogue applies the 1x1 conv 32 -> 3 + bias, the sigmoid, *255 and the uint8 truncation of
 // wav2lip_avatar.py:138,145 on the fp32 accumulators and writes the 3 bytes of every pixel to its frame's own output.
-// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate): all but the n youngest vector-memory operations of this wave
-// have completed.  LDS-DMA copies retire in issue order, so "the copies of chunk c have landed" = "at most (copies issued after them) remain".
-#define LTK_WAITVM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-        LTK_WAITVM_CASE(0) LTK_WAITVM_CASE(1) LTK_WAITVM_CASE(2) LTK_WAITVM_CASE(3) LTK_WAITVM_CASE(4) LTK_WAITVM_CASE(5) LTK_WAITVM_CASE(6) LTK_WAITVM_CASE(7)
-        LTK_WAITVM_CASE(8) LTK_WAITVM_CASE(9) LTK_WAITVM_CASE(10) LTK_WAITVM_CASE(11) LTK_WAITVM_CASE(12) LTK_WAITVM_CASE(13) LTK_WAITVM_CASE(14) LTK_WAITVM_CASE(15)
-        LTK_WAITVM_CASE(16) LTK_WAITVM_CASE(17) LTK_WAITVM_CASE(18) LTK_WAITVM_CASE(19) LTK_WAITVM_CASE(20) LTK_WAITVM_CASE(21) LTK_WAITVM_CASE(22) LTK_WAITVM_CASE(23)
-        LTK_WAITVM_CASE(24) LTK_WAITVM_CASE(25) LTK_WAITVM_CASE(26) LTK_WAITVM_CASE(27) LTK_WAITVM_CASE(28) LTK_WAITVM_CASE(29) LTK_WAITVM_CASE(30) LTK_WAITVM_CASE(31)
-        LTK_WAITVM_CASE(32) LTK_WAITVM_CASE(33) LTK_WAITVM_CASE(34) LTK_WAITVM_CASE(35) LTK_WAITVM_CASE(36) LTK_WAITVM_CASE(37) LTK_WAITVM_CASE(38) LTK_WAITVM_CASE(39)
-        LTK_WAITVM_CASE(40) LTK_WAITVM_CASE(41) LTK_WAITVM_CASE(42) LTK_WAITVM_CASE(43) LTK_WAITVM_CASE(44) LTK_WAITVM_CASE(45) LTK_WAITVM_CASE(46) LTK_WAITVM_CASE(47)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 struct HeadArgs {
     const float* w;                  // [3][32] weights, then [3] bias (fp32)
     const OutPtrs* outs;             // DEVICE table, per frame: uint8 [256][256][3]
 };
 
-// RING = 1 (1x1 convolutions / linear layers, T = 1): the channel chunks go through a ring of a.ring >= 3 LDS stages with counted waits instead of
-// the two-stage loop.  A 1x1 chunk is 8-16 MFMAs per wave (0.1-0.25 us) against a ~1.5-us LDS-DMA round trip, so with ONE chunk in flight a K = 1280
-// linear layer is a chain of 40 round trips (MuseTalk ff.net: 60 us for 11 us of MFMA work); the ring keeps a.ring - 1 chunks in flight.  Every copy
-// is unconditional there (a slot without a source pixel reads the chunk's first pixel: a 1x1 conv has no halo, and the columns of the slots
-// that are not output pixels are never stored), so every wave issues the same number of copies per stage and vmcnt can be counted; no zero fill.
-// Same chunk order, same MFMA order: results are bit-identical to the two-stage loop.
-template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0, int RING = 0>
+template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0>
 __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem, const HeadArgs* hd = nullptr) {
     static_assert(HEAD == 0 || (G == 1 && NBT == 1 && T == 9 && S == 1 && Q == 0), "fused head: the 3x3 32-cout output conv");
-    static_assert(RING == 0 || (G == 1 && T == 1 && S == 1 && Q == 0 && HEAD == 0), "chunk ring: 1x1 convolutions");
     constexpr int BN = NBT * 32;
     constexpr int MAXA = k3_maxa(PXW, NC8, S, T);
     constexpr int MAXB = k3_maxb(NBT, NC8, T);
@@ -185,7 +162,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     const int PHW = a.PH * a.PW;
 
     // ---- zero both A stages once: halo slots outside the image are never written by the DMA
-    if (!RING && !ABL(a, 32)) {
+    if (!ABL(a, 32)) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const bool two = c_end - c_begin > 1;               // a one-chunk item (16-channel layers) never touches the second stage
         for (int i = tid * 16; i < A_BYTES; i += 256 * 16) {
@@ -206,15 +183,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     // hoists it out of the item loop, keeps ~2 VGPRs per descriptor alive across the whole kernel, runs out of
     // registers and reloads the spills from scratch at every item start -- with an s_waitcnt vmcnt(0) in front of
     // every DMA of the first chunk.  An opaque copy of the lane id makes it per-item work (~100 VALU ops).
-    // RING: piece (k, wave) is copied iff it lies inside the NCB channel-block images (a tile of a small batch has fewer than 256 * PXW slots);
-    // wave-uniform, so the number of copies a wave issues per stage is known (ring_na) and its vmcnt can be counted
-    unsigned ring_amask = 0;
-    int ring_na = 0;
-    if constexpr (RING) {
-#pragma unroll
-        for (int k = 0; k < MAXA; ++k)
-            if ((k * 4 + wave) < NCB * p64n) { ring_amask |= 1u << k; ++ring_na; }
-    }
     int lane_i = lane;
     asm volatile("" : "+v"(lane_i));
 #pragma unroll
@@ -238,7 +206,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + pxs;
         const bool ok = (cbj < NCB) && (pix < a.npix) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) &&
                         ((unsigned)ix < (unsigned)a.W);
-        a_goff[k] = ok ? (unsigned)((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) * 2u : (RING ? 0u : ~0u);      // RING: a slot without a source reads the chunk's first pixel
+        a_goff[k] = ok ? (unsigned)((((n * a.x_cbt + a.x_cb0 + cbj) * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * 16 + half * 8) * 2u : ~0u;
     }
 
     // ---- B staging: NBT sub-slabs of slab32 16-byte items each; LDS image [sub][tap][plane][32]
@@ -253,10 +221,8 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         const unsigned char* xc = reinterpret_cast<const unsigned char*>(a.x + (size_t)c * NCB * HW16);
         if (!ABL(a, 1)) {
 #pragma unroll
-            for (int k = 0; k < MAXA; ++k) {
-                if constexpr (RING) { if ((ring_amask >> k) & 1) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024); }   // wave-uniform test
-                else if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024);
-            }
+            for (int k = 0; k < MAXA; ++k)
+                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024);
         }
         const unsigned char* wc = reinterpret_cast<const unsigned char*>(wsrc + (size_t)c * slab32);
         if (!ABL(a, 2)) {
@@ -484,26 +450,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         }
     };
 
-    if constexpr (RING) {
-        const int D = a.ring;                                  // LDS stages (host: D * STAGE fits the block)
-        int nb_w = 0;                                          // weight copies of THIS wave per stage (whole waves are in or out: slab32 is a multiple of 64)
-#pragma unroll
-        for (int k = 0; k < MAXB; ++k) nb_w += (wave * 64 + k * 256 < NBT * slab32) ? 1 : 0;
-        const int npc = ring_na + nb_w;                        // copies per stage and wave
-        const int nch = c_end - c_begin;
-        for (int s = 0; s < D - 1 && s < nch; ++s) stage(c_begin + s, s);
-        int buf = 0, nbuf = D - 1;                             // stage of chunk idx / of the chunk issued in iteration idx
-        for (int idx = 0; idx < nch; ++idx) {
-            wait_vm(min(D - 2, nch - 1 - idx) * npc);          // everything but the chunks issued after this one
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // chunk idx visible to every wave; every wave is out of stage nbuf (chunk idx - 1)
-            asm volatile("" ::: "memory");
-            if (idx + D - 1 < nch) stage(c_begin + idx + D - 1, nbuf);
-            if (!ABL(a, 4)) compute(buf);
-            buf = (buf + 1 == D) ? 0 : buf + 1;
-            nbuf = (nbuf + 1 == D) ? 0 : nbuf + 1;
-        }
-    } else {
     __syncthreads();                       // zero fill done before any DMA lands
     stage(c_begin, 0);
     // folded-BN scale/shift of this block's BN output channels -> LDS by DMA, behind the first chunk (a register
@@ -517,7 +463,6 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         __syncthreads();                   // vmcnt(0): chunk c landed; every wave left stage cur^1
         if (c + 1 < c_end) stage(c + 1, cur ^ 1);
         if (!ABL(a, 4)) compute(cur);
-    }
     }
 
 #if LTK_ABLATE_BUILD
@@ -728,7 +673,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
 // per-block dispatch, kernarg fetch and descriptor set-up were a fixed ~16 us per launch; a non-persistent launch
 // (gridDim.x == nitems) is the same code with one trip.  Logical ids are XCD-contiguous: consecutive ids (same
 // pixel tile, different cout tiles) run on one XCD and share its L2.
-template <int G, int NBT, int PXW, int NC8, int T, int S = 1, int Q = 0, int RING = 0>
+template <int G, int NBT, int PXW, int NC8, int T, int S = 1, int Q = 0>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nblk = gridDim.x;
@@ -737,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     const int first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     for (int item = first; item < a.nitems; item += nblk) {
         if (item != first) __syncthreads();      // every wave is out of the previous item's LDS stages
-        conv3_item<G, NBT, PXW, NC8, T, S, Q, 0, RING>(a, item, smem);
+        conv3_item<G, NBT, PXW, NC8, T, S, Q>(a, item, smem);
     }
 }
 
@@ -829,13 +774,6 @@ static k3_kernel_t k3_pick_mx(int NBT, int PXW) {     // MX-scaled fp8 operands:
 
 static k3_kernel_t k3_pick_s2(int NBT, int NC8) {     // 3x3 stride 2 pad 1 (face-encoder / U-Net downsamples): PXW = 2
     if (NC8 == 2) return NBT == 2 ? (k3_kernel_t)conv3_kernel<1, 2, 2, 2, 9, 2> : (k3_kernel_t)conv3_kernel<1, 1, 2, 2, 9, 2>;
-    return nullptr;
-}
-
-static k3_kernel_t k3_pick_ring(int NBT, int PXW, int NC8) {     // 1x1 convolutions with the chunk ring (conv3_item, RING = 1)
-#define K3RING(n, p, c) if (NBT == n && PXW == p && NC8 == c) return (k3_kernel_t)conv3_kernel<1, n, p, c, 1, 1, 0, 1>
-    K3RING(2, 2, 8); K3RING(1, 2, 8); K3RING(2, 2, 2); K3RING(1, 2, 2); K3RING(4, 2, 4); K3RING(2, 2, 4); K3RING(1, 2, 4);
-#undef K3RING
     return nullptr;
 }
 
@@ -1039,14 +977,6 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         return -1;
     }
     k3_kernel_t k = p.mx ? k3_pick_mx(NBT, PXW) : p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
-    // 1x1 convolutions: LTK_RING1 = n >= 3 runs the channel chunks through a ring of up to n LDS stages (as many as fit the CU's LDS,
-    // no more than the item has chunks) instead of the two-stage loop; same results bit for bit
-    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !head && knob(K_RING1) >= 3) {
-        const size_t stage_b = a_bytes + b_bytes;
-        const int D = std::min(std::min(knob(K_RING1), (int)((156 * 1024) / stage_b)), a.chunks_per_split);
-        k3_kernel_t kr = k3_pick_ring(NBT, PXW, NC8);
-        if (D >= 3 && kr) { k = kr; a.ring = D; lds = (size_t)D * stage_b; }
-    }
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }

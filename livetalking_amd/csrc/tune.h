@@ -51,8 +51,6 @@ enum Knob {
     K_MT_TILE_TABLE,      // LTK_MT_TILE_TABLE  1: measured per-level conv3 tile width for the U-Net's 3x3 convs in passes of <= 16 frames (musetalk.hip mt_graph_run)
     K_LDS_SWZ,            // LTK_LDS_SWZ        1: conv3's stride-1 LDS image takes the row-parity key on tiles narrower than 32 pixels (conflict-free
                           //                    ds_read_b128 on 16- / 8-pixel-wide maps); 0: column key everywhere (rounds 1-3)
-    K_RING1,              // LTK_RING1          0: conv3's 1x1 launches run the two-stage chunk loop; n >= 3: a ring of up to n LDS stages with counted waits
-                          //                    (n - 1 chunks in flight; as many stages as fit 156 KB of LDS and the item has chunks).  Bit-identical results.
     K_COUNT
 };
 

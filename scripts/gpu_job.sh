@@ -181,7 +181,7 @@ r4s)  # round-4 job S: host-path trims, in-job A/B of the Python trees (build/ol
   one() { (cd $1 && timeout 40 python bench.py --sessions $2 --steps $3 --warmup 5 --no-also --no-cpu-baseline --no-traffic 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$4 sessions=$2', d['value'], d['ms_per_step'])") | tee -a $L; }
   for rnd in 1 2; do one $R/build/oldhost 16 40 old; one $R 16 40 new; done
   one $R/build/oldhost 1 200 old; one $R 1 200 new ;;
-r4t)  # round-4 job T: the 1x1 chunk ring (LTK_RING1): bitwise parity + per-shape timing, then the MuseTalk pass per op
+r4t)  # round-4 job T: the 1x1 chunk ring (LTK_RING1; needs the tree of commit cb1ad49): bitwise parity + per-shape timing, then the MuseTalk pass per op
   timeout 35 python scripts/ring1_ab.py quick > $O/r4t_ring1_shapes.txt 2>&1; tail -12 $O/r4t_ring1_shapes.txt
   timeout 45 python scripts/mt_op_times.py 16 RING1=0,4 2>&1 | grep -E "^====|conv/linear  |->" > $O/r4t_mt_ring1.txt; grep -E "^====" $O/r4t_mt_ring1.txt; grep -E "\->" $O/r4t_mt_ring1.txt | head -30 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;

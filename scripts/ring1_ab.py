@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """conv3's 1x1 launches: the two-stage chunk loop (LTK_RING1 = 0) against the chunk ring (LTK_RING1 = 3, 4, 6 LDS stages), per layer shape:
 outputs compared BIT FOR BIT (same chunk and MFMA order) and the launch timed (ltk_conv2d_f16, HIP events, 20 iterations).  GPU only.
+The ring kernels live in commit cb1ad49 only (measured slower, profiles/r04_ring1_negative.txt): on a later tree the knob is unknown and this script fails.
 
     python scripts/ring1_ab.py [quick]
 """
