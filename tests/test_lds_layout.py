@@ -114,3 +114,41 @@ def test_what_the_column_key_cost_on_narrow_maps():
 def test_stride2_image_on_wide_rows():
     for Wo in (32, 64, 128):
         assert avg_cycles("c3", Wo, 2, S=2) == (4.0, 4)
+
+
+def writer_unit_source(S, g, slot):
+    """conv3_item's staging descriptor for the 16-byte unit `slot` of a channel-block image: (image b, patch row, SOURCE patch column, source half)."""
+    l2w, l2h, NB, PW, PH, swz_x, swz_row = g
+    pix = slot >> 1
+    b, rem = divmod(pix, PH * PW)
+    py, px = divmod(rem, PW)
+    if S == 2:
+        q = (2 * (px & 1) + (slot & 1)) ^ ((px >> 3) & 3)
+        return b, py, (px & ~1) | (q >> 1), q & 1
+    return b, py, px, (slot & 1) ^ (swz_x & (px >> 3) & 1) ^ (swz_row & (b * PH + py) & 1)
+
+
+def test_reader_meets_writer():
+    checked = 0
+    for S, kinds in ((1, ("c3", "c1", "ct", "u4")), (2, ("c3",))):
+        for kind in kinds:
+            taps = TAPS["c3"] if S == 2 else TAPS[kind]
+            for Wo in (4, 8, 16, 32, 64):
+                for N in (1, 3, 16):
+                    for pxw in ((1, 2, 4) if (kind == "c3" and S == 1) else (2,)):
+                        for new_rule in (True, False):
+                            g = geom(kind, Wo, N, pxw, S, new_rule)
+                            l2w, l2h, NB, PW, PH, _, _ = g
+                            for wave in range(4):
+                                for j in range(pxw):
+                                    for dy, dx in taps:
+                                        addrs = a_read_addrs(S, g, wave, j, pxw, dy, dx)
+                                        for lane, a in enumerate(addrs):
+                                            m = (wave * pxw + j) * 32 + (lane & 31)
+                                            tx, ty, b = m & ((1 << l2w) - 1), (m >> l2w) & ((1 << l2h) - 1), m >> (l2w + l2h)
+                                            if b >= NB:
+                                                continue                     # a pixel slot beyond the tile's images: never stored
+                                            assert a % 16 == 0
+                                            assert writer_unit_source(S, g, a // 16) == (b, ty * S + dy, tx * S + dx, lane >> 5), (S, kind, Wo, N, pxw, new_rule, lane, dy, dx)
+                                            checked += 1
+    assert checked > 100000
