@@ -14,6 +14,30 @@ import numpy as np
 from ...hostshim import BaseASR
 
 
+# what `whisper_logmel_kernel` computes = WhisperFeatureExtractor's defaults = whisper-tiny's preprocessor_config.json
+FEATURE_EXTRACTOR = {"feature_size": 80, "sampling_rate": 16000, "hop_length": 160, "chunk_length": 30, "n_fft": 400}
+# the encoder program's shape (whisper-tiny; config.json beside the checkpoint)
+ENCODER_SHAPE = {"d_model": 384, "encoder_layers": 4, "encoder_attention_heads": 6, "encoder_ffn_dim": 1536, "num_mel_bins": 80,
+                 "max_source_positions": 1500}
+
+
+def check_whisper_dir(model_path: str) -> None:
+    """The reference builds its front end from the directory's files (AutoFeatureExtractor / WhisperModel.from_pretrained,
+    audio2feature.py:20-21); the engine's log-mel kernel and encoder program are fixed, so a directory that asks for
+    anything else is an error."""
+    import json
+    import os
+    for fname, want in (("preprocessor_config.json", FEATURE_EXTRACTOR), ("config.json", ENCODER_SHAPE)):
+        p = os.path.join(model_path, fname)
+        if not os.path.exists(p):
+            continue
+        with open(p) as f:
+            cfg = json.load(f)
+        bad = [f"{k}: file has {cfg[k]!r}, engine is built for {v!r}" for k, v in want.items() if k in cfg and cfg[k] != v]
+        if bad:
+            raise ValueError(f"{p}: " + "; ".join(bad))
+
+
 class Audio2Feature:
     """avatars/musetalk/whisper/audio2feature.py:15-23: owns the Whisper encoder; here it lives in the engine."""
 
@@ -21,6 +45,7 @@ class Audio2Feature:
         self.engine = engine
         if encoder_state_dict is None:
             from transformers import WhisperModel   # the checkpoint reader the reference uses
+            check_whisper_dir(model_path)
             encoder_state_dict = WhisperModel.from_pretrained(model_path).encoder.state_dict()
         engine.load_whisper(encoder_state_dict)
 

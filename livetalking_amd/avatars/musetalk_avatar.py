@@ -94,6 +94,52 @@ def convert_deprecated_vae_attention(sd: dict) -> dict:
     return out
 
 
+# The U-Net program of csrc/musetalk.hip is built for ONE topology: MuseTalk 1.5's `models/musetalkV15/musetalk.json`, which
+# the reference hands to diffusers' UNet2DConditionModel(**config) (avatars/musetalk/utils/utils.py:15-31,
+# avatars/musetalk/models/unet.py:36-46).  A deployment's file is read and every field that shapes the graph must agree;
+# a different file is an error here, where the reference would build a different network.
+UNET_TOPOLOGY = {
+    "in_channels": 8, "out_channels": 4, "block_out_channels": [320, 640, 1280, 1280], "layers_per_block": 2,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"],
+    "cross_attention_dim": 384, "attention_head_dim": 8, "norm_num_groups": 32, "norm_eps": 1e-5, "act_fn": "silu",
+    "flip_sin_to_cos": True, "freq_shift": 0, "downsample_padding": 1, "mid_block_scale_factor": 1,
+    "center_input_sample": False,
+}
+# models/sd-vae/config.json (AutoencoderKL sd-vae-ft-mse): the fields the decoder program and decode_latents depend on
+VAE_TOPOLOGY = {
+    "latent_channels": 4, "out_channels": 3, "block_out_channels": [128, 256, 512, 512], "layers_per_block": 2,
+    "norm_num_groups": 32, "act_fn": "silu", "scaling_factor": 0.18215,
+    "up_block_types": ["UpDecoderBlock2D"] * 4,
+}
+
+
+def check_model_config(path: str, expected: dict, what: str) -> bool:
+    """Reads a diffusers config JSON if it exists and compares the graph-shaping fields with the compiled topology.
+    Returns False when there is no file (state dicts handed over directly), raises ValueError on a mismatch."""
+    import json
+    if not os.path.exists(path):
+        return False
+    with open(path) as f:
+        cfg = json.load(f)
+    bad = []
+    for k, want in expected.items():
+        if k not in cfg:
+            continue                                    # diffusers fills absent fields with its defaults = these values
+        got = cfg[k]
+        if isinstance(want, float):
+            ok = isinstance(got, (int, float)) and abs(float(got) - want) <= 1e-9 * max(1.0, abs(want))
+        elif isinstance(want, list):
+            ok = list(got) == want
+        else:
+            ok = got == want
+        if not ok:
+            bad.append(f"{k}: file has {got!r}, engine is built for {want!r}")
+    if bad:
+        raise ValueError(f"{path}: {what} topology differs from the one csrc/musetalk.hip implements: " + "; ".join(bad))
+    return True
+
+
 def _read_vae_checkpoint():
     import torch
     from safetensors.torch import load_file   # sd-vae ships diffusion_pytorch_model.safetensors / .bin
@@ -108,13 +154,17 @@ def load_model(unet_state_dict=None, vae_state_dict=None, whisper_encoder_state_
     One engine per GPU of LTK_DEVICES (default: every visible GPU), or just `device`."""
     import torch
     if unet_state_dict is None:
+        check_model_config(os.path.join("models", "musetalkV15", "musetalk.json"), UNET_TOPOLOGY, "U-Net")
         unet_state_dict = torch.load(os.path.join("models", "musetalkV15", "unet.pth"), map_location="cpu")
     if vae_state_dict is None:
+        check_model_config(os.path.join("models", "sd-vae", "config.json"), VAE_TOPOLOGY, "VAE")
         vae_state_dict = _read_vae_checkpoint()
     vae_state_dict = convert_deprecated_vae_attention(vae_state_dict)
     vae_state_dict = {k: v for k, v in vae_state_dict.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
     if whisper_encoder_state_dict is None:
         from transformers import WhisperModel   # the checkpoint reader the reference uses (audio2feature.py:20-23)
+        from .audio_features.whisper import check_whisper_dir
+        check_whisper_dir("./models/whisper")
         whisper_encoder_state_dict = WhisperModel.from_pretrained("./models/whisper").encoder.state_dict()
     if max_frames is None:
         max_frames = int(os.environ.get("LTK_MT_MAX_FRAMES", "64"))

@@ -12,8 +12,18 @@ What runs from the reference, unmodified (imported, never copied):
                                                              without temb, incl. the asymmetric-pad stride-2 downsample)
   avatars.musetalk.whisper.whisper.model.MultiHeadAttention  (model.py:57-100: the same multi-head attention arithmetic as
                                                              diffusers' Attention; pins head split + scaling)
+  avatars.musetalk.myutil.get_image_blending                 (myutil.py:4-25) and
+  avatars.musetalk_avatar.MuseReal.paste_back_frame          (musetalk_avatar.py:154-164), under a cv2 stub that carries the
+                                                             restated leaves resize / cvtColor / blendLinear (paste_oracle.py):
+                                                             the same recipe gen_golden.py uses for LipReal.paste_back_frame
+  avatars.musetalk_avatar.MuseReal.inference_batch           (musetalk_avatar.py:130-152) and
+  avatars.musetalk.models.vae.VAE.decode_latents             (vae.py:96-108), with the reference's own PositionalEncoding and
+                                                             `unet.model` / `vae.vae.decode` replaced by the oracle's network
+                                                             functions: pins the CONTROL FLOW (latent gather by mirror_index
+                                                             across the ping-pong turn, timesteps=[0], PE, 1/scaling_factor,
+                                                             x/2+0.5 clamp, round, RGB->BGR flip), not the networks
 The U-Net / VAE graph itself lives in `diffusers` (absent): see oracle/musetalk_oracle.py (PARITY UNPINNED as a whole).
-Writes tests/golden/musetalk_host_golden.npz and musetalk_blocks_golden.npz after asserting that the oracle restatements agree.
+Writes tests/golden/musetalk_host_golden.npz, musetalk_blocks_golden.npz and musetalk_plugin_golden.npz after asserting that the oracle restatements agree.
 """
 from __future__ import annotations
 
@@ -21,6 +31,8 @@ import argparse
 import os
 import sys
 import tempfile
+import types
+import zlib
 
 import numpy as np
 import torch
@@ -29,8 +41,127 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 sys.path.insert(0, REPO)
 
-from oracle import musetalk_oracle, whisper_oracle  # noqa: E402
+import synth_inputs as synth  # noqa: E402
+from oracle import musetalk_oracle, paste_oracle, whisper_oracle  # noqa: E402
 from oracle import ref_loop as gen_golden  # noqa: E402  (install_stubs / _stub)
+
+
+def pin_plugin(out_dir: str):
+    """MuseReal.paste_back_frame + get_image_blending and MuseReal.inference_batch + VAE.decode_latents, run from the
+    reference, against paste_oracle.paste_blend_frame and musetalk_oracle.inference_batch."""
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.COLOR_BGR2RGB = 4
+    calls = {"cvtColor": 0, "blendLinear": 0, "resize": 0}
+
+    def cvt(img, code):
+        assert code == cv2.COLOR_BGR2GRAY
+        calls["cvtColor"] += 1
+        return paste_oracle.cvt_bgr2gray_u8(img)
+
+    def blend(a, b, w1, w2):
+        assert a.shape == b.shape and a.dtype == np.uint8 and w1.dtype == np.float32 and w1.shape == a.shape[:2] == w2.shape
+        calls["blendLinear"] += 1
+        return paste_oracle.blend_linear_u8(a, b, w1, w2)
+
+    inner_resize = cv2.resize
+
+    def resize(src, dsize, *a, **k):
+        assert not a and not k                                   # default INTER_LINEAR (musetalk_avatar.py:159)
+        calls["resize"] += 1
+        return inner_resize(src, dsize)
+
+    cv2.cvtColor, cv2.blendLinear, cv2.resize = cvt, blend, resize
+    cv2.VideoCapture = object
+    cv2.INTER_LANCZOS4 = 4
+    import avatars.musetalk_avatar as ref_plugin
+    from avatars.musetalk.myutil import get_image_blending
+    from avatars.musetalk.models.vae import VAE
+    from avatars.musetalk.models.unet import PositionalEncoding
+    from utils.image import mirror_index as ref_mirror
+
+    # ---- (a) the composite
+    frames, masks, face_boxes, crop_boxes, preds = synth.musetalk_blend_avatar()
+    mr = ref_plugin.MuseReal.__new__(ref_plugin.MuseReal)
+    mr.frame_list_cycle, mr.mask_list_cycle = frames, masks
+    mr.coord_list_cycle, mr.mask_coords_list_cycle = face_boxes, crop_boxes
+    crcs, subs = [], []
+    for i in range(4):
+        before = frames[i].copy()
+        # what inference_batch hands over: a uint8 array; and a float array (a foreign producer): astype truncates
+        ref_frame = mr.paste_back_frame(preds[i], i)
+        ref_float = mr.paste_back_frame(preds[i].astype(np.float32) + 0.75, i)
+        assert np.array_equal(frames[i], before), "the cached frame must survive (ori_frame is a copy)"
+        mine = paste_oracle.paste_blend_frame(preds[i], frames[i], face_boxes[i], masks[i], crop_boxes[i])
+        assert ref_frame.dtype == np.uint8 and ref_frame.shape == frames[i].shape and ref_frame.flags["C_CONTIGUOUS"]
+        assert np.array_equal(ref_frame, mine), f"paste_blend_frame restatement drifted (frame {i})"
+        assert np.array_equal(ref_float, mine), f"astype(uint8) truncation (frame {i})"
+        # get_image_blending called directly, on a mask whose channels DIFFER: the cvtColor leg is really taken
+        rng = np.random.default_rng(100 + i)
+        cmask = rng.integers(0, 256, masks[i].shape, dtype=np.uint8)
+        x1, y1, x2, y2 = face_boxes[i]
+        face = paste_oracle.resize_linear_u8(preds[i], (x2 - x1, y2 - y1))
+        ref_c = get_image_blending(frames[i].copy(), face, face_boxes[i], cmask, crop_boxes[i])
+        gray3 = np.repeat(paste_oracle.cvt_bgr2gray_u8(cmask)[:, :, None], 3, axis=2)
+        assert np.array_equal(ref_c, paste_oracle.paste_blend_frame(preds[i], frames[i], face_boxes[i], gray3, crop_boxes[i]))
+        xs, ys, xe, ye = crop_boxes[i]
+        crcs.append(zlib.crc32(ref_frame.tobytes()))
+        subs.append(ref_frame[ys:ye:4, xs:xe:4][:60, :55].copy())
+    assert calls["cvtColor"] == 12 and calls["blendLinear"] == 12 and calls["resize"] == 8, calls
+    print("composite: reference MuseReal.paste_back_frame / get_image_blending == oracle on 4 frames "
+          "(soft mask on a growing box, crop box on the frame edge, shrinking box, hard mask)")
+
+    # ---- (b) inference_batch control flow: the reference's method and VAE.decode_latents around the oracle's networks
+    unet_sd = {k: torch.from_numpy(v) for k, v in synth.musetalk_unet_state_dict().items()}
+    vae_sd = {k: torch.from_numpy(v) for k, v in synth.vae_decoder_state_dict().items()}
+    n, B, index = 3, 4, 1                      # bank frames 1, 2, 2, 1: across the ping-pong turn
+    lats = [torch.from_numpy(x) for x in synth.musetalk_latents(n)]
+    feats = synth.musetalk_whisper_feats(B, seed=31)
+    seen = {}
+
+    class _UNetModel:
+        dtype = torch.float32
+
+        def __call__(self, latent, timesteps, encoder_hidden_states=None):
+            seen["timesteps"] = timesteps.clone()
+            seen["latent"] = latent.clone()
+            return types.SimpleNamespace(sample=musetalk_oracle.unet_forward(unet_sd, latent, encoder_hidden_states,
+                                                                            timestep=int(timesteps[0])))
+
+    class _VaeModel:
+        dtype = torch.float32
+        config = types.SimpleNamespace(scaling_factor=musetalk_oracle.VAE_SCALING)
+
+        def decode(self, z):
+            seen["z"] = z.clone()
+            return types.SimpleNamespace(sample=musetalk_oracle.vae_decode(vae_sd, z))
+
+    vae = VAE.__new__(VAE)                     # the ctor calls AutoencoderKL.from_pretrained; decode_latents needs these two
+    vae.vae, vae.scaling_factor = _VaeModel(), _VaeModel.config.scaling_factor
+    mr = ref_plugin.MuseReal.__new__(ref_plugin.MuseReal)
+    mr.batch_size = B
+    mr.input_latent_list_cycle = lats
+    mr.unet = types.SimpleNamespace(device=torch.device("cpu"), model=_UNetModel())
+    mr.vae, mr.pe, mr.timesteps = vae, PositionalEncoding(d_model=384), torch.tensor([0])
+    with torch.no_grad():
+        ref_pred = mr.inference_batch(index, [feats[i] for i in range(B)])
+        mine = musetalk_oracle.inference_batch(unet_sd, vae_sd, lats, index, B, feats)
+    assert ref_pred.shape == (B, 256, 256, 3) and ref_pred.dtype == np.uint8
+    assert int(seen["timesteps"][0]) == 0 and len(seen["timesteps"]) == 1
+    order = [ref_mirror(n, index + i) for i in range(B)]
+    assert order == [1, 2, 2, 1]
+    assert all(torch.equal(seen["latent"][i], lats[order[i]][0]) for i in range(B))
+    d = np.abs(ref_pred.astype(np.int32) - mine.astype(np.int32))
+    assert d.max() == 0, f"inference_batch restatement drifted: max {d.max()} LSB on {int((d != 0).sum())} bytes"
+    print(f"inference_batch: reference MuseReal.inference_batch + VAE.decode_latents == oracle, B={B} @ index {index} of {n} "
+          f"(bank order {order}), bit-identical")
+    np.savez_compressed(
+        os.path.join(out_dir, "musetalk_plugin_golden.npz"),
+        blend_generator="synth_inputs.musetalk_blend_avatar()", blend_crc=np.asarray(crcs, dtype=np.uint32),
+        blend_sub=np.stack(subs), infer_n=n, infer_batch=B, infer_index=index, infer_feat_seed=31,
+        infer_order=np.asarray(order), infer_pred_sub=np.ascontiguousarray(ref_pred[:, ::4, ::4]),
+        infer_pred_mean=ref_pred.reshape(B, -1).mean(axis=1))
+    print("wrote musetalk_plugin_golden.npz")
 
 
 def main():
@@ -43,6 +174,8 @@ def main():
     gen_golden._stub("torchvision")
     gen_golden._stub("torchvision.transforms", Normalize=lambda **k: None)
     sys.path.insert(0, args.ref)
+    args.out = os.path.abspath(args.out)
+    os.makedirs(args.out, exist_ok=True)
     os.chdir(tempfile.mkdtemp(prefix="ltk_golden_mt_"))
 
     # ---- PositionalEncoding (unet.py:12-27)
@@ -73,6 +206,8 @@ def main():
     np.savez_compressed(os.path.join(args.out, "musetalk_host_golden.npz"), pe_table=pe_table.astype(np.float32), chunk_rows=rows,
                         chunk_rows_short=rows_short)
     print("wrote musetalk_host_golden.npz: pe_table", pe_table.shape, "chunk_rows", rows.shape, rows[0], rows[-1])
+
+    pin_plugin(args.out)
 
     # ---- ResnetBlock2D + asymmetric-pad downsample: the reference's in-tree implementation (syncnet.py:71-139).  The module
     # imports two diffusers classes for its attention block; they are stubbed, ResnetBlock2D itself is plain torch.

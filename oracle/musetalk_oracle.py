@@ -353,7 +353,7 @@ def get_latents_for_unet(vae_sd: SD, face_bgr, noise: Optional[Tensor] = None) -
 
 def decode_latents(vae_sd: SD, latents: Tensor):
     """avatars/musetalk/models/vae.py:96-108 -> uint8 (B,256,256,3) BGR."""
-    image = vae_decode(vae_sd, latents / VAE_SCALING)
+    image = vae_decode(vae_sd, (1 / VAE_SCALING) * latents)       # vae.py:102: the reciprocal, then a product
     image = (image / 2 + 0.5).clamp(0, 1)
     image = image.detach().cpu().permute(0, 2, 3, 1).float().numpy()
     image = (image * 255).round().astype("uint8")

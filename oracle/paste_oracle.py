@@ -115,6 +115,15 @@ def blend_linear_u8(src1: np.ndarray, src2: np.ndarray, w1: np.ndarray, w2: np.n
     return np.clip(np.rint(q), 0, 255).astype(np.uint8)
 
 
+def cvt_bgr2gray_u8(img_bgr: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) for 8UC3, restated from OpenCV's published 8-bit path
+    (modules/imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar>): 14-bit fixed point,
+    gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14 (coefficients sum to 16384, so B = G = R = v gives v: the saved
+    MuseTalk masks are grey, which is why paste_blend_frame below reads channel 0).  PARITY UNPINNED (no OpenCV here)."""
+    a = np.asarray(img_bgr).astype(np.int64)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+
+
 def paste_blend_frame(pred_frame: np.ndarray, ori_frame: np.ndarray, bbox, mask_bgr: np.ndarray, crop_box) -> np.ndarray:
     """MuseReal.paste_back_frame on explicit inputs (musetalk_avatar.py:154-164, myutil.py:4-25)."""
     x1, y1, x2, y2 = [int(v) for v in bbox]

@@ -357,6 +357,39 @@ def musetalk_latents(n_frames: int = 4, seed: int = 5) -> List[np.ndarray]:
     return [(rng.standard_normal((1, 8, 32, 32)) * 0.18215 * 4).astype(np.float32) for _ in range(n_frames)]
 
 
+def _soft_mask(h: int, w: int, blur: int) -> np.ndarray:
+    """A lower-half box, box-blurred twice (the shape of the Gaussian-blurred masks genavatar writes,
+    avatars/musetalk/utils/blending.py:129-135), stored grey as cv2.imread returns a grey PNG: (h,w,3) uint8, B = G = R."""
+    m = np.zeros((h, w), np.float64)
+    m[h // 2:, w // 8: w - w // 8] = 255.0
+    k = np.ones(blur) / blur
+    for _ in range(2):
+        m = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, m)
+        m = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, m)
+    m8 = np.clip(np.rint(m), 0, 255).astype(np.uint8)
+    return np.repeat(m8[:, :, None], 3, axis=2)
+
+
+def musetalk_blend_avatar(full_hw: Tuple[int, int] = (360, 640), seed: int = 9):
+    """Four frames for the MuseTalk composite (avatars/musetalk_avatar.py:154-164, myutil.py:4-25), one per case the
+    composite has: 0 soft mask on a growing face box (300 px wide > 256), 1 a crop box touching the frame's left and
+    bottom edges, 2 a shrinking face box (150 x 170 < 256), 3 a growing, non-square box with a hard-edged (0 / 255) mask.
+    Returns (frames, masks, face_boxes (x1,y1,x2,y2), crop_boxes (x_s,y_s,x_e,y_e), preds uint8 (4,256,256,3))."""
+    H, W = full_hw
+    rng = np.random.default_rng(seed)
+    frames = [_smooth_image(rng, H, W) for _ in range(4)]
+    face_boxes = [(170, 30, 470, 330), (20, H - 230, 200, H - 30), (250, 100, 400, 270), (180, 20, 460, 340)]
+    crop_boxes = [(140, 10, 500, H - 5), (0, H - 260, 230, H), (220, 60, 440, 320), (150, 5, 490, H - 2)]
+    masks = []
+    for i, (xs, ys, xe, ye) in enumerate(crop_boxes):
+        m = _soft_mask(ye - ys, xe - xs, 15 if i != 1 else 9)
+        if i == 3:
+            m = np.where(m >= 128, 255, 0).astype(np.uint8)
+        masks.append(m)
+    preds = np.stack([_smooth_image(rng, 256, 256, cells=6) for _ in range(4)])
+    return frames, masks, face_boxes, crop_boxes, preds
+
+
 def musetalk_whisper_feats(batch: int, seed: int = 11) -> np.ndarray:
     """(B,50,384) audio feature stand-in with the value range of Whisper encoder states."""
     rng = np.random.default_rng(seed)

@@ -260,3 +260,44 @@ def test_infer_b16_end_to_end_vs_oracle():
         assert worst >= 40.0 and d.max() <= 6 and float((d <= 2).mean()) >= 0.99
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_paste_blend_vs_reference_golden(golden_dir):
+    """ltk_paste_blend against what the reference's own MuseReal.paste_back_frame + get_image_blending produced
+    (tests/golden/musetalk_plugin_golden.npz, written by oracle/gen_golden_musetalk.py::pin_plugin from
+    avatars/musetalk_avatar.py:154-164 + myutil.py:4-25): CRC-exact on the four composite cases - soft mask on a growing
+    face box, a crop box touching the frame's left and bottom edges, a shrinking face box, a hard 0/255 mask - through the
+    per-frame entry and through the batched egress entry the plugin's paste_back_frame uses."""
+    import os
+    import zlib
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from livetalking_amd.engine import Engine
+    from livetalking_amd.egress import SRC_MUSETALK, DeviceEgress, FrameGroup
+    from oracle import paste_oracle
+    g = np.load(os.path.join(golden_dir, "musetalk_plugin_golden.npz"))
+    frames, masks, face_boxes, crop_boxes, preds = synth.musetalk_blend_avatar()
+    eng = Engine(0)
+    try:
+        aid = eng.register_musetalk_avatar(synth.musetalk_latents(4), frames, face_boxes, masks, crop_boxes)
+        d_pred = torch.from_numpy(preds).cuda()
+        H, W = frames[0].shape[:2]
+        for i in range(4):
+            out = np.empty((H, W, 3), np.uint8)
+            eng.paste_blend(aid, i, d_pred[i].data_ptr(), out)
+            ref = paste_oracle.paste_blend_frame(preds[i], frames[i], face_boxes[i], masks[i], crop_boxes[i])
+            dd = np.abs(out.astype(int) - ref.astype(int))
+            assert np.array_equal(out, ref), (i, int(dd.max()), int((dd != 0).sum()))
+            assert zlib.crc32(out.tobytes()) == int(g["blend_crc"][i]), i
+        eg = DeviceEgress(eng, H, W, SRC_MUSETALK, aid, fmt="bgr24", watermark=None)
+        try:
+            items = list(d_pred.unbind(0))
+            FrameGroup.attach(items, d_pred, idx=[0, 1, 2, 3])
+            for i in range(4):                      # the first call composites all four (ltk_egress_batch), one pinned copy
+                o = eg.speaking_frame_of(items[i], i)
+                assert zlib.crc32(np.ascontiguousarray(o).tobytes()) == int(g["blend_crc"][i]), ("batched", i)
+        finally:
+            eg.close()
+    finally:
+        eng.close()
