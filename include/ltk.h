@@ -263,6 +263,11 @@ int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats)
  * knobs that shape a plan (weight pack order) only affect plans created afterwards. */
 int ltk_debug_set_knob(const char* name, int value);
 
+/* Device-free consistency check of the engine's measured per-layer tile table (csrc/engine.hip kTileTable, knob TILE_TABLE):
+ * every entry must name an existing layer, a frame-count bucket and a tile / split conv3 has an instantiation for.  Returns
+ * the number of bad entries (0 = consistent) and writes their descriptions into `msg` (NUL-terminated, at most `cap` bytes). */
+int ltk_debug_tile_table_check(char* msg, int cap);
+
 /* The device side of one ltk_wav2lip_infer pass, exactly as that call enqueues it (mel pack, conv stack with the bank gather
  * and the output head fused, replayed from the captured hipGraph under knob GRAPH), on dummy inputs, timed with HIP events
  * on the engine's compute stream: used by bench.py for `roofline.achieved`.  Returns average milliseconds per pass over

@@ -76,6 +76,7 @@ SYMBOLS = {
     "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "ltk_debug_set_knob": (C.c_int, [C.c_char_p, C.c_int]),
+    "ltk_debug_tile_table_check": (C.c_int, [C.c_char_p, C.c_int]),
     "ltk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "ltk_wav2lip_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "ltk_wav2lip_graph_count": (C.c_int, [C.c_void_p]),

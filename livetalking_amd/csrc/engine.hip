@@ -168,6 +168,41 @@ const TileEntry kTileTable[] = {
     {"face_decoder_blocks.1.0", 2, 0, 0, 4},
 };
 
+// Device-free consistency check of kTileTable (include/ltk.h ltk_debug_tile_table_check): every entry names a layer of the network
+// description above, a frame-count bucket, and a tile / split conv3 has an instantiation for on that layer.  The table is keyed by
+// strings and was tuned on single boxes: an entry that no longer matches anything would cost speed silently.
+int check_tile_table_impl(std::string& msg) {
+    int bad = 0;
+    auto find = [](const char* name) -> const LayerDef* {
+        for (const LayerDef& d : kAudio) if (!strcmp(d.prefix, name)) return &d;
+        for (const BlockLayer& b : kFaceEnc) if (!strcmp(b.d.prefix, name)) return &b.d;
+        for (const BlockLayer& b : kFaceDec) if (!strcmp(b.d.prefix, name)) return &b.d;
+        if (!strcmp(kOutConv.prefix, name)) return &kOutConv;
+        return nullptr;
+    };
+    const size_t n = sizeof(kTileTable) / sizeof(kTileTable[0]);
+    for (size_t i = 0; i < n; ++i) {
+        const TileEntry& t = kTileTable[i];
+        auto complain = [&](const char* what) { ++bad; msg += std::string(t.layer) + " (bucket " + std::to_string(t.bucket) + "): " + what + "; "; };
+        const LayerDef* d = find(t.layer);
+        if (!d) { complain("no such layer"); continue; }
+        if (t.bucket < 0 || t.bucket >= 5) complain("bucket outside 0..4");
+        if ((t.pxw == 0) != (t.nbt == 0)) complain("pxw and nbt must be given together");
+        if (t.pxw != 0 && t.pxw != 1 && t.pxw != 2 && t.pxw != 4) complain("pxw must be 0, 1, 2 or 4");
+        if (t.nbt < 0 || t.nbt > 2) complain("nbt must be 0, 1 or 2");
+        if (t.ks < 0 || t.ks > 32) complain("split factor outside 0..32");
+        if (t.pxw == 0 && t.nbt == 0 && t.ks == 0) complain("entry changes nothing");
+        const bool s1_3x3 = !d->transposed && d->k == 3 && d->sh == 1 && d->sw == 1;
+        if ((t.pxw == 1 || t.pxw == 4) && !s1_3x3) complain("128- / 512-pixel tiles exist for 3x3 stride-1 layers only");
+        if (t.pxw == 4 && d->cout > 32) complain("512-pixel tiles exist for <= 32 output channels only");
+        if (t.nbt == 2 && d->cout < 64) complain("64-cout blocks need >= 64 output channels");
+        if (d->k == 7) complain("the first layer runs on conv7, not conv3");
+        for (size_t j = 0; j < i; ++j)
+            if (!strcmp(kTileTable[j].layer, t.layer) && kTileTable[j].bucket == t.bucket) complain("duplicate entry");
+    }
+    return bad;
+}
+
 void apply_tile_table_impl(std::vector<Layer>& layers) {
     for (const TileEntry& t : kTileTable)
         for (Layer& L : layers)
@@ -1025,7 +1060,15 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
     const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
+    if (rc) {
+        // enqueue_pass failed mid-capture (possibly with the aux stream forked and never joined: EndCapture then reports an
+        // unjoined capture): clear the sticky HIP error so that the next call's own checks do not report this one
+        if (ce != hipSuccess) fprintf(stderr, "ltk: capture of the %d-frame pass aborted (%s)\n", nf, hipGetErrorString(ce));
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        g.seen = -1;
+        return rc;
+    }
     hipGraphExec_t exec = nullptr;
     hipError_t ie = ce;
     if (ce == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1040,6 +1083,13 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     g.exec = exec;
     CHK(hipGraphLaunch(exec, s));
     return 0;
+}
+
+int ltk_debug_tile_table_check(char* msg, int cap) {
+    std::string m;
+    const int bad = check_tile_table_impl(m);
+    if (msg && cap > 0) { strncpy(msg, m.c_str(), (size_t)cap - 1); msg[cap - 1] = 0; }
+    return bad;
 }
 
 int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream) {

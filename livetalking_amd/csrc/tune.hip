@@ -8,7 +8,9 @@
 
 #include <atomic>
 #include <mutex>
+#include <map>
 #include <set>
+#include <vector>
 #include <utility>
 
 namespace ltk {
@@ -62,15 +64,32 @@ int knob(Knob k) {
 }
 
 int ensure_dyn_lds(const void* func, int bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
+    // Runs in front of every conv launch (~70 per eager pass, from any engine / session thread): the common case is answered from
+    // a per-thread cache without a lock; the process-wide table behind it records the byte count configured per (device,
+    // function), so a later, larger request re-sets the attribute instead of being skipped.
+    struct Seen { int dev; const void* func; int bytes; };
+    thread_local std::vector<Seen> mine;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(mu);
-    if (done.count({dev, func})) return 0;
-    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done.insert({dev, func});
-    return (int)e;
+    for (const Seen& s : mine)
+        if (s.func == func && s.dev == dev && s.bytes >= bytes) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> done;
+    int have = 0;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = done.find({dev, func});
+        if (it != done.end()) have = it->second;
+        if (have < bytes) {
+            const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return (int)e;
+            done[{dev, func}] = have = bytes;
+        }
+    }
+    for (Seen& s : mine)
+        if (s.func == func && s.dev == dev) { s.bytes = have; return 0; }
+    mine.push_back({dev, func, have});
+    return 0;
 }
 
 unsigned knob_epoch() { return g_epoch.load(std::memory_order_relaxed); }

@@ -13,7 +13,9 @@ scheduler batches them instead (continuous batching):
   batch open for LTK_COALESCE_AUTO_US (default 200 us, 0.03 % of a 640-ms step; 0 / 200 / 500 us measured with 16 free-running
   session threads: 200 >= 0 > 500, profiles/r02_scheduler_window.txt) so that sessions woken by the same clock
   tick ride one launch sequence instead of "one alone, then the rest"; a lone session never waits;
-* LTK_COALESCE_MS > 0 holds every batch open for that long after its first request (fixed window);
+* LTK_COALESCE_MS > 0 holds a batch open for that long after its first request (fixed window) when that request finds the
+  engine idle (it leads the batch in its own thread); requests that arrive while a call is in flight are issued by the workers
+  on the lead timer below, without the window;
 * up to LTK_INFLIGHT (default 2) calls are in flight: the next batch is issued shortly before the running call is expected to
   end, so its launches queue behind the running kernels and the GPU does not idle through the host turn-around.
 
@@ -169,6 +171,11 @@ class BatchingScheduler:
             if alone:
                 self._leader_hold = False
             group, frames = self._take_batch()
+            if alone and self._pending:
+                # the leader's batch hit the frame limit: the rest is the workers' business from NOW on (they skipped the queue
+                # while the batch was held open), not only once this call completes
+                self._ensure_workers()
+                self._cv.notify_all()
             now = time.perf_counter()
             self._inflight_frames += frames
             if self._spf is not None:
@@ -273,6 +280,11 @@ class BatchingScheduler:
         with self._cv:
             self._workers = [w for w in self._workers if w.is_alive()]
             self._closed = False
+            if self._pending:
+                # a request that arrived while the workers were shutting down (the ones started for it saw `_closed` and
+                # left): it is served by fresh workers now instead of waiting for some later infer() to come by
+                self._ensure_workers()
+                self._cv.notify_all()
 
 
 class CoalescingScheduler(BatchingScheduler):

@@ -377,7 +377,7 @@ def musetalk_blend_avatar(full_hw: Tuple[int, int] = (360, 640), seed: int = 9):
     Returns (frames, masks, face_boxes (x1,y1,x2,y2), crop_boxes (x_s,y_s,x_e,y_e), preds uint8 (4,256,256,3))."""
     H, W = full_hw
     rng = np.random.default_rng(seed)
-    frames = [_smooth_image(rng, H, W) for _ in range(4)]
+    frames = [np.ascontiguousarray(_smooth_image(rng, H, W)) for _ in range(4)]
     face_boxes = [(170, 30, 470, 330), (20, H - 230, 200, H - 30), (250, 100, 400, 270), (180, 20, 460, 340)]
     crop_boxes = [(140, 10, 500, H - 5), (0, H - 260, 230, H), (220, 60, 440, 320), (150, 5, 490, H - 2)]
     masks = []
@@ -386,7 +386,7 @@ def musetalk_blend_avatar(full_hw: Tuple[int, int] = (360, 640), seed: int = 9):
         if i == 3:
             m = np.where(m >= 128, 255, 0).astype(np.uint8)
         masks.append(m)
-    preds = np.stack([_smooth_image(rng, 256, 256, cells=6) for _ in range(4)])
+    preds = np.ascontiguousarray(np.stack([_smooth_image(rng, 256, 256, cells=6) for _ in range(4)]))     # C order: the device reads raw bytes
     return frames, masks, face_boxes, crop_boxes, preds
 
 

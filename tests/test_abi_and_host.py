@@ -486,3 +486,27 @@ def test_abi_argument_validation_without_gpu():
         from livetalking_amd.engine import Engine
         with pytest.raises(Exception):
             Engine(0)
+
+
+def test_tile_table_entries_name_existing_layers_and_legal_tiles():
+    """csrc/engine.hip kTileTable is keyed by layer-name strings and was tuned on single boxes: every entry must name a layer
+    of the network description, a frame-count bucket and a tile / split conv3 has an instantiation for (device-free check
+    inside the library, include/ltk.h ltk_debug_tile_table_check); the table itself is read from the source here so that the
+    test also notices an entry the C side does not parse as expected."""
+    import ctypes as C
+    import re
+    from livetalking_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(4096)
+    bad = lib.ltk_debug_tile_table_check(buf, len(buf))
+    assert bad == 0, buf.value.decode()
+    src = open(os.path.join(ROOT, "livetalking_amd", "csrc", "engine.hip")).read()
+    table = src[src.index("const TileEntry kTileTable[] = {"):]
+    table = table[:table.index("};")]
+    entries = re.findall(r'\{"([a-z_.0-9]+)",\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\}', table)
+    assert len(entries) >= 10
+    layers = set(re.findall(r'\{"((?:audio_encoder|face_encoder_blocks|face_decoder_blocks|output_block)[.0-9]+)",\s*(?:false|true)', src))
+    assert len(layers) == 54
+    for name, bucket, pxw, nbt, ks in entries:
+        assert name in layers, name
+        assert int(bucket) in range(5) and int(pxw) in (0, 1, 2, 4) and int(nbt) in (0, 1, 2) and 0 <= int(ks) <= 32

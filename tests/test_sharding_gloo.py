@@ -137,3 +137,51 @@ def test_bench_session_threads_run_free_between_steps():
             drv.step(0, nsteps=2)
     finally:
         drv.close()
+
+
+def test_rank_device_override_is_explicit(monkeypatch):
+    """LTK_RANK_DEVICES maps local ranks onto listed GPUs (the one-GPU test of the real multi-rank path); without it rank r is
+    GPU r, and a rank the list does not name is an error, not GPU 0."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("LTK_RANK_DEVICES", raising=False)
+    assert [bench.rank_device(r) for r in range(4)] == [0, 1, 2, 3]
+    monkeypatch.setenv("LTK_RANK_DEVICES", "0,0")
+    assert [bench.rank_device(r) for r in range(2)] == [0, 0]
+    with pytest.raises(SystemExit):
+        bench.rank_device(2)
+
+
+@pytest.mark.gpu
+def test_bench_two_real_ranks_on_one_gpu():
+    """The NON-dry multi-rank path of bench.py - engine + bank replica + session per rank, gloo barriers on both sides of a GPU
+    step, max over ranks - under the driver's own launcher (torch.distributed.run), with both ranks mapped onto GPU 0 by the
+    explicit LTK_RANK_DEVICES override: n_gpus 2, two per-rank rates, value = 2 x frames / max time, i.e. about the sum of
+    the two ranks' rates (they share one GPU here, so each runs at roughly half the single-rank rate)."""
+    import socket
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LTK_RANK_DEVICES="0,0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-also", "--no-cpu-baseline", "--no-traffic",
+           "--sustain", "0.3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["metric"] == "inferfps" and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert len(d["per_rank_fps"]) == 2 and all(v > 100 for v in d["per_rank_fps"])
+    assert d["config"]["parallelism"].startswith("session-sharded x2")
+    frames = 2 * 3 * 16
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 3e-3)) <= 0.01 * d["value"]           # whole-job frames / max-over-ranks time
+    assert d["value"] <= sum(d["per_rank_fps"]) * 1.02                                         # never more than the ranks' own rates add up to
+    assert d["value"] >= 0.5 * sum(d["per_rank_fps"])                                          # and the barrier costs less than half of it
+    assert d["sustained"]["steps"] >= 3 and d["sustained"]["value"] > 100
+    # without the override two ranks on a one-GPU box must fail loudly
+    if torch.cuda.device_count() < 2:
+        env2 = {k: v for k, v in env.items() if k != "LTK_RANK_DEVICES"}
+        r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env2)
+        assert r2.returncode != 0 and "needs GPU 1" in (r2.stderr + r2.stdout)

@@ -460,3 +460,37 @@ def test_graph_replay_equals_eager_launches(engine, golden_dir):
         Engine.set_knob("DF_FRAMES", 0)
         Engine.set_knob("DF_MIN", 32)
     engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
+def test_tile_table_off_equals_table_on_within_one_lsb(engine, golden_dir):
+    """The measured per-layer tile table (csrc/engine.hip kTileTable, knob TILE_TABLE) only moves work between tile shapes and
+    split factors: with it disabled (conv3's rule alone) a 16-frame and a 64-frame call must give the same frames - tiles never
+    change a sum's order, the few split-factor entries do (fixed-order split-K: <= 1 LSB on a small share of the bytes)."""
+    from livetalking_amd.engine import Engine
+    from livetalking_amd import _lib
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=64)
+        aid = eng.register_avatar(faces, frames, coords)
+        for nf in (16, 64):
+            mel = torch.from_numpy(np.stack([feats[i % len(feats)] for i in range(nf)]).astype(np.float32)).cuda()
+
+            def run():
+                pred = torch.zeros(nf, 256, 256, 3, dtype=torch.uint8, device="cuda")
+                eng.wav2lip_infer([(aid, 1, nf, mel.data_ptr(), pred.data_ptr())])
+                return pred.cpu().numpy().astype(np.int16)
+
+            try:
+                Engine.set_knob("TILE_TABLE", 1)
+                on = run()
+                Engine.set_knob("TILE_TABLE", 0)
+                off = run()
+            finally:
+                Engine.set_knob("TILE_TABLE", 1)
+            d = np.abs(on - off)
+            print(f"[tile table off vs on, {nf} frames] max {int(d.max())} LSB, differing bytes {float((d != 0).mean()):.5f}")
+            assert d.max() <= 1 and float((d != 0).mean()) < 0.05
+    finally:
+        eng.close()
