@@ -279,6 +279,11 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
  * second time ltk_wav2lip_infer sees it).  Tests and bench.py use it to prove that the graph path is the one that ran. */
 int ltk_wav2lip_graph_count(ltk_engine* e);
 
+/* Number of (program, frame count) pairs of the MuseTalk side - the U-Net + VAE decoder pass behind ltk_musetalk_infer, the
+ * Whisper encoder behind ltk_whisper_step - that currently run from a captured hipGraph (knob GRAPH; captured the second time
+ * a frame count is seen). */
+int ltk_program_graph_count(ltk_engine* e);
+
 /* Per-layer view of the same pass (tuning / profiling): layer names in execution order (state_dict prefixes), the time
  * of every layer inside a whole pass on one stream (HIP events between consecutive launches, so a layer sees the cache
  * state its predecessor left, not the hot loop of an isolated microbenchmark), and the engine's per-layer tile table:

@@ -291,6 +291,10 @@ struct ltk_engine {
     std::map<int, PassGraph> graphs;
     unsigned graph_epoch = 0;         // knob_epoch() the graphs were captured under
     unsigned long graph_clock = 0;
+    // captured MuseTalk / Whisper programs (run_program): the static launch list of a program over its persistent buffers, one
+    // executable graph per (program, frame count); the kernels that carry per-call pointers stay outside the graph
+    std::map<std::pair<const void*, int>, PassGraph> prog_graphs;
+    unsigned prog_graph_epoch = 0;
     // debug capture
     bool capture = false;
     std::map<std::string, std::vector<float>> taps;
@@ -540,6 +544,12 @@ void drop_graphs(ltk_engine* e) {
     for (auto& kv : e->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     e->graphs.clear();
+}
+
+void drop_prog_graphs(ltk_engine* e) {
+    for (auto& kv : e->prog_graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    e->prog_graphs.clear();
 }
 
 void wav2lip_unload(ltk_engine* e) {
@@ -880,6 +890,7 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_lohi) (void)hipFree(e->d_lohi);
     e->avatars.clear();
     e->mt_avatars.clear();
+    drop_prog_graphs(e);
     if (e->mt) mt_graph_delete(e->mt);
     if (e->whisper) mt_graph_delete(e->whisper);
     if (e->vae_enc) mt_graph_delete(e->vae_enc);
@@ -1340,6 +1351,14 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     return LTK_OK;
 }
 
+int ltk_program_graph_count(ltk_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    int n = 0;
+    for (auto& kv : e->prog_graphs) n += kv.second.exec ? 1 : 0;
+    return n;
+}
+
 int ltk_wav2lip_graph_count(ltk_engine* e) {
     if (!e) return 0;
     std::lock_guard<std::mutex> g(e->mu);
@@ -1583,6 +1602,55 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
     return LTK_OK;
 }
 
+// One run of a device program (the U-Net + VAE decoder pass, the Whisper encoder) on the compute stream, under e->mu.  Every op
+// of a program reads and writes the program's own persistent buffers with launch arguments that depend on the frame count only,
+// so the whole launch list (436 launches for a MuseTalk pass, ~60 for a Whisper step) is captured as ONE hipGraph the second time a
+// (program, frame count) is seen and replayed from then on (knob GRAPH, as for the Wav2Lip pass: the first, eager run also sets
+// every kernel's dynamic-LDS attribute, which a capture must not do).  The kernels that carry per-call pointers - latent / token
+// gather in front, uint8 frame writer behind - stay outside the graph.  What this buys is the host side: one launch per pass
+// instead of hundreds, on a host that also runs the sessions' Python.
+static int run_program(ltk_engine* e, MtGraph* prog, int nf) {
+    hipStream_t s = e->compute;
+    if (!knob(K_GRAPH)) return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
+    if (e->prog_graph_epoch != knob_epoch()) {
+        if (hipStreamSynchronize(s) != hipSuccess) return -2;
+        drop_prog_graphs(e);
+        e->prog_graph_epoch = knob_epoch();
+    }
+    ltk_engine::PassGraph& g = e->prog_graphs[{(const void*)prog, nf}];
+    g.stamp = ++e->graph_clock;
+    if (g.exec) return hipGraphLaunch(g.exec, s) == hipSuccess ? 0 : -2;
+    if (g.seen < 0 || g.seen++ == 0) return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
+    size_t live = 0;
+    for (auto& kv : e->prog_graphs) live += kv.second.exec ? 1 : 0;
+    if (live >= kMaxPassGraphs) {
+        auto victim = e->prog_graphs.end();
+        for (auto it = e->prog_graphs.begin(); it != e->prog_graphs.end(); ++it)
+            if (it->second.exec && (victim == e->prog_graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
+        if (victim != e->prog_graphs.end()) {
+            if (hipStreamSynchronize(s) != hipSuccess) return -2;
+            (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); g.seen = -1; return mt_run(prog, nf, e->d_partial, e->partial_cap, s); }
+    const int rc = mt_run(prog, nf, e->d_partial, e->partial_cap, s);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
+    if (rc) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = ce;
+    if (ce == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        g.seen = -1;
+        fprintf(stderr, "ltk: hipGraph capture of a %d-frame program failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
+        return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
+    }
+    g.exec = exec;
+    return hipGraphLaunch(exec, s) == hipSuccess ? 0 : -2;
+}
+
 // latents already gathered into the graph's latent tensor; d_feat = fp32 [nf][50][384] on the device
 static int mt_run_locked(ltk_engine* e, const float* d_feat, const PtrList64* feat_ptrs, int nf, const OutList64* outs,
                          float* d_image_f32) {
@@ -1591,7 +1659,7 @@ static int mt_run_locked(ltk_engine* e, const float* d_feat, const PtrList64* fe
     f16* ctx = mt_ctx_in(e->mt, &cbt);
     if (feat_ptrs) launch_tokens_gather_to_cb16(*feat_ptrs, nf, 50, 384, e->d_pe, ctx, cbt, s);
     else launch_tokens_to_cb16(d_feat, nf, 50, 384, e->d_pe, ctx, cbt, 0, s);
-    const int rc = mt_run(e->mt, nf, e->d_partial, e->partial_cap, s);
+    const int rc = run_program(e, e->mt, nf);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     if (outs || d_image_f32) {
         OutList64 none;
@@ -1992,10 +2060,12 @@ int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, 
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
     CHK(hipEventCreate(&t1));
-    int rc = mt_run(e->mt, frames, e->d_partial, e->partial_cap, e->compute);
+    // as ltk_musetalk_infer enqueues the program: eagerly the first time a frame count is seen, then captured, then replayed
+    int rc = run_program(e, e->mt, frames);
+    if (!rc) rc = run_program(e, e->mt, frames);
     if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     CHK(hipEventRecord(t0, e->compute));
-    for (int i = 0; i < iters && !rc; ++i) rc = mt_run(e->mt, frames, e->d_partial, e->partial_cap, e->compute);
+    for (int i = 0; i < iters && !rc; ++i) rc = run_program(e, e->mt, frames);
     if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     CHK(hipEventRecord(t1, e->compute));
     CHK(hipEventSynchronize(t1));
@@ -2048,7 +2118,7 @@ int ltk_whisper_step(ltk_engine* e, const float* pcm, int n_samples, int batch, 
         int cbt, cb0;
         f16* mel = mt_latent_in(e->whisper, &cbt);
         launch_whisper_logmel(e->d_wpcm, n_samples, e->d_wbasis, e->d_wlogspec, e->d_wgmax, mel, s);
-        rc = mt_run(e->whisper, 1, e->d_partial, e->partial_cap, s);
+        rc = run_program(e, e->whisper, 1);
         if (rc) rc = fail(LTK_E_INVALID, std::string("whisper: ") + mt_graph_error(e->whisper));
         if (!rc) {
             WhisperStates st;

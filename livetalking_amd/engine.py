@@ -369,6 +369,10 @@ class Engine:
         """Frame counts whose Wav2Lip pass currently replays from a captured hipGraph (include/ltk.h)."""
         return int(self._lib.ltk_wav2lip_graph_count(self._h))
 
+    def program_graph_count(self) -> int:
+        """(program, frame count) pairs of the MuseTalk side (U-Net + VAE pass, Whisper encoder) that replay from a captured hipGraph."""
+        return int(self._lib.ltk_program_graph_count(self._h))
+
     def time_convs(self, frames: int, iters: int):
         ms = C.c_float()
         macs = C.c_double()

@@ -301,3 +301,39 @@ def test_paste_blend_vs_reference_golden(golden_dir):
             eg.close()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_musetalk_graph_replay_equals_eager_launches(mt):
+    """Knob GRAPH (default on): the 436-launch U-Net + VAE program of a given frame count is captured as ONE hipGraph the
+    second time it is seen and replayed from then on; the kernels with per-call pointers (latent / token gather, frame
+    writer) stay outside it.  Four calls with different bank positions, audio features and output tensors - eager, capture,
+    two replays - must give byte for byte what the same calls give launch by launch (GRAPH=0)."""
+    from livetalking_amd.engine import Engine
+    eng, usd, vsd = mt
+    n = 4
+    lats = synth.musetalk_latents(n)
+    frames, masks, face_boxes, crop_boxes, _ = synth.musetalk_blend_avatar()
+    aid = eng.register_musetalk_avatar(lats, frames, face_boxes, masks, crop_boxes)
+    feats = [torch.from_numpy(synth.musetalk_whisper_feats(B, seed=40 + k)).cuda() for k in range(4)]
+
+    def run_all():
+        outs = []
+        for k in range(4):
+            pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+            eng.musetalk_infer([(aid, 1 + 2 * k, B, feats[k].data_ptr(), pred.data_ptr())])
+            outs.append(pred)
+        return outs
+
+    try:
+        Engine.set_knob("GRAPH", 0)
+        eager = run_all()
+        assert eng.program_graph_count() == 0
+        Engine.set_knob("GRAPH", 1)
+        replay = run_all()
+        assert eng.program_graph_count() >= 1, "the MuseTalk pass was not captured"
+        for k in range(4):
+            assert torch.equal(eager[k], replay[k]), f"call {k}: graph replay differs from the eager launches"
+        assert not torch.equal(eager[0], eager[1])
+    finally:
+        Engine.set_knob("GRAPH", 1)
