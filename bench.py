@@ -247,6 +247,10 @@ def run_wav2lip(args, ranks: Ranks):
     import livetalking_amd.avatars.wav2lip_avatar as plugin
     import synth_inputs as synth  # seeded synthetic input generators (repo root; nothing from oracle/)
 
+    face_cache = os.environ.get("LTK_FACE_CACHE", "0") not in ("", "0")
+    if face_cache and not args.sub:
+        raise SystemExit("bench.py: LTK_FACE_CACHE is an opt-in deployment mode (the face encoder's outputs are cached per bank frame); "
+                         "the timed line never uses it - it is reported on its own also[] entry")
     S, B = args.sessions, args.batch
     frames_per_step = S * B
     if frames_per_step > 4096:
@@ -351,10 +355,19 @@ def run_wav2lip(args, ranks: Ranks):
                          "pass_ms_note": "device time of one ltk_wav2lip_infer pass as that call enqueues it: mel pack + 54 conv launches + fused head "
                                          "(graph replay under knob GRAPH); conv_stack_ms is the same figure under its round-1..4 name",
                          "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass,
-                         "hipgraph": bool(graphs_timed_run), "graphs_captured_in_timed_run": graphs_timed_run},
+                         "hipgraph": bool(graphs_timed_run), "graphs_captured_in_timed_run": graphs_timed_run,
+                         "face_cache": False},
             "per_rank_fps": [round(args.steps * frames_per_step / t, 1) for t in per_rank],
             "scheduler": sched,
         }
+        if face_cache:
+            # the session calls above skipped the face encoder (cached per bank frame): no roofline figure for this entry - the
+            # HIP-event pass time below is the FULL pass on dummy inputs and `value` is not algorithmic FLOPs over time
+            out["face_cache"] = {"on": True, "bytes_per_bank_frame": 4146176,
+                                 "cache_bytes": int(eng.face_cache_bytes(sessions[0]._aid)) if hasattr(sessions[0], "_aid") else None,
+                                 "full_pass_ms": round(conv_ms, 4)}
+            out["roofline"] = None
+            out["config"]["workload"] += ", LTK_FACE_CACHE=1 (deployment mode: face-encoder skip tensors cached per bank frame)"
         if sustained is not None:
             out["sustained"] = sustained
         if paced is not None:
@@ -714,9 +727,11 @@ def delivered_capacity(args):
                 "tested": results}
 
     custom = [int(v) for v in args.delivered_sessions.split(",")] if args.delivered_sessions else None
+    fmts = [f for f in args.delivered_formats.split(",") if f]
     out = {"period_ms": period * 1e3, "bank_frames": BANK_FRAMES,
-           "bgr24": run_format("", custom or [384, 448, 512]),
-           "i420": run_format("i420", custom or [384, 448, 512]),
+           "face_cache": os.environ.get("LTK_FACE_CACHE", "0") not in ("", "0"),
+           "bgr24": run_format("", custom or [384, 448, 512]) if "bgr24" in fmts else None,
+           "i420": run_format("i420", custom or [384, 448, 512]) if "i420" in fmts else None,
            "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 host frames (bgr24: paste_back_frame - "
                    "the batch's composites on the GPU, one pinned device-to-host copy; i420: the plugin's opt.egress path, + watermark + BGR->I420 "
                    "on the GPU); one Python thread per session; pinned pool warmed, period 0 excluded"}
@@ -858,10 +873,10 @@ def sub_mtpasses(args):
     eng.close()
 
 
-def run_sub(name, extra, timeout=600):
+def run_sub(name, extra, timeout=600, env=None):
     cmd = [sys.executable, os.path.abspath(__file__), "--sub", name] + extra
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env) if env else None)
     except subprocess.TimeoutExpired:
         return {"error": f"{name}: timed out after {timeout} s"}
     for line in reversed(r.stdout.strip().splitlines()):
@@ -908,6 +923,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
     ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default: 384,448,512 for both frame formats)")
+    ap.add_argument("--delivered-formats", default="bgr24,i420", help="frame formats of the delivered-capacity run")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sustain is None:
@@ -988,9 +1004,17 @@ def main():
                 for a, sb in zip(also, subs):
                     if sb is not None and isinstance(a, dict) and isinstance(a.get("roofline"), dict):
                         add_traffic(a["roofline"], *sb)
+            fc = run_sub("also-w2l16-facecache", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "3", "--paced", "4"],
+                         env={"LTK_FACE_CACHE": "1"})
+            if isinstance(fc, dict):
+                fc["baseline_config"] = ("configs[3] per-GPU share in the opt-in deployment mode LTK_FACE_CACHE=1 (not a benchmark line: the face "
+                                         "encoder's outputs are cached per bank frame, 4.15 MB each; compare with also[0])")
+            also.append(fc)
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
             out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
+            out["delivered_face_cache"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--delivered-sessions", "512,576,640",
+                                                                         "--delivered-formats", "bgr24"], env={"LTK_FACE_CACHE": "1"})
             w16 = also[0] if isinstance(also[0], dict) else {}
             out["sessions_25fps"] = {"per_gpu_delivered": (out["delivered"].get("bgr24") or {}).get("max_sessions_25fps_delivered"),
                                      "per_gpu_delivered_i420": (out["delivered"].get("i420") or {}).get("max_sessions_25fps_delivered"),

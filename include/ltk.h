@@ -279,6 +279,16 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
  * second time ltk_wav2lip_infer sees it).  Tests and bench.py use it to prove that the graph path is the one that ran. */
 int ltk_wav2lip_graph_count(ltk_engine* e);
 
+/* Opt-in deployment mode, knob FACE_CACHE (environment LTK_FACE_CACHE=1 or ltk_debug_set_knob): the Wav2Lip face encoder reads
+ * the bank frame only (avatars/wav2lip/models/wav2lip_v2.py:132-140: `feats` come from the masked + reference crop, the audio
+ * enters at the decoder), so its eight skip tensors are computed once per avatar - on the avatar's first ltk_wav2lip_infer call,
+ * 4.15 MB of fp16 per bank frame, resident in HBM - and a pass copies them into the decoder's concat buffers instead of running
+ * conv7 + 20 encoder layers.  Frames are byte-identical to the mode off for 16-frame calls (the cache is built by 16-frame
+ * launches), within 1 LSB for other call sizes, byte-identical for every size under LTK_SPLITK=0.  bench.py never times this
+ * mode on its headline line (cached outputs are skipped work there); it reports it on its own also[] entry.
+ * Returns the bytes of skip cache the avatar currently holds (0 = none built). */
+int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes);
+
 /* Number of (program, frame count) pairs of the MuseTalk side - the U-Net + VAE decoder pass behind ltk_musetalk_infer, the
  * Whisper encoder behind ltk_whisper_step - that currently run from a captured hipGraph (knob GRAPH; captured the second time
  * a frame count is seen). */

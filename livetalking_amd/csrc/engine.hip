@@ -140,6 +140,7 @@ struct Layer {
     bool residual = false;
     bool res_folded = false;   // the identity branch lives in the centre tap of the packed weights
     bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
+    bool face_enc = false;   // face-encoder layer: depends on the bank frame only (knob FACE_CACHE)
     double macs = 0;  // per frame
     // measured tile / split choice per frame-count bucket (<= 16, 32, 64, 128, 256+ frames per launch); 0 = conv3's rule
     struct Tile { signed char pxw = 0, nbt = 0, ks = 0; } tile[5];
@@ -220,6 +221,11 @@ struct Avatar {
     std::vector<int32_t> coords;
     int n = 0, H = 0, W = 0;
     int device = 0;
+    // knob FACE_CACHE: the face encoder's skip tensors of every bank frame (records of feat_rec_bytes, misc_kernels.h FeatGeom),
+    // built on first use under the engine's enqueue lock; feat_epoch = knob_epoch() it was built under
+    uint8_t* d_feat = nullptr;
+    size_t feat_rec_bytes = 0;
+    unsigned feat_epoch = 0;
     Avatar() = default;
     Avatar(const Avatar&) = delete;
     Avatar& operator=(const Avatar&) = delete;
@@ -227,6 +233,7 @@ struct Avatar {
         (void)hipSetDevice(device);
         if (d_face) (void)hipFree(d_face);
         if (d_full) (void)hipFree(d_full);
+        if (d_feat) (void)hipFree(d_feat);
     }
 };
 
@@ -627,6 +634,7 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
                 bump(&bh[L.out_buf], (size_t)L.Ho * L.Wo * bl.d.cout);
             }
             L.macs = (double)bl.d.cin * bl.d.cout * bl.d.k * bl.d.k * L.Ho * L.Wo;
+            L.face_enc = true;
             e->layers.push_back(L);
             in_buf = L.out_buf; in_ld = L.out_ld; in_coff = L.out_coff; H = L.Ho; W = L.Wo;
         }
@@ -692,10 +700,12 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // Knob DF_FRAMES > 0: the decoder blocks >= DF_BLOCK and the output conv run depth-first over sub-batches of that many frames
 // (all their layers for frames [f0, f0 + df), then the next sub-batch), so that a producer's output is still in the 256 MiB
 // Infinity Cache when its consumer reads it; every layer sees the same frames with the same weights, only the launch size changes.
+// `part`: 0 the whole network; 1 the face encoder only (builds the skip cache of knob FACE_CACHE: no audio branch, no decoder);
+// 2 everything but the face encoder (its skip tensors are already in the concat buffers).
 int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr,
-              const FacePtrs* faces = nullptr) {
+              const FacePtrs* faces = nullptr, int part = 0) {
     std::string err;
-    const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM) && !evs;
+    const bool fork = !e->capture && e->aux && !knob(K_NO_AUX_STREAM) && !evs && part != 1;
     size_t evi = 0;
     bool joined = !fork;
     if (fork) {
@@ -715,6 +725,12 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         for (size_t i = head; i < e->layers.size(); ++i) order.push_back(&e->layers[i]);
     } else {
         for (Layer& L : e->layers) order.push_back(&L);
+    }
+    if (part != 0) {
+        std::vector<Layer*> kept;
+        for (Layer* L : order)
+            if ((part == 1) == L->face_enc) kept.push_back(L);
+        order.swap(kept);
     }
     // one layer on frames [f0, f0 + n) of the arena
     auto launch_layer = [&](Layer& L, int f0, int n, bool on_aux) -> int {
@@ -1013,15 +1029,33 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
 // One pass over frames [0, nf) of the arena on `s`; the per-frame pointer tables are already in e->d_tab.
 // bank_faces: the faces table holds uint8 bank crops (else `d_face6`: float32 NCHW test input); have_outs: the outs table holds
 // the uint8 frame destinations; d_pred_f32 (test hook): float32 NCHW sigmoid output.
+// geometry of a face-cache record against the concat buffers (misc_kernels.h FeatGeom): level k = face_encoder_blocks.k's output
+static FeatGeom feat_geom(ltk_engine* e) {
+    FeatGeom g;
+    unsigned off = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int cat = B_CAT0 + (7 - k), hw = kFeatHW[k] * kFeatHW[k];
+        g.cat[k] = e->buf[cat] + (size_t)(kDecCh[7 - k] / 16) * hw * 16;     // channel blocks [dec_ch/16, +feat_ch/16) of a frame
+        g.cat_stride[k] = (unsigned)e->buf_halfs[cat];
+        g.off[k] = off;
+        off += (unsigned)((size_t)kFeatCh[k] * hw * sizeof(f16) / 16);
+    }
+    g.off[8] = off;
+    return g;
+}
+
+// `cached` (knob FACE_CACHE): the faces table holds the frames' skip-cache records instead of their bank crops; the face encoder
+// does not run, one copy launch puts its eight outputs where it would have written them.
 static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool fused, bool have_outs,
-                        float* d_pred_f32) {
+                        float* d_pred_f32, bool cached = false) {
     const FacePtrs* d_faces = &e->d_tab->faces;
     const OutPtrs* d_outs = &e->d_tab->outs;
     const bool pack_fused = bank_faces && e->c7 && knob(K_CONV7);     // the first layer reads the bank crops itself
-    if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
+    if (cached) launch_feat_copy(d_faces, nf, feat_geom(e), 0, s);
+    else if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
     launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);
-    const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, pack_fused ? d_faces : nullptr);
+    const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, (pack_fused && !cached) ? d_faces : nullptr, cached ? 2 : 0);
     if (rc) return rc;
     if (!fused) {
         launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, have_outs ? d_outs : nullptr, d_pred_f32, s);
@@ -1037,7 +1071,8 @@ constexpr size_t kMaxPassGraphs = 48;
 // kernel's dynamic-LDS attribute) and is captured the second time; a dependent launch costs ~3.1 us on a stream and ~2.0 us inside a
 // graph (profiles/r03_ubench_launch_chain.txt), and the host issues one launch instead of ~70.  The audio-encoder branch on the aux
 // stream becomes a branch of the graph (its fork / join events are captured as dependencies).
-static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32) {
+static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32,
+                       bool cached = false) {
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
     const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
     // knob GRAPH: 0 never, non-zero (default 1) every eligible pass.  Measured (profiles/r04_vs_r03_same_job.txt, r04_graph_auto_ab.txt): the replay of a
@@ -1046,16 +1081,16 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     // last box: 1.3836 / 1.3904 / 1.3956 ms eager, 1.3619 / 1.3699 / 1.3596 ms replayed), and a host serving hundreds of sessions sustains 512 instead
     // of 448 of them (profiles/r04_delivered_graph_ab.txt).
     const bool graphable = knob(K_GRAPH) && bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
-    if (!graphable) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    if (!graphable) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached && bank_faces);
     if (e->graph_epoch != knob_epoch()) {           // a knob changed (tests, tuners): the captured launch sequences are stale
         CHK(hipStreamSynchronize(s));
         drop_graphs(e);
         e->graph_epoch = knob_epoch();
     }
-    ltk_engine::PassGraph& g = e->graphs[nf];
+    ltk_engine::PassGraph& g = e->graphs[nf | (cached ? (1 << 20) : 0)];      // the cached pass is a different launch sequence
     g.stamp = ++e->graph_clock;
     if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); return 0; }
-    if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached);
     size_t live = 0;
     for (auto& kv : e->graphs) live += kv.second.exec ? 1 : 0;
     if (live >= kMaxPassGraphs) {                       // least recently used out
@@ -1069,7 +1104,7 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     }
     hipGraph_t graph = nullptr;
     CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+    const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached);
     const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
     if (rc) {
         // enqueue_pass failed mid-capture (possibly with the aux stream forked and never joined: EndCapture then reports an
@@ -1089,7 +1124,7 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
         (void)hipGetLastError();
         g.seen = -1;
         fprintf(stderr, "ltk: hipGraph capture of the %d-frame pass failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
-        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32);
+        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached);
     }
     g.exec = exec;
     CHK(hipGraphLaunch(exec, s));
@@ -1103,11 +1138,53 @@ int ltk_debug_tile_table_check(char* msg, int cap) {
     return bad;
 }
 
+// Knob FACE_CACHE: the face encoder's outputs of every bank frame of `a`, computed by the SAME kernels a 16-frame pass runs (the
+// bank is walked in chunks of 16 frames - the last chunk overlaps its predecessor so that every launch has 16 frames - hence a
+// 16-frame call renders byte for byte what it renders with the knob off; other call sizes may pick other split factors for the
+// small-map encoder layers, as two different call sizes do among themselves: <= 1 LSB, exact under LTK_SPLITK=0).  Under e->mu, on
+// the compute stream (stream order keeps the arena and the pointer table consistent with the calls around it).
+static int build_face_cache(ltk_engine* e, Avatar& a) {
+    const FeatGeom g = feat_geom(e);
+    const size_t rec = (size_t)g.off[8] * 16;
+    if (!a.d_feat) {
+        if (hipMalloc((void**)&a.d_feat, rec * a.n) != hipSuccess) { (void)hipGetLastError(); return fail(LTK_E_NOMEM, "face-cache allocation failed"); }
+        a.feat_rec_bytes = rec;
+    }
+    const int chunk = std::min(std::min(16, a.n), std::min(e->micro_batch, kPackMaxFrames));
+    const bool pack_fused = e->c7 && knob(K_CONV7);
+    for (int f0 = 0; f0 < a.n; f0 += chunk) {
+        const int first = std::min(f0, a.n - chunk);
+        FacePtrs fp;
+        for (int i = 0; i < chunk; ++i) fp.p[i] = a.d_face + (size_t)(first + i) * 256 * 256 * 3;
+        launch_upload_tables(&fp, nullptr, nullptr, chunk, e->d_tab, e->compute);
+        if (!pack_fused) launch_pack_faces(&e->d_tab->faces, chunk, e->buf[B_X0], e->compute);
+        const int rc = run_convs(e, chunk, e->compute, nullptr, nullptr, pack_fused ? &e->d_tab->faces : nullptr, 1);
+        if (rc) return rc;
+        for (int i = 0; i < chunk; ++i) fp.p[i] = a.d_feat + (size_t)(first + i) * rec;
+        launch_upload_tables(&fp, nullptr, nullptr, chunk, e->d_tab, e->compute);
+        launch_feat_copy(&e->d_tab->faces, chunk, g, 1, e->compute);
+        CHK(hipGetLastError());
+    }
+    a.feat_epoch = knob_epoch();
+    return 0;
+}
+
+int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes) {
+    if (!e || !bytes) return fail(LTK_E_INVALID, "bad arguments");
+    std::lock_guard<std::mutex> g(e->pool_mu);
+    auto it = e->avatars.find(avatar_id);
+    if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
+    *bytes = it->second->d_feat ? it->second->feat_rec_bytes * (size_t)it->second->n : 0;
+    return LTK_OK;
+}
+
 int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream) {
     if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
     CHK(enter_device(e->device));
     // resolve every frame's bank crop and mel window up front
+    const bool want_cache = knob(K_FACE_CACHE) != 0;
+    std::vector<int> fidx;                            // knob FACE_CACHE: (request, bank frame) of every frame
     std::vector<const uint8_t*> fptr;
     std::vector<const float*> mptr;
     std::vector<uint8_t*> optr;
@@ -1123,6 +1200,7 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             for (int i = 0; i < reqs[r].batch; ++i) {
                 const int idx = mirror_index(a.n, reqs[r].index + i);  // wav2lip_avatar.py:121-124
                 fptr.push_back(a.d_face + (size_t)idx * 256 * 256 * 3);
+                if (want_cache) { fidx.push_back(r); fidx.push_back(idx); }
                 mptr.push_back((const float*)reqs[r].d_mel + (size_t)i * 80 * 16);
                 optr.push_back((uint8_t*)reqs[r].d_pred + (size_t)i * 65536 * 3);
             }
@@ -1146,13 +1224,22 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             CHK(hipStreamWaitEvent(e->compute, ready.e, 0));
         }
         const int mbs = std::min(e->micro_batch, kPackMaxFrames);
+        // knob FACE_CACHE: every avatar of the call gets its skip cache on first use (and again after a knob change); the call then
+        // runs without the face encoder.  The mode needs the product configuration (fused head, no layer capture).
+        const bool cached = want_cache && !e->capture && knob(K_HEAD_FUSED);
+        if (cached) {
+            for (auto& ap : hold)
+                if (!rc && (!ap->d_feat || ap->feat_epoch != knob_epoch())) rc = build_face_cache(e, *ap);
+            if (!rc)
+                for (int i = 0; i < total; ++i) fptr[i] = hold[fidx[2 * i]]->d_feat + (size_t)fidx[2 * i + 1] * hold[fidx[2 * i]]->feat_rec_bytes;
+        }
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
             for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; op.p[i] = optr[f0 + i]; }
             launch_upload_tables(&fp, &mp, &op, nf, e->d_tab, e->compute);
             if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "pointer table upload failed");
-            else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr);
+            else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached);
         }
         if (!rc) {
             if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");

@@ -44,6 +44,17 @@ struct OutPtrs {
 void launch_head(const f16* x32, int x_ld, int nframes, const float* w3x32, const float* b3,
                  const OutPtrs* out_u8, float* out_f32_nchw, hipStream_t s);
 
+// Face-encoder skip cache (knob FACE_CACHE): a bank frame's record holds the eight skip tensors of the face encoder back to back,
+// each as its channel-block range [C/16][H][W][16] of fp16 (what the encoder's last layer of a block writes into the decoder's
+// concat buffer).  One launch moves the records of `nframes` frames: dir 0 record -> concat buffers (a pass; `recs` = the pass's
+// DEVICE table, carried in the FacePtrs slot: the bank crops are not read in this mode), dir 1 concat buffers -> records (build).
+struct FeatGeom {
+    f16* cat[8];                 // level k: first half of the tensor inside frame 0 of its concat buffer
+    unsigned cat_stride[8];      // halfs between two frames of that buffer
+    unsigned off[9];             // record offset of level k, in 16-byte items; off[8] = items per record
+};
+void launch_feat_copy(const FacePtrs* recs, int nframes, const FeatGeom& g, int dir, hipStream_t s);
+
 // The three tables of one pass, contiguous in device memory.
 struct DevTables {
     FacePtrs faces;

@@ -143,6 +143,26 @@ void launch_upload_tables(const FacePtrs* faces, const MelPtrs* mels, const OutP
     }
 }
 
+// face-encoder skip cache <-> concat buffers (misc_kernels.h FeatGeom): blockIdx.y = frame, 16 bytes per thread and trip
+__global__ __launch_bounds__(256) void feat_copy_kernel(const FacePtrs* __restrict__ recs, const FeatGeom g, int dir) {
+    const int f = blockIdx.y;
+    uint4* const rec = reinterpret_cast<uint4*>(const_cast<uint8_t*>(recs->p[f]));
+    const unsigned total = g.off[8];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) k += (i >= g.off[q]) ? 1 : 0;
+        uint4* const cat = reinterpret_cast<uint4*>(g.cat[k] + (size_t)f * g.cat_stride[k]) + (i - g.off[k]);
+        if (dir == 0) *cat = rec[i];
+        else rec[i] = *cat;
+    }
+}
+
+void launch_feat_copy(const FacePtrs* recs, int nframes, const FeatGeom& g, int dir, hipStream_t s) {
+    const unsigned blocks = (g.off[8] + 256u * 4u - 1u) / (256u * 4u);       // four items per thread
+    hipLaunchKernelGGL(feat_copy_kernel, dim3(blocks, (unsigned)nframes), dim3(256), 0, s, recs, g, dir);
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, int N, int HW, int ld, int coff, int C,
                                                             float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -51,6 +51,9 @@ enum Knob {
     K_MT_TILE_TABLE,      // LTK_MT_TILE_TABLE  1: measured per-level conv3 tile width for the U-Net's 3x3 convs in passes of <= 16 frames (musetalk.hip mt_graph_run)
     K_LDS_SWZ,            // LTK_LDS_SWZ        1: conv3's stride-1 LDS image takes the row-parity key on tiles narrower than 32 pixels (conflict-free
                           //                    ds_read_b128 on 16- / 8-pixel-wide maps); 0: column key everywhere (rounds 1-3)
+    K_FACE_CACHE,         // LTK_FACE_CACHE     1 (opt-in deployment mode, default 0): the face encoder's eight skip tensors depend on the BANK frame only
+                          //                    (wav2lip_v2.py:132-140), so they are computed once per avatar (4.15 MB of fp16 per bank frame, resident in HBM)
+                          //                    and a pass copies them into the decoder's concat buffers instead of running conv7 + 20 encoder layers
     K_COUNT
 };
 

@@ -35,6 +35,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_MT_ROWCONV", 1024},
     {"LTK_MT_TILE_TABLE", 1},
     {"LTK_LDS_SWZ", 1},
+    {"LTK_FACE_CACHE", 0},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -369,6 +369,12 @@ class Engine:
         """Frame counts whose Wav2Lip pass currently replays from a captured hipGraph (include/ltk.h)."""
         return int(self._lib.ltk_wav2lip_graph_count(self._h))
 
+    def face_cache_bytes(self, avatar_id: int) -> int:
+        """Bytes of face-encoder skip cache the avatar holds (knob FACE_CACHE, include/ltk.h); 0 = none built."""
+        n = C.c_size_t(0)
+        _lib.check(self._lib.ltk_avatar_face_cache_bytes(self._h, int(avatar_id), C.byref(n)))
+        return int(n.value)
+
     def program_graph_count(self) -> int:
         """(program, frame count) pairs of the MuseTalk side (U-Net + VAE pass, Whisper encoder) that replay from a captured hipGraph."""
         return int(self._lib.ltk_program_graph_count(self._h))

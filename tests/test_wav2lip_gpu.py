@@ -494,3 +494,60 @@ def test_tile_table_off_equals_table_on_within_one_lsb(engine, golden_dir):
             assert d.max() <= 1 and float((d != 0).mean()) < 0.05
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_face_cache_mode_equals_mode_off(golden_dir):
+    """Knob FACE_CACHE (opt-in deployment mode, include/ltk.h ltk_avatar_face_cache_bytes): the face encoder's skip tensors of
+    every bank frame are computed once per avatar and copied into the decoder's concat buffers instead of running conv7 + 20
+    encoder layers (wav2lip_v2.py:132-140: `feats` depend on the bank frame only).  A 16-frame call across the bank's ping-pong
+    turn must give byte for byte the frames of the mode off (the cache is built by 16-frame launches of the same kernels); a
+    64-frame call of four sessions stays within 1 LSB (other split factors on the small-map encoder layers, as between any two
+    call sizes) and is byte-identical under LTK_SPLITK=0; the cached pass replays from its own captured graph."""
+    from livetalking_amd.engine import Engine
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=20, full_hw=(180, 320), box=96, seed=4)
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    feats = gm["ref_chunks"].reshape(-1, 80, 16).astype(np.float32)          # 48 real mel windows
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=64)
+        aid = eng.register_avatar(faces, frames, coords)
+        mel16 = torch.from_numpy(feats[:16].copy()).cuda()
+        mel64 = torch.from_numpy(np.concatenate([feats, feats[:16]]).copy()).cuda()
+
+        def run16():
+            pred = torch.zeros(16, 256, 256, 3, dtype=torch.uint8, device="cuda")
+            for _ in range(3):                                          # eager, capture, replay
+                eng.wav2lip_infer([(aid, 13, 16, mel16.data_ptr(), pred.data_ptr())])       # bank frames 13..19, 19..11
+            return pred.cpu().numpy().astype(np.int16)
+
+        def run64():
+            pred = torch.zeros(64, 256, 256, 3, dtype=torch.uint8, device="cuda")
+            reqs = [(aid, 5 + 9 * s, 16, mel64[16 * s:].data_ptr(), pred[16 * s:].data_ptr()) for s in range(4)]
+            for _ in range(2):
+                eng.wav2lip_infer(reqs)
+            return pred.cpu().numpy().astype(np.int16)
+
+        try:
+            off16, off64 = run16(), run64()
+            assert eng.face_cache_bytes(aid) == 0
+            Engine.set_knob("FACE_CACHE", 1)
+            on16, on64 = run16(), run64()          # (the knob change dropped the graphs of the mode off: what is counted below is new)
+            per_frame = sum(c * hw * hw * 2 for c, hw in zip((16, 32, 64, 128, 256, 512, 512, 512), (256, 128, 64, 32, 16, 8, 4, 1)))
+            assert eng.face_cache_bytes(aid) == 20 * per_frame and per_frame == 4_146_176
+            assert eng.graph_count() == 2, "the cached 16- and 64-frame passes were not captured as their own graphs"
+            assert np.array_equal(on16, off16), f"16-frame call: max diff {np.abs(on16 - off16).max()} LSB"
+            d = np.abs(on64 - off64)
+            print(f"[face cache, 64-frame call] max {int(d.max())} LSB, differing bytes {float((d != 0).mean()):.5f}")
+            assert d.max() <= 1 and float((d != 0).mean()) < 0.05
+            Engine.set_knob("SPLITK", 0)
+            Engine.set_knob("FACE_CACHE", 0)
+            off64_s = run64()
+            Engine.set_knob("FACE_CACHE", 1)
+            on64_s = run64()
+            assert np.array_equal(on64_s, off64_s), "LTK_SPLITK=0: the cache must be exact at every call size"
+        finally:
+            Engine.set_knob("FACE_CACHE", 0)
+            Engine.set_knob("SPLITK", 1)
+    finally:
+        eng.close()
