@@ -337,8 +337,18 @@ def run_wav2lip(args, ranks: Ranks):
     # of the same workload.  One "launch" below = one pass over min(frames_per_step, 256) frames.
     nf_pass = min(frames_per_step, 256)
     graphs_timed_run = eng.graph_count()            # > 0: the timed inference_batch calls above ran from captured graphs
+    pf_stats = eng.prefetch_stats()                 # knob PREFETCH: how the session calls above actually ran
     conv_ms, conv_macs = eng.time_convs(nf_pass, 10)
     achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
+    # the same pass with every call running the whole network on its own (knob PREFETCH off: rounds 1-4), for comparison
+    conv_ms_whole = None
+    if pf_stats["issued"] > 0:
+        from livetalking_amd.engine import Engine
+        Engine.set_knob("PREFETCH", 0)
+        try:
+            conv_ms_whole = eng.time_convs(nf_pass, 10)[0]
+        finally:
+            Engine.set_knob("PREFETCH", 1)
     out = None
     if ranks.rank == 0:
         out = {
@@ -356,7 +366,14 @@ def run_wav2lip(args, ranks: Ranks):
                                          "(graph replay under knob GRAPH); conv_stack_ms is the same figure under its round-1..4 name",
                          "frames_per_pass": nf_pass, "flops_per_frame": 2.0 * conv_macs / nf_pass,
                          "hipgraph": bool(graphs_timed_run), "graphs_captured_in_timed_run": graphs_timed_run,
-                         "face_cache": False},
+                         "face_cache": False,
+                         "pipelined_across_calls": bool(pf_stats["hits"] > 0),
+                         "prefetch": dict(pf_stats, note="knob PREFETCH: while a call runs its audio encoder + decoder, the face encoder of the frames "
+                                          "the session's NEXT call will ask for (bank frames index+B.., known from the bank walk) runs beside it on a third "
+                                          "stream; hits = calls that started at the decoder.  Every layer runs once per frame and step inside the timed "
+                                          "region (the first call runs the whole pass, the last call's prefetch is extra work); frames byte-identical to "
+                                          "the knob off (tests/test_wav2lip_gpu.py::test_prefetched_face_encoder_equals_whole_pass)"),
+                         "pass_ms_whole_pass_per_call": round(conv_ms_whole, 4) if conv_ms_whole else None},
             "per_rank_fps": [round(args.steps * frames_per_step / t, 1) for t in per_rank],
             "scheduler": sched,
         }

@@ -289,6 +289,17 @@ int ltk_wav2lip_graph_count(ltk_engine* e);
  * Returns the bytes of skip cache the avatar currently holds (0 = none built). */
 int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes);
 
+/* Knob PREFETCH (default on; LTK_PREFETCH=0 switches it off): software pipelining ACROSS the calls of one session.  The face
+ * encoder reads the bank frame only (wav2lip_v2.py:132-140) and a session walks its bank in order (base_avatar.py:366-376:
+ * inference_batch(index, ...), index advancing by one per frame), so when a single-request call of <= 32 frames continues
+ * the previous one (same avatar, index = previous index + batch) the engine runs, beside that call's audio encoder + decoder and
+ * on a third stream, the face encoder of the frames the NEXT call will ask for, into the other set of concat buffers; the next
+ * call then starts at the decoder.  Every layer still runs once per frame and step and the frames are byte-identical to the
+ * knob off (same kernels, same launch shapes); a call that does not continue the sequence (another session, a jump of the
+ * index, a multi-request call) runs the whole pass and the unused prefetch is dropped.  Counters since engine creation:
+ * single-request calls that found their encoder outputs prefetched / that did not / prefetches issued. */
+int ltk_wav2lip_prefetch_stats(ltk_engine* e, unsigned long long* hits, unsigned long long* misses, unsigned long long* issued);
+
 /* Number of (program, frame count) pairs of the MuseTalk side - the U-Net + VAE decoder pass behind ltk_musetalk_infer, the
  * Whisper encoder behind ltk_whisper_step - that currently run from a captured hipGraph (knob GRAPH; captured the second time
  * a frame count is seen). */

@@ -81,6 +81,7 @@ SYMBOLS = {
     "ltk_wav2lip_time_convs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "ltk_wav2lip_graph_count": (C.c_int, [C.c_void_p]),
     "ltk_program_graph_count": (C.c_int, [C.c_void_p]),
+    "ltk_wav2lip_prefetch_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "ltk_avatar_face_cache_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "ltk_musetalk_op_count": (C.c_int, [C.c_void_p]),
     "ltk_musetalk_op_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),

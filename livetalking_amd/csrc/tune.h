@@ -54,6 +54,11 @@ enum Knob {
     K_FACE_CACHE,         // LTK_FACE_CACHE     1 (opt-in deployment mode, default 0): the face encoder's eight skip tensors depend on the BANK frame only
                           //                    (wav2lip_v2.py:132-140), so they are computed once per avatar (4.15 MB of fp16 per bank frame, resident in HBM)
                           //                    and a pass copies them into the decoder's concat buffers instead of running conv7 + 20 encoder layers
+    K_PREFETCH,           // LTK_PREFETCH       1 (default): a session's consecutive single-request calls (index advancing by its batch size, <= 32 frames) are
+                          //                    software-pipelined across calls: while call N runs its audio encoder + decoder, the face encoder of the frames call
+                          //                    N+1 will ask for (bank frames index+B ..) runs beside it on a third stream into the other set of concat buffers; call
+                          //                    N+1 then starts at the decoder.  Every layer still runs once per frame and step; a call that does not continue the
+                          //                    sequence runs the whole pass.  0: every call runs the whole pass (rounds 1-4)
     K_COUNT
 };
 

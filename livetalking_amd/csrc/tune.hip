@@ -36,6 +36,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_MT_TILE_TABLE", 1},
     {"LTK_LDS_SWZ", 1},
     {"LTK_FACE_CACHE", 0},
+    {"LTK_PREFETCH", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

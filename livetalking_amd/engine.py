@@ -375,6 +375,13 @@ class Engine:
         _lib.check(self._lib.ltk_avatar_face_cache_bytes(self._h, int(avatar_id), C.byref(n)))
         return int(n.value)
 
+    def prefetch_stats(self) -> dict:
+        """Knob PREFETCH (include/ltk.h): single-request calls that found their face-encoder outputs prefetched by the previous
+        call / that did not / prefetches issued."""
+        h, m, i = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        _lib.check(self._lib.ltk_wav2lip_prefetch_stats(self._h, C.byref(h), C.byref(m), C.byref(i)))
+        return {"hits": int(h.value), "misses": int(m.value), "issued": int(i.value)}
+
     def program_graph_count(self) -> int:
         """(program, frame count) pairs of the MuseTalk side (U-Net + VAE pass, Whisper encoder) that replay from a captured hipGraph."""
         return int(self._lib.ltk_program_graph_count(self._h))

@@ -551,3 +551,57 @@ def test_face_cache_mode_equals_mode_off(golden_dir):
             Engine.set_knob("SPLITK", 1)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [1, 0])
+def test_prefetched_face_encoder_equals_whole_pass(golden_dir, graph):
+    """Knob PREFETCH (default on): a session's consecutive single-request calls are pipelined across calls - the face encoder of
+    the frames call N+1 will ask for runs beside call N's decoder on a third stream into the other set of concat buffers
+    (include/ltk.h ltk_wav2lip_prefetch_stats).  A sequence of calls as a session issues them (index += batch, across the bank's
+    ping-pong turn), then a jump of the index (the prefetch is dropped), then the sequence resumed, with another avatar's call
+    interleaved once: every call's frames must equal byte for byte the frames of the knob off, the counters must show that calls
+    really started at the decoder, and the same with the pass replayed from graphs and launched eagerly."""
+    from livetalking_amd.engine import Engine
+    frames, faces, coords = synth.wav2lip_avatar(n_frames=20, full_hw=(180, 320), box=96, seed=4)
+    frames2, faces2, coords2 = synth.wav2lip_avatar(n_frames=7, full_hw=(180, 320), box=96, seed=6)
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    feats = gm["ref_chunks"].reshape(-1, 80, 16).astype(np.float32)
+    B = 16
+    # (avatar, index): nine consecutive steps of avatar 0 (20 bank frames: several ping-pong turns), a jump, three more, the other
+    # avatar once, then avatar 0 continuing where it was
+    seq = [(0, B * k) for k in range(9)] + [(0, 7), (0, 7 + B), (0, 7 + 2 * B), (1, 3), (0, 7 + 3 * B), (0, 7 + 4 * B), (0, 7 + 5 * B)]
+    eng = Engine(0)
+    try:
+        Engine.set_knob("GRAPH", graph)
+        eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=32)
+        aids = [eng.register_avatar(faces, frames, coords), eng.register_avatar(faces2, frames2, coords2)]
+        mels = [torch.from_numpy(np.roll(feats, 3 * k, axis=0)[:B].copy() * (1.0 - 0.01 * k)).cuda() for k in range(len(seq))]
+
+        def run_all():
+            outs = []
+            for k, (av, index) in enumerate(seq):
+                pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+                eng.wav2lip_infer([(aids[av], index, B, mels[k].data_ptr(), pred.data_ptr())])
+                outs.append(pred.cpu())
+            return outs
+
+        try:
+            Engine.set_knob("PREFETCH", 0)
+            whole = run_all()
+            st0 = eng.prefetch_stats()
+            assert st0["hits"] == 0 and st0["issued"] == 0
+            Engine.set_knob("PREFETCH", 1)
+            piped = run_all()
+            st = eng.prefetch_stats()
+            print(f"[prefetch, graph={graph}] {st}")
+            # hits: steps 2..8 of the first run (7), steps 2 and 3 after the jump... the call after the foreign avatar misses, then two hits
+            assert st["hits"] >= 9 and st["issued"] >= st["hits"] and st["misses"] >= 4
+            for k in range(len(seq)):
+                assert torch.equal(piped[k], whole[k]), f"call {k} {seq[k]}: max diff {int((piped[k].to(torch.int16) - whole[k].to(torch.int16)).abs().max())} LSB"
+            assert not torch.equal(whole[0], whole[1])
+        finally:
+            Engine.set_knob("PREFETCH", 1)
+            Engine.set_knob("GRAPH", 1)
+    finally:
+        eng.close()
