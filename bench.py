@@ -777,7 +777,9 @@ def cpu_baseline(batch: int):
     frames, faces, coords = synth.wav2lip_avatar(n_frames=8, full_hw=(360, 640), box=160, seed=0)
     audio = synth.synthetic_audio(2.0)
     kind, call = "port", None
-    if os.path.exists(os.path.join(REF_ROOT, "avatars", "wav2lip_avatar.py")):
+    # LTK_CPU_BASELINE_KIND=port times the oracle port even where a checkout exists (scripts/cpu_baseline_compare.py: both kinds in
+    # the build container, so that the GPU box's `kind: port` figure is a validated proxy of the reference class)
+    if os.environ.get("LTK_CPU_BASELINE_KIND", "") != "port" and os.path.exists(os.path.join(REF_ROOT, "avatars", "wav2lip_avatar.py")):
         try:
             from oracle import ref_loop
             cwd = os.getcwd()

@@ -72,28 +72,33 @@ def main():
         f.write("kernel,calls,total_us,avg_us,min_us,max_us,pct,vgpr,sgpr\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1]):
             f.write(f"\"{k}\",{s[0]},{s[1]:.1f},{s[1]/s[0]:.2f},{s[2]:.2f},{s[3]:.2f},{100*s[1]/tot:.2f},{s[4]},{s[5]}\n")
-    # one inference pass
-    # a pass starts with the mel pack (the face pack is fused into the first conv since round 2) and ends with the output conv
-    # that carries the fused head (or the separate head kernel of the unfused path)
-    idx = [i for i, r in enumerate(rows) if "pack_mel" in r[0]]
+    # one inference pass = everything behind the previous pass's last kernel up to and including this pass's last kernel: the fused
+    # head (conv3_head_kernel / head_kernel) for Wav2Lip, the frame writer (vae_post_kernel) for MuseTalk.  (Since round 5 a Wav2Lip
+    # pass may carry the NEXT call's face encoder beside it - knob PREFETCH -, whose first launches go out in front of the mel pack:
+    # delimiting by the end marker keeps them in the pass that issued them.)
+    def is_end(name):
+        return "head_kernel" in name or "vae_post_kernel" in name
+    ends = [i for i, r in enumerate(rows) if is_end(r[0])]
     conv_us = 0.0
     with open(a.dst_prefix + "_pass_timeline.txt", "w") as f:
         f.write("# last inference pass of the profiled run: start_us dur_us stream grid lds_bytes kernel\n")
-        if idx:
-            t0 = rows[idx[-1]][1]
-            # pack_mel_kernel runs one grid row per frame: the frame count of THIS pass (a multi-session run coalesces calls of different sizes)
-            pm = rows[idx[-1]]
-            nfr = pm[9] // max(pm[10], 1) if pm[9] else 0
-            f.write(f"# frames in the listed pass: {nfr if nfr else 'unknown (no grid_y in the trace)'}\n")
-            for r in rows[idx[-1]:]:
+        if ends:
+            last = ends[-1]
+            first = ends[-2] + 1 if len(ends) > 1 else 0
+            # the pointer-table upload belongs to the pass it precedes; skip host-side blits between passes
+            seg = [r for r in rows[first:last + 1] if "__amd_rocclr" not in r[0]]
+            t0 = seg[0][1]
+            pm = [r for r in seg if "pack_mel" in r[0] or "gather_latents" in r[0]]
+            nfr = (pm[0][9] // max(pm[0][10], 1)) if pm and pm[0][9] else 0      # one grid row per frame
+            f.write(f"# frames in the listed pass: {nfr if nfr else a.frames}\n")
+            streams = sorted({r[8] for r in seg})
+            for r in seg:
                 n = short(r[0])
-                f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{r[8]} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
-                if "conv" in n or "rowgemm" in n:
+                f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{streams.index(r[8])} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
+                if a.all_kernels or "conv" in n or "rowgemm" in n:
                     conv_us += (r[2] - r[1]) / 1e3
-                nlaunch = nlaunch + 1 if "nlaunch" in dir() else 1
-                if "head_kernel" in n:
-                    f.write(f"# first start .. head end: {(r[2]-t0)/1e3:.1f} us; sum of conv kernels {conv_us:.1f} us; {nlaunch} launches\n")
-                    break
+            f.write(f"# first start .. last end: {(max(r[2] for r in seg)-t0)/1e3:.1f} us; sum of {'all' if a.all_kernels else 'conv'} kernels "
+                    f"{conv_us:.1f} us; {len(seg)} launches on {len(streams)} stream(s)\n")
 
     fetch = counters(os.path.join(sub("pmc_fetch"), "r_results.db"))
     write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
