@@ -99,8 +99,6 @@ __host__ __device__ constexpr int k3_maxa(int PXW, int NC8, int S = 1, int T = 9
                   : S == 2 ? (NC8 == 2 ? 10 : 20) : PXW == 4 ? (NC8 == 2 ? 6 : 12) : (NC8 == 2 ? 4 : (NC8 == 4 ? 8 : 16));
 }
 __host__ __device__ constexpr int k3_maxb(int NBT, int NC8, int T) { return (NBT * T * NC8 * 32 + 255) / 256; }
-// 8-wave blocks (1024-pixel tile of a 3x3 conv, 16-channel chunks): 34 x 34 patch pixels = 2368 slots = 37 copies of 64 slots over 8 waves
-__host__ __device__ constexpr int k3_maxa8() { return 5; }
 
 #define GLDS16(gptr, lptr)                                                                                   \
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                  \
@@ -125,16 +123,12 @@ struct HeadArgs {
     const OutPtrs* outs;             // DEVICE table, per frame: uint8 [256][256][3]
 };
 
-// NW = waves per block: 4 (256 threads, two resident blocks per CU), or 8 (round 5 experiment, knob CONV3_NW8: ONE 512-thread block per
-// CU whose 1024-pixel tile shares one weight slab - 0.095 instead of 0.13 LDS-DMA pieces per MFMA on the 64-cout 3x3 layers)
-template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0, int NW = 4>
+template <int G, int NBT, int PXW, int NC8, int T, int S, int Q, int HEAD = 0>
 __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsigned char* const smem, const HeadArgs* hd = nullptr) {
     static_assert(HEAD == 0 || (G == 1 && NBT == 1 && T == 9 && S == 1 && Q == 0), "fused head: the 3x3 32-cout output conv");
-    static_assert(NW == 4 || (NW == 8 && G == 1 && T == 9 && S == 1 && Q == 0 && HEAD == 0 && PXW == 4 && NC8 == 2), "8-wave blocks: 3x3 stride-1 fp16, 1024-pixel tiles");
-    constexpr int NT = 64 * NW;
     constexpr int BN = NBT * 32;
-    constexpr int MAXA = NW == 8 ? k3_maxa8() : k3_maxa(PXW, NC8, S, T);
-    constexpr int MAXB = (NBT * T * NC8 * 32 + NT - 1) / NT;
+    constexpr int MAXA = k3_maxa(PXW, NC8, S, T);
+    constexpr int MAXB = k3_maxb(NBT, NC8, T);
     static_assert(G == 1 || (G == 4 && (T == 9 || T == 16) && NBT == 1), "merged convT (9 taps) / upsample-conv (16): 32 couts per block");
     static_assert(NBT <= 2 || T == 1, "128-cout blocks: 1x1 convolutions only (accumulator budget)");
     static_assert(Q == 0 || G == 1, "fp8 operands: plain convolutions only");
@@ -171,7 +165,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     if (!ABL(a, 32)) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const bool two = c_end - c_begin > 1;               // a one-chunk item (16-channel layers) never touches the second stage
-        for (int i = tid * 16; i < A_BYTES; i += NT * 16) {
+        for (int i = tid * 16; i < A_BYTES; i += 256 * 16) {
             *reinterpret_cast<uint4*>(smem + i) = z;
             if (two) *reinterpret_cast<uint4*>(smem + STAGE + i) = z;
         }
@@ -193,7 +187,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
     asm volatile("" : "+v"(lane_i));
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
-        const int s64 = k * NW + wave;                      // wave-uniform
+        const int s64 = k * 4 + wave;                       // wave-uniform
         const int cbj = s64 / p64n;
         const int slot = (s64 - cbj * p64n) * 64 + lane_i;
         const int pix = slot >> 1;
@@ -228,7 +222,7 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         if (!ABL(a, 1)) {
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
-                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * NW + wave) * 1024);
+                if (a_goff[k] != ~0u) GLDS16(xc + a_goff[k], Ab + (k * 4 + wave) * 1024);
         }
         const unsigned char* wc = reinterpret_cast<const unsigned char*>(wsrc + (size_t)c * slab32);
         if (!ABL(a, 2)) {
@@ -236,10 +230,10 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             asm volatile("" : "+v"(tq));           // kernel-lifetime values and spilled (see lane_i above)
 #pragma unroll
             for (int k = 0; k < MAXB; ++k) {
-                const unsigned i = tq + k * (unsigned)NT;
+                const unsigned i = tq + k * 256u;
                 if (i < (unsigned)(NBT * slab32)) {
                     const unsigned off = i * 16u + (NBT > 1 ? (i / (unsigned)slab32) * b_sub1 : 0u);   // sub-slab s starts s*nchunks*slab32 items in
-                    GLDS16(wc + off, Bb + (k * NT + wave * 64) * 16);
+                    GLDS16(wc + off, Bb + (k * 256 + wave * 64) * 16);
                 }
             }
         }
@@ -692,20 +686,6 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const K3Args a) {
     }
 }
 
-// 8-wave variant (knob CONV3_NW8): one 512-thread block per CU, 1024 pixels x NBT*32 couts per item
-template <int NBT>
-__global__ __launch_bounds__(512, 1) void conv3_kernel_w8(const K3Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nblk = gridDim.x;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    for (int item = first; item < a.nitems; item += nblk) {
-        if (item != first) __syncthreads();
-        conv3_item<1, NBT, 4, 2, 9, 1, 0, 0, 8>(a, item, smem);
-    }
-}
-
 template <int PXW>
 __global__ __launch_bounds__(256, 2) void conv3_head_kernel(const K3Args a, const HeadArgs h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -902,10 +882,8 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     const bool forced_tile = io.force_pxw != 0 && io.force_nbt != 0;
     int l2w = 0, l2h = 0, NB = 1, PH = 1, PW = 1, npix = 0, SLOTS = 0, swz_x = 1, swz_row = 0;
     long long blocks = 0;
-    int NWsel = 4;             // waves per block (8: knob CONV3_NW8, see below)
     auto geom = [&](int pxw) -> bool {
-        const int M = 32 * NWsel * pxw;
-        const int maxa_slots = NWsel == 8 ? k3_maxa8() * 512 : k3_maxa(pxw, NC8, S, T) * 256;
+        const int M = 128 * pxw;
         const int lm = ceil_log2_(M);
         l2w = std::min(5, ceil_log2_(a.Wo));
         l2h = std::min(lm - l2w, ceil_log2_(a.Ho));
@@ -920,14 +898,14 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
             if (l2w == 3 && ext > 0) PW = 12;
         }
         // tiny maps: the halo makes NB patches larger than the staging budget -> fewer images per tile
-        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > maxa_slots) --NB;
+        while (NB > 1 && (NC8 / 2) * ((2 * NB * PH * PW + 63) / 64 * 64) > k3_maxa(pxw, NC8, S, T) * 256) --NB;
         npix = NB * PH * PW;
         SLOTS = (2 * npix + 63) / 64 * 64;
         const int tiles_x = (a.Wo + (1 << l2w) - 1) >> l2w, tiles_y = (a.Ho + (1 << l2h) - 1) >> l2h;
         const int tiles_n = (io.N + NB - 1) / NB;
         blocks = (long long)tiles_x * tiles_y * tiles_n;
         a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tiles_n = tiles_n;
-        return (NC8 / 2) * SLOTS <= maxa_slots && npix < 32768;
+        return (NC8 / 2) * SLOTS <= k3_maxa(pxw, NC8, S, T) * 256 && npix < 32768;
     };
     bool fit;
     if (G == 1 && T == 9 && S == 1 && kn_pxw == 0 && kn_nbt == 0 && knob(K_TILE_RULE)) {
@@ -958,18 +936,6 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         }
     }
     if (!fit) { if (err) *err = "conv3: patch does not fit the staging budget"; return -1; }
-    // knob CONV3_NW8 (round-5 experiment): where the rule settled on 512-pixel x 64-cout tiles and the map still gives >= knob items of
-    // 1024 pixels, run 8-wave blocks (one per CU) that share one weight slab over 1024 pixels
-    if (knob(K_CONV3_NW8) > 0 && G == 1 && T == 9 && S == 1 && NC8 == 2 && !p.q8 && !p.mx && PXW == 4 && !(io.head_w && io.head_outs) && a.Wo >= 32 && a.Ho >= 32) {
-        const int keepNB = NB; const long long keepBlocks = blocks;
-        NWsel = 8;
-        if (geom(4) && blocks * ((p.lCout + 32 * NBT - 1) / (32 * NBT)) >= knob(K_CONV3_NW8)) {
-            // keep NWsel = 8
-        } else {
-            NWsel = 4; geom(4);
-            (void)keepNB; (void)keepBlocks;
-        }
-    }
     // 1x1 convs (plain GEMMs): a 128-cout block halves the A traffic per MAC (the A tile has no tap reuse to amortise it)
     if (T == 1 && NC8 == 4 && G == 1 && p.lCout % 128 == 0 && ((blocks * (p.lCout / 128) >= 384 && kn_nbt == 0) || kn_nbt == 4)) NBT = 4;
     // (1x1 / linear layers on >= 1024 pixels: below one item per CU; MuseTalk's 640-channel projections on 4096 tokens are 10 %
@@ -1011,13 +977,12 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         return -1;
     }
     k3_kernel_t k = p.mx ? k3_pick_mx(NBT, PXW) : p.q8 ? k3_pick_q8(NBT, PXW, NC8) : (S == 2) ? k3_pick_s2(NBT, NC8) : k3_pick(G, NBT, PXW, NC8, T);
-    if (NWsel == 8) k = NBT == 2 ? (k3_kernel_t)conv3_kernel_w8<2> : (k3_kernel_t)conv3_kernel_w8<1>;
     if (!k) { if (err) *err = "conv3: no kernel instantiation"; return -1; }
     const long long nblk = blocks * a.n_ntiles * ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffll) { if (err) *err = "bad grid"; return -1; }
     HIPCHK3((hipError_t)ensure_dyn_lds((const void*)k, 160 * 1024));
     a.nitems = (int)nblk;
-    const int persist_blocks = NWsel == 8 ? std::max(1, knob(K_CONV_PERSIST) / 2) : knob(K_CONV_PERSIST);      // 0: one block per item
+    const int persist_blocks = knob(K_CONV_PERSIST);      // 0: one block per item
     const long long grid = (persist_blocks > 0 && nblk > persist_blocks) ? persist_blocks : nblk;
     if (head) {
         typedef void (*k3_head_t)(const K3Args, const HeadArgs);
@@ -1030,7 +995,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         HIPCHK3(hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NWsel * 64), lds, stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, stream, a);
     HIPCHK3(hipGetLastError());
     if (ksplit > 1) {
         const long long items = a.Mtot * (p.lCout >> 3);

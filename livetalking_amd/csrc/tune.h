@@ -59,8 +59,6 @@ enum Knob {
                           //                    N+1 will ask for (bank frames index+B ..) runs beside it on a third stream into the other set of concat buffers; call
                           //                    N+1 then starts at the decoder.  Every layer still runs once per frame and step; a call that does not continue the
                           //                    sequence runs the whole pass.  0: every call runs the whole pass (rounds 1-4)
-    K_CONV3_NW8,          // LTK_CONV3_NW8      > 0 (round-5 experiment, default 0): 3x3 stride-1 fp16 layers whose rule tile is 512 px x 64 / 32 couts run as
-                          //                    8-wave blocks of 1024 px (one block per CU, one weight slab per 1024 pixels) when that still gives this many items
     K_COUNT
 };
 
