@@ -277,11 +277,17 @@ def run_wav2lip(args, ranks: Ranks):
         eng.mel_step(audio[off: off + n_chunks * 320], starts, d_mel[s].data_ptr())
     drv = SessionThreads(sessions, [d_mel[s] for s in range(S)], stride=7)
 
-    for i in range(args.warmup):
+    # untimed priming in front of the W warm-up steps: a frame count's pass is captured as a hipGraph the SECOND time each of its
+    # launch variants is seen (knob PREFETCH has three per frame count), and a capture inside the timed region would be timed;
+    # the steps walk the bank in the order a session does, so that priming, warm-up and timed steps are one unbroken sequence
+    PRIME = 8
+    for i in range(PRIME):
         drv.step(i)
+    for i in range(args.warmup):
+        drv.step(PRIME + i)
     ranks.barrier()
     t0 = time.perf_counter()
-    drv.step(args.warmup, nsteps=args.steps)
+    drv.step(PRIME + args.warmup, nsteps=args.steps)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0                     # this rank's own time (reported per rank)
     ranks.barrier()
@@ -297,7 +303,7 @@ def run_wav2lip(args, ranks: Ranks):
         n_sus = max(args.steps, int(args.sustain / max(elapsed_max / args.steps, 1e-6)) + 1)
         ranks.barrier()
         ts = time.perf_counter()
-        drv.step(args.warmup + args.steps, nsteps=n_sus)
+        drv.step(PRIME + args.warmup + args.steps, nsteps=n_sus)
         torch.cuda.synchronize()
         ranks.barrier()
         sus_max, _ = ranks.gather_max(time.perf_counter() - ts)
@@ -305,7 +311,7 @@ def run_wav2lip(args, ranks: Ranks):
                      "seconds": round(sus_max, 3), "ms_per_step": round(sus_max / n_sus * 1e3, 4),
                      "note": "same loop as the timed region, run for >= --sustain seconds directly behind it; not `value`"}
 
-    paced = paced_sessions(drv, args.warmup + args.steps, args.paced, B) if args.paced > 0 else None
+    paced = paced_sessions(drv, PRIME + args.warmup + args.steps + 4096, args.paced, B) if args.paced > 0 else None
     sched = dict(sessions[0]._sched.stats)
     # PCIe-inclusive rate of one session (outside the timed region): mel windows start on the HOST (the reference's ASR hands
     # numpy arrays over, mel.py:34-67) and every frame comes back composited into its full frame as a host array, as
@@ -432,11 +438,17 @@ def run_musetalk(args, ranks: Ranks, shared=None):
         sessions.append(plugin.MuseReal(ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=s), model, avatar))
     d_feat = torch.from_numpy(synth.musetalk_whisper_feats(fps_step)).cuda().reshape(S, B, 50, 384)
     drv = SessionThreads(sessions, [d_feat[s] for s in range(S)], stride=3)
-    for i in range(args.warmup):
+    # untimed priming in front of the W warm-up steps: a frame count's pass is captured as a hipGraph the SECOND time each of its
+    # launch variants is seen (knob PREFETCH has three per frame count), and a capture inside the timed region would be timed;
+    # the steps walk the bank in the order a session does, so that priming, warm-up and timed steps are one unbroken sequence
+    PRIME = 3
+    for i in range(PRIME):
         drv.step(i)
+    for i in range(args.warmup):
+        drv.step(PRIME + i)
     ranks.barrier()
     t0 = time.perf_counter()
-    drv.step(args.warmup, nsteps=args.steps)
+    drv.step(PRIME + args.warmup, nsteps=args.steps)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0
     ranks.barrier()
@@ -1032,7 +1044,7 @@ def main():
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
             out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
-            out["delivered_face_cache"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--delivered-sessions", "512,576,640",
+            out["delivered_face_cache"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--delivered-sessions", "512,576",
                                                                          "--delivered-formats", "bgr24"], env={"LTK_FACE_CACHE": "1"})
             w16 = also[0] if isinstance(also[0], dict) else {}
             out["sessions_25fps"] = {"per_gpu_delivered": (out["delivered"].get("bgr24") or {}).get("max_sessions_25fps_delivered"),

@@ -294,7 +294,10 @@ struct ltk_engine {
     f16* alt[B_COUNT] = {nullptr};
     int alt_frames = 0;
     hipStream_t aux2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_pf_done = nullptr, ev_main[2] = {nullptr, nullptr};   // prefetch finished / a pass finished (alternating)
+    bool pf_outstanding = false;
+    unsigned long pass_seq = 0;
+    std::shared_ptr<Avatar> pf_hold;  // the bank the outstanding prefetch reads
     DevTables* d_tab_next = nullptr;  // faces table of the prefetched frames
     struct Prefetched { int avatar = -1, first = -1, nf = 0, parity = 0; unsigned epoch = 0; bool valid = false; } pf;
     struct LastSolo { int avatar = -1, first = -1, nf = 0; } last_solo;
@@ -915,8 +918,9 @@ int ltk_engine_create(int device, ltk_engine** out) {
     CHK(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
     CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&e->ev_pf_done, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&e->ev_main[0], hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&e->ev_main[1], hipEventDisableTiming));
     e->partial_cap = (size_t)128 << 20;
     e->partial_aux_cap = (size_t)16 << 20;
     e->partial_pf_cap = (size_t)64 << 20;
@@ -961,8 +965,9 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_partial_pf) (void)hipFree(e->d_partial_pf);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
-    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+    if (e->ev_pf_done) (void)hipEventDestroy(e->ev_pf_done);
+    if (e->ev_main[0]) (void)hipEventDestroy(e->ev_main[0]);
+    if (e->ev_main[1]) (void)hipEventDestroy(e->ev_main[1]);
     if (e->aux2) (void)hipStreamDestroy(e->aux2);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->compute) (void)hipStreamDestroy(e->compute);
@@ -1100,42 +1105,28 @@ static FeatGeom feat_geom(ltk_engine* e) {
 // does not run, one copy launch puts its eight outputs where it would have written them.
 // Knob PREFETCH (see tune.h): `par` = the concat-buffer set this call's decoder works in; `have_feats` = the face encoder's
 // outputs for this call's frames are already there (the previous call prefetched them): the pass starts at the audio encoder /
-// decoder; `prefetch` = the face encoder of the NEXT call's frames (bank crops in e->d_tab_next) runs beside this pass on the
-// third stream into the other set.  The branch joins the compute stream at the end, so one event / one graph covers both.
+// decoder.
 static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool fused, bool have_outs,
-                        float* d_pred_f32, bool cached = false, int par = 0, bool have_feats = false, bool prefetch = false) {
+                        float* d_pred_f32, bool cached = false, int par = 0, bool have_feats = false) {
     const FacePtrs* d_faces = &e->d_tab->faces;
     const OutPtrs* d_outs = &e->d_tab->outs;
     const bool pack_fused = bank_faces && e->c7 && knob(K_CONV7);     // the first layer reads the bank crops itself
-    int rc = 0;
-    if (prefetch) {
-        // the branch goes out FIRST: it then runs beside this call's latency-bound head (audio encoder, small-map decoder layers),
-        // where the chip is nearly idle, not beside the big decoder layers (measured: issued behind the pass, the graph started
-        // it ~390 us into the pass and it slowed the 32^2 / 64^2 decoder layers by 1.5-2x)
-        CHK(hipEventRecord(e->ev_fork2, s));
-        CHK(hipStreamWaitEvent(e->aux2, e->ev_fork2, 0));
-        rc = run_convs(e, nf, e->aux2, nullptr, nullptr, &e->d_tab_next->faces, 1, par ^ 1, true);
-        if (rc) return rc;
-        CHK(hipEventRecord(e->ev_join2, e->aux2));
-    }
     if (cached) launch_feat_copy(d_faces, nf, feat_geom(e), 0, s);
     else if (have_feats) {}
     else if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
     launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);
-    rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, (pack_fused && !cached && !have_feats) ? d_faces : nullptr,
-                   (cached || have_feats) ? 2 : 0, par);
+    const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, (pack_fused && !cached && !have_feats) ? d_faces : nullptr,
+                             (cached || have_feats) ? 2 : 0, par);
     if (rc) return rc;
     if (!fused) {
         launch_head(e->buf[B_OUT32], 32, nf, e->d_head, e->d_head + 96, have_outs ? d_outs : nullptr, d_pred_f32, s);
         CHK(hipGetLastError());
     }
-    if (prefetch) CHK(hipStreamWaitEvent(s, e->ev_join2, 0));
     return 0;
 }
 
 constexpr size_t kMaxPassGraphs = 48;
-
 
 // enqueue_pass, replayed from a captured hipGraph where the pass has no per-call arguments: the product configuration (bank crops
 // in, fused head out) on the engine's own streams.  A frame count runs eagerly the first time it is seen (which also sets every
@@ -1143,7 +1134,7 @@ constexpr size_t kMaxPassGraphs = 48;
 // graph (profiles/r03_ubench_launch_chain.txt), and the host issues one launch instead of ~70.  The audio-encoder branch on the aux
 // stream becomes a branch of the graph (its fork / join events are captured as dependencies).
 static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32,
-                       bool cached = false, int par = 0, bool have_feats = false, bool prefetch = false) {
+                       bool cached = false, int par = 0, bool have_feats = false) {
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
     const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
     // knob GRAPH: 0 never, non-zero (default 1) every eligible pass.  Measured (profiles/r04_vs_r03_same_job.txt, r04_graph_auto_ab.txt): the replay of a
@@ -1154,19 +1145,19 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     const bool graphable = knob(K_GRAPH) && bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
     if (!graphable) {
         const bool product = bank_faces && fused && e->c7 && knob(K_CONV7) && s == e->compute;
-        if ((par || have_feats || prefetch) && !product) return fail(LTK_E_STATE, "pipelined pass outside the product configuration");
-        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached && bank_faces, par, have_feats, prefetch);
+        if ((par || have_feats) && !product) return fail(LTK_E_STATE, "pipelined pass outside the product configuration");
+        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached && bank_faces, par, have_feats);
     }
     if (e->graph_epoch != knob_epoch()) {           // a knob changed (tests, tuners): the captured launch sequences are stale
         CHK(hipStreamSynchronize(s));
         drop_graphs(e);
         e->graph_epoch = knob_epoch();
     }
-    // the cached pass and the four pipelined variants of a frame count are different launch sequences
-    ltk_engine::PassGraph& g = e->graphs[nf | (cached ? (1 << 20) : 0) | (par << 21) | (have_feats ? (1 << 22) : 0) | (prefetch ? (1 << 23) : 0)];
+    // the cached pass and the pipelined variants of a frame count are different launch sequences
+    ltk_engine::PassGraph& g = e->graphs[nf | (cached ? (1 << 20) : 0) | (par << 21) | (have_feats ? (1 << 22) : 0)];
     g.stamp = ++e->graph_clock;
     if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); return 0; }
-    if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats, prefetch);
+    if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats);
     size_t live = 0;
     for (auto& kv : e->graphs) live += kv.second.exec ? 1 : 0;
     if (live >= kMaxPassGraphs) {                       // least recently used out
@@ -1180,7 +1171,7 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     }
     hipGraph_t graph = nullptr;
     CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats, prefetch);
+    const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats);
     const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
     if (rc) {
         // enqueue_pass failed mid-capture (possibly with the aux stream forked and never joined: EndCapture then reports an
@@ -1200,10 +1191,52 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
         (void)hipGetLastError();
         g.seen = -1;
         fprintf(stderr, "ltk: hipGraph capture of the %d-frame pass failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
-        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats, prefetch);
+        return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats);
     }
     g.exec = exec;
     CHK(hipGraphLaunch(exec, s));
+    return 0;
+}
+
+// Knob PREFETCH: the face encoder of the frames the session's NEXT call will ask for (bank crops in e->d_tab_next), on the third
+// stream, into concat-buffer set `par_target` - its own launch sequence and its own graph, issued BEHIND the call's pass (whose
+// launches reach the GPU first: a graph's nodes go out a few microseconds apiece, and the call's latency-bound head runs at that
+// pace).  Ordering: it starts behind the previous prefetch (stream order) and behind the pass that last READ the target set
+// (ev_main[prev]; in the call flow that pass has completed on the host already, ltk_wav2lip_time_convs issues passes back to back);
+// whoever uses the arena next waits for ev_pf_done (wait_prefetch).
+static int wait_prefetch(ltk_engine* e) {
+    if (e->pf_outstanding) { CHK(hipStreamWaitEvent(e->compute, e->ev_pf_done, 0)); e->pf_outstanding = false; }
+    return 0;
+}
+
+static int launch_prefetch(ltk_engine* e, int nf, int par_target, hipEvent_t reader_done) {
+    hipStream_t s = e->aux2;
+    if (reader_done) CHK(hipStreamWaitEvent(s, reader_done, 0));
+    auto enq = [&]() -> int { return run_convs(e, nf, s, nullptr, nullptr, &e->d_tab_next->faces, 1, par_target, true); };
+    int rc = 0;
+    if (!knob(K_GRAPH)) rc = enq();
+    else {
+        ltk_engine::PassGraph& g = e->graphs[nf | (par_target << 21) | (1 << 24)];
+        g.stamp = ++e->graph_clock;
+        if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); }
+        else if (g.seen < 0 || g.seen++ == 0) rc = enq();
+        else {
+            hipGraph_t graph = nullptr;
+            CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            rc = enq();
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (rc) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
+            hipGraphExec_t exec = nullptr;
+            hipError_t ie = ce;
+            if (ce == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess || !exec) { (void)hipGetLastError(); g.seen = -1; rc = enq(); }
+            else { g.exec = exec; CHK(hipGraphLaunch(exec, s)); }
+        }
+    }
+    if (rc) return rc;
+    CHK(hipEventRecord(e->ev_pf_done, s));
+    e->pf_outstanding = true;
     return 0;
 }
 
@@ -1322,24 +1355,30 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         const int par = hit ? e->pf.parity : 0;
         e->pf.valid = false;                    // whatever this call does, it overwrites the set the old prefetch went to or consumes it
         if (solo) { if (hit) ++e->pf_hits; else ++e->pf_misses; }
-        if (prefetch) {
-            FacePtrs nx;
-            const Avatar& a = *hold[0];
-            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
-            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->compute);
-            ++e->pf_issued;
-        }
+        if ((rc = wait_prefetch(e))) return rc;          // a hit needs its data; everything else needs the buffers it was writing
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
             for (int i = 0; i < nf; ++i) { fp.p[i] = fptr[f0 + i]; mp.p[i] = mptr[f0 + i]; op.p[i] = optr[f0 + i]; }
-            launch_upload_tables(&fp, &mp, &op, nf, e->d_tab, e->compute);
+            launch_upload_tables(hit ? nullptr : &fp, &mp, &op, nf, e->d_tab, e->compute);       // a hit does not read its own bank crops
             if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "pointer table upload failed");
-            else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached, par, hit, prefetch);
+            else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached, par, hit);
         }
+        const unsigned long seq = e->pass_seq++;
+        if (!rc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
         if (!rc && prefetch) {
-            e->pf.valid = true; e->pf.avatar = reqs[0].avatar; e->pf.first = first + total; e->pf.nf = total; e->pf.parity = par ^ 1;
-            e->pf.epoch = knob_epoch();
+            // behind the pass: the next call's face encoder, on the third stream (launch_prefetch)
+            FacePtrs nx;
+            const Avatar& a = *hold[0];
+            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
+            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
+            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
+            if (!rc) {
+                ++e->pf_issued;
+                e->pf_hold = hold[0];
+                e->pf.valid = true; e->pf.avatar = reqs[0].avatar; e->pf.first = first + total; e->pf.nf = total; e->pf.parity = par ^ 1;
+                e->pf.epoch = knob_epoch();
+            }
         }
         e->last_solo = ltk_engine::LastSolo();
         if (!rc && solo) { e->last_solo.avatar = reqs[0].avatar; e->last_solo.first = first; e->last_solo.nf = total; }
@@ -1528,20 +1567,26 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     if (pipe) {
         FacePtrs nx;
         for (int i = 0; i < frames; ++i) nx.p[i] = (const uint8_t*)tio.face.p;
-        launch_upload_tables(&nx, nullptr, nullptr, frames, e->d_tab_next, e->compute);
+        launch_upload_tables(&nx, nullptr, nullptr, frames, e->d_tab_next, e->aux2);
     }
     int par = 0;
     bool primed = false;
     auto pass = [&]() -> int {
         int prc = 0;
         if (pipe) {
-            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed, true);
+            if ((prc = wait_prefetch(e))) return prc;
+            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed);
+            if (prc) return prc;
+            const unsigned long seq = e->pass_seq++;
+            CHK(hipEventRecord(e->ev_main[seq & 1], e->compute));
+            prc = launch_prefetch(e, frames, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
             par ^= 1; primed = true;
             return prc;
         }
         for (int f0 = 0; f0 < frames && !prc; f0 += mbs) prc = launch_pass(e, std::min(mbs, frames - f0), e->compute, true, nullptr, true, nullptr);
         return prc;
     };
+    if ((rc = wait_prefetch(e))) return rc;
     if (pipe) { rc = pass(); if (!rc) rc = pass(); if (!rc) rc = pass(); if (rc) return rc; }     // prime, then both parities seen once (eager)
     rc = pass();              // warm (eager)
     if (!rc) rc = pass();     // warm (captures the graph under knob GRAPH)
@@ -1613,6 +1658,7 @@ int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_
     if (n_layers != (int)e->layers.size()) return fail(LTK_E_INVALID, "n_layers != ltk_wav2lip_layer_count");
     CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
+    { const int wrc = wait_prefetch(e); if (wrc) return wrc; }
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     std::vector<hipEvent_t> evs(e->layers.size() + 1);
     for (auto& ev : evs) CHK(hipEventCreate(&ev));
