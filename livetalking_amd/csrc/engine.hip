@@ -21,7 +21,6 @@
 #include <vector>
 
 #include "../../include/ltk.h"
-#include "audio_fused.h"
 #include "conv_mfma.h"
 #include "misc_kernels.h"
 #include "musetalk.h"
@@ -126,8 +125,7 @@ const int kFeatHW[8] = {256, 128, 64, 32, 16, 8, 4, 1};
 const float kBnEps = 1e-5f;  // nn.BatchNorm2d default (conv.py:9,38)
 
 constexpr int kPrefetchMaxFrames = 32;     // knob PREFETCH: calls of at most this many frames are pipelined across calls
-enum BufId { B_MEL = 0, B_AT0, B_AT1, B_X0, B_T0, B_T1, B_OUT32, B_AT2, B_CAT0, B_COUNT = B_CAT0 + 8 };
-constexpr int kAudioFusedMaxFrames = 64;   // knob AUDIO_FUSED: one workgroup per frame pays while the launch leaves most CUs idle anyway
+enum BufId { B_MEL = 0, B_AT0, B_AT1, B_X0, B_T0, B_T1, B_OUT32, B_CAT0, B_COUNT = B_CAT0 + 8 };
 
 struct Layer {
     std::string name;
@@ -307,7 +305,6 @@ struct ltk_engine {
     size_t buf_halfs[B_COUNT] = {0};  // per frame
     float* d_head = nullptr;          // 96 weights + 3 bias
     Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
-    AudioMidPlan amid;                // audio_encoder.4 .. .8 in one launch (audio_fused.hip); its output lives in B_AT2
     double macs_per_frame = 0;
     DevTables* d_tab = nullptr;       // per-frame pointer tables of the pass being enqueued (misc_kernels.h), filled on the compute stream
     // captured passes (knob GRAPH): one executable graph per frame count of the product configuration (bank crops in, fused head out);
@@ -416,11 +413,7 @@ const float* find_tensor(const ltk_named_tensor* sd, int n, const std::string& n
 // k x k map to 1x1 (face_encoder_blocks.7.0) is run as a 1x1 conv over the map viewed as ONE pixel of
 // k*k*cin channels (a channel-blocked k x k map is contiguous per channel block).
 // `map_w` > 0: the input map is map_w x map_w (face encoder / decoder): 3x3 layers whose OUTPUT map is at most 8 x 8 also get a rowconv plan.
-// `keep` (optional): receives the layer's fp32 weights as they are packed (identity folded into the centre tap where that applies)
-// and its folded BatchNorm scale / shift: audio_mid_pack builds its own pack from the same numbers
-struct KeptLayer { std::vector<float> w, sc, sf; bool folded = false; };
-int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw, int flat_ld, int map_w,
-                     KeptLayer* keep = nullptr) {
+int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw, int flat_ld, int map_w) {
     const std::string p = d.prefix;
     const size_t wcount = (size_t)d.cin * d.cout * d.k * d.k;
     const float* w = find_tensor(sd, n, p + ".conv_block.0.weight", wcount);
@@ -459,7 +452,6 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
             L->res_folded = true;
         }
     }
-    if (keep) { keep->w.assign(w, w + wcount); keep->sc = sc; keep->sf = sf; keep->folded = L->res_folded; }
     if (flat_ld > 0) {
         // channel-blocked map [n][cb][k*k][16] read as ONE pixel of cin*k*k channels: flat channel = ((cb*kk + t)*16 + c16)
         const int kk = d.k * d.k;
@@ -557,9 +549,8 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
 
 // A Layer is pushed into e->layers only after it is complete: on a failure the device plans built so far go here (a failed load
 // that is retried would otherwise leak the packed weights each time)
-int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0,
-                KeptLayer* keep = nullptr) {
-    const int rc = build_layer_impl(e, d, sd, n, L, hint_hw, flat_ld, map_w, keep);
+int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, int n, Layer* L, int hint_hw = 0, int flat_ld = 0, int map_w = 0) {
+    const int rc = build_layer_impl(e, d, sd, n, L, hint_hw, flat_ld, map_w);
     if (rc) {
         conv_plan_destroy(&L->plan); rowgemm_plan_destroy(&L->rg);
         for (RowGemmPlan& q : L->rgT) rowgemm_plan_destroy(&q);
@@ -602,7 +593,6 @@ void wav2lip_unload(ltk_engine* e) {
     if (e->d_head) { (void)hipFree(e->d_head); e->d_head = nullptr; }
     conv7_plan_destroy(e->c7);
     e->c7 = nullptr;
-    audio_mid_destroy(&e->amid);
     e->loaded = false;
 }
 
@@ -622,17 +612,13 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
     // ---- audio encoder (wav2lip_v2.py:132): MEL -> AT0/AT1 ping-pong
     {
         int H = 80, W = 16, in_buf = B_MEL, in_ld = 8, pp = 0;
-        KeptLayer kept[6];
-        int ai = 0;
         for (const LayerDef& d : kAudio) {
             Layer L;
-            KeptLayer* const keep = (ai >= 3 && ai <= 8) ? &kept[ai - 3] : nullptr;
-            ++ai;
             // audio_encoder.11: the 3x3 "valid" conv on the 3x3 map = a GEMM over the flattened map with one row per frame (K = 2304),
             // like face_encoder_blocks.7.0: rowgemm for launches of <= 32 frames (16 blocks of the first-generation kernel streamed its
             // 2.4 MB of weights in 26 us - the longest launch of the audio branch, which heads the critical path under knob PREFETCH)
             const bool flat = !d.transposed && d.pad == 0 && d.k > 1 && d.k == H && d.k == W && d.cin % 64 == 0 && !knob(K_NO_FLATTEN);
-            if ((rc = build_layer(e, d, sd, n, &L, H * W, flat ? in_ld : 0, 0, keep))) return rc;
+            if ((rc = build_layer(e, d, sd, n, &L, H * W, flat ? in_ld : 0, 0))) return rc;
             L.audio = true;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = 0; L.H = H; L.W = W;
             if (flat) { L.Ho = 1; L.Wo = 1; L.H = 1; L.W = 1; L.in_ld = d.k * d.k * in_ld; }
@@ -643,17 +629,6 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             L.macs = (double)d.cin * d.cout * d.k * d.k * L.Ho * L.Wo;
             e->layers.push_back(L);
             in_buf = L.out_buf; in_ld = d.cout; H = L.Ho; W = L.Wo; pp ^= 1;
-        }
-        // audio_encoder.4 .. .8 in one launch (audio_fused.hip): needs the residual layers' identity folded (the fused kernel has no
-        // residual read) and the geometry it is written for
-        const bool geom_ok = kAudio[3].cin == 32 && kAudio[3].cout == 64 && kAudio[3].sh == 3 && kAudio[3].sw == 1 && kAudio[6].cin == 64 &&
-                             kAudio[6].cout == 128 && kAudio[6].sh == 3 && kAudio[6].sw == 3 && kAudio[8].cout == 128;
-        if (knob(K_AUDIO_FUSED) && geom_ok && kept[1].folded && kept[2].folded && kept[4].folded && kept[5].folded) {
-            const float *w6[6], *s6[6], *f6[6];
-            for (int l = 0; l < 6; ++l) { w6[l] = kept[l].w.data(); s6[l] = kept[l].sc.data(); f6[l] = kept[l].sf.data(); }
-            std::string aerr;
-            if (audio_mid_pack(&e->amid, w6, s6, f6, &aerr)) return fail(LTK_E_HIP, aerr);
-            bh[B_AT2] = (size_t)128 * 9 * 6;
         }
     }
     const int audio_emb_buf = e->layers.back().out_buf;
@@ -792,15 +767,11 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
             if ((part == 1) == L->face_enc) kept.push_back(L);
         order.swap(kept);
     }
-    // knob AUDIO_FUSED: audio_encoder.4 .. .8 as one launch (one workgroup per frame) into B_AT2; audio_encoder.9 then reads from there.
-    // Not while layers are captured or timed one by one, not for large launches (16 frames = 16 CUs: fine beside an idle chip only)
-    const bool amid = e->amid.ready && knob(K_AUDIO_FUSED) && !e->capture && !evs && nf <= kAudioFusedMaxFrames && part != 1;
     // one layer on frames [f0, f0 + n) of the arena
     auto launch_layer = [&](Layer& L, int f0, int n, bool on_aux) -> int {
         const int bucket = frame_bucket(n);
         ConvIO io;
-        io.x = ((amid && L.name == "audio_encoder.9") ? e->buf[B_AT2] : B(L.in_buf)) + (size_t)f0 * L.in_ld * L.H * L.W;
-        io.N = n; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
+        io.x = B(L.in_buf) + (size_t)f0 * L.in_ld * L.H * L.W; io.N = n; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;
         io.y = B(L.out_buf) + (size_t)f0 * L.out_ld * L.Ho * L.Wo; io.y_ld = L.out_ld; io.y_coff = L.out_coff;
         io.res = (L.residual && !L.res_folded) ? io.x : nullptr; io.res_ld = L.in_ld; io.res_coff = L.in_coff;
         io.relu = 1;
@@ -851,13 +822,6 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
     for (size_t oi = 0; oi < df_first; ++oi) {
         Layer& L = *order[oi];
         const bool on_aux = fork && L.audio;
-        if (amid && L.audio && L.name.size() == 15 && L.name[14] >= '4' && L.name[14] <= '8') {       // "audio_encoder.4" .. ".8"
-            if (L.name[14] == '4') {
-                const int arc = audio_mid_launch(e->amid, e->buf[L.in_buf], L.in_ld * L.H * L.W, e->buf[B_AT2], 128 * 9 * 6, nf, on_aux ? e->aux : s, &err);
-                if (arc) return fail(LTK_E_HIP, err);
-            }
-            continue;
-        }
         if (!on_aux && !joined && !L.audio && L.in_buf >= B_AT0 && L.in_buf <= B_AT1 && L.name.rfind("face_decoder", 0) == 0) {
             CHK(hipEventRecord(e->ev_join, e->aux));
             CHK(hipStreamWaitEvent(s, e->ev_join, 0));

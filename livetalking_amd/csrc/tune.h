@@ -59,8 +59,6 @@ enum Knob {
                           //                    N+1 will ask for (bank frames index+B ..) runs beside it on a third stream into the other set of concat buffers; call
                           //                    N+1 then starts at the decoder.  Every layer still runs once per frame and step; a call that does not continue the
                           //                    sequence runs the whole pass.  0: every call runs the whole pass (rounds 1-4)
-    K_AUDIO_FUSED,        // LTK_AUDIO_FUSED    1 (default): audio_encoder.4 .. .8 as ONE launch, one workgroup per frame, activations in LDS (audio_fused.hip)
-                          //                    for launches of <= 64 frames; 0: six launches (rounds 1-4)
     K_COUNT
 };
 

@@ -37,7 +37,6 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_LDS_SWZ", 1},
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
-    {"LTK_AUDIO_FUSED", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -605,39 +605,3 @@ def test_prefetched_face_encoder_equals_whole_pass(golden_dir, graph):
             Engine.set_knob("GRAPH", 1)
     finally:
         eng.close()
-
-
-@pytest.mark.gpu
-def test_fused_audio_mid_encoder_vs_six_launches(engine, golden_dir):
-    """Knob AUDIO_FUSED (default on): audio_encoder.3 .. .8 (wav2lip_v2.py:45-51) as ONE launch, one workgroup per frame with the
-    activations in LDS (csrc/audio_fused.hip), against the six separate launches.  Same fp16 weights (identity folded into the
-    centre tap), same contraction order and epilogue as conv3, so the four residual layers are reproduced exactly and the two
-    strided layers differ from the first-generation kernel by fp32 summation order only: frames within 1 LSB, and both settings
-    within the usual tolerance of the reference's golden frames."""
-    from livetalking_amd.engine import Engine
-    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
-    B, index = int(g["batch"]), int(g["index"])
-    aid = engine.register_avatar(faces, frames, coords)
-    mel = torch.from_numpy(np.stack(feats).astype(np.float32)).cuda()
-
-    def run():
-        pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
-        for _ in range(2):
-            engine.wav2lip_infer([(aid, index, B, mel.data_ptr(), pred.data_ptr())])
-        return pred.cpu().numpy()
-
-    try:
-        Engine.set_knob("AUDIO_FUSED", 0)
-        six = run()
-        Engine.set_knob("AUDIO_FUSED", 1)
-        one = run()
-    finally:
-        Engine.set_knob("AUDIO_FUSED", 1)
-    d = np.abs(one.astype(np.int16) - six.astype(np.int16))
-    print(f"[audio fused vs six launches] max {int(d.max())} LSB, differing bytes {float((d != 0).mean()):.5f}")
-    assert d.max() <= 1 and float((d != 0).mean()) < 0.10
-    ref = g["ref_pred_u8"]
-    for name, got in (("fused", one), ("six", six)):
-        dr = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-        assert psnr_u8(got, ref) >= 40.0 and dr.max() <= 6, name
-    engine.release_avatar(aid)
