@@ -348,7 +348,7 @@ def run_wav2lip(args, ranks: Ranks):
     achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
     # the same pass with every call running the whole network on its own (knob PREFETCH off: rounds 1-4), for comparison
     conv_ms_whole = None
-    if pf_stats["issued"] > 0:
+    if pf_stats["issued"] > 0 and not args.no_whole_pass:
         from livetalking_amd.engine import Engine
         Engine.set_knob("PREFETCH", 0)
         try:
@@ -949,6 +949,8 @@ def main():
     ap.add_argument("--paced", type=int, default=0, help="after the timed run: N periods of B/25 s with every session paced at 25 fps")
     ap.add_argument("--sustain", type=float, default=None,
                     help="seconds of the `sustained` twin behind the timed region (default 2.0 for the primary wav2lip line, 0 = off)")
+    ap.add_argument("--no-whole-pass", action="store_true", help="skip the comparison timing with knob PREFETCH off (profiler runs: the last pass of "
+                    "the process is then a pipelined one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configs (also[]) and the paced capacity")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")

@@ -41,8 +41,8 @@ profile)
   }
   # MuseTalk twice: the weight upload of the model load shows up as ~1100 __amd_rocclr_copyBuffer / ~470 fillBufferAligned launches
   # whatever the number of passes (mt: 3 passes, mt12: 12 passes) - they are not part of a pass
-  prof w2l --steps 6 --warmup 2
-  prof w2l256 --sessions 16 --steps 3 --warmup 1
+  prof w2l --steps 6 --warmup 2 --no-whole-pass --sustain 0
+  prof w2l256 --sessions 16 --steps 3 --warmup 1 --sustain 0
   prof mt --model musetalk --steps 2 --warmup 1
   prof mtfp8 --model musetalk --fp8 --sessions 4 --steps 2 --warmup 1
   want mt12 && timeout 400 rocprofv3 --kernel-trace --stats -d $P/mt12_trace -o r -- python $R/bench.py --model musetalk --steps 11 --warmup 1 --no-cpu-baseline > $P/mt12_trace.log 2>&1
