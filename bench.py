@@ -846,7 +846,7 @@ def measure_traffic(sub, extra, passes, conv_only):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
-    tot = {}
+    tot, heads = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ltk_pmc_")
         cmd = [exe, "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--sub", sub,
@@ -863,9 +863,11 @@ def measure_traffic(sub, extra, passes, conv_only):
         if "counters_collection" not in names:
             return None, "no counters_collection view in the rocprofv3 database"
         v = 0.0
-        for k, c, val in db.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+        for k, c, val, cnt in db.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"):
             if c != counter:
                 continue
+            if "head_kernel" in k:
+                heads[counter] = heads.get(counter, 0) + int(cnt)       # one fused-head launch per Wav2Lip pass: the pass count of the run
             if conv_only and "conv" not in k and "rowgemm" not in k:       # conv7 / conv3 / conv_mfma / rowconv + rowgemm: the layer kernels
                 continue
             if not conv_only and ("__amd_rocclr" in k or "debug" in k):
@@ -873,7 +875,11 @@ def measure_traffic(sub, extra, passes, conv_only):
             v += float(val)
         tot[counter] = v
         shutil.rmtree(d, ignore_errors=True)
-    n = passes + (2 if sub == "convpasses" else 1)        # warm passes of the profiled body (sub_convpasses / sub_mtpasses)
+    # passes of the profiled body: counted from the trace for Wav2Lip (ltk_wav2lip_time_convs runs 2 warm passes, 5 under knob PREFETCH;
+    # one fused-head dispatch each), `passes` + the two warm runs of ltk_musetalk_time for MuseTalk
+    n = passes + 2
+    if sub == "convpasses" and heads.get("FETCH_SIZE"):
+        n = heads["FETCH_SIZE"]
     rd = tot["FETCH_SIZE"] * 1024.0 * 2.0 / n
     wr = tot["WRITE_SIZE"] * 1024.0 / n
     return rd + wr, {"read_bytes": rd, "write_bytes": wr, "passes_profiled": n,
@@ -899,8 +905,9 @@ def sub_mtpasses(args):
     from livetalking_amd.engine import Engine
     nt = min(args.sessions * args.batch, 64)
     eng = Engine(0)
+    Engine.set_knob("GRAPH", 0)             # counters per kernel dispatch: the same launches, issued one by one
     eng.load_musetalk(synth.musetalk_unet_state_dict(), synth.vae_decoder_state_dict(), max_frames=nt, fp8=args.fp8)
-    eng.musetalk_time(nt, args.steps)       # = 1 warm pass + `steps` passes
+    eng.musetalk_time(nt, args.steps)       # = 2 warm passes + `steps` passes
     eng.close()
 
 

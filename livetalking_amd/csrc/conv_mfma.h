@@ -160,6 +160,7 @@ struct RowConvIO {
     f16* y = nullptr; int y_ld = 0, y_coff = 0, Ho = 0, Wo = 0;
     const f16* res = nullptr; int res_ld = 0, res_coff = 0;              // residual with the output's geometry, or nullptr
     int N = 0, KW = 3, stride = 1, pad = 1, relu = 1;
+    int stride_w = 0;                                                    // column stride when it differs from `stride` (0 = the same)
 };
 int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream, std::string* err);
 // ConvTranspose2d(k3, s2, p1, op1) on a source map of <= 8 x 8 pixels: four per-phase plans p[py * 2 + px] over

@@ -14,7 +14,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -133,7 +135,7 @@ struct Layer {
     RowGemmPlan rg;                 // set for the layers whose input and output maps are one pixel per frame (rowgemm.hip)
     int rg_y_ld = 0;               // output row pitch of that GEMM (the 1x1-expand layer writes k*k*Cout contiguous channels)
     bool rowconv = false;          // `rg` is a rowconv plan instead: 3x3 conv on a map of <= 8 x 8 output pixels (rowgemm.hip)
-    int rc_stride = 1;
+    int rc_stride = 1, rc_stride_w = 0;
     RowGemmPlan rgT[4];            // ConvTranspose2d(k3,s2,p1,op1) on a source map of <= 8 x 8 pixels: one plan per output phase (rowconvT_launch)
     int cin_real = 0;
     int in_buf = 0, in_ld = 0, in_coff = 0, H = 0, W = 0;
@@ -298,6 +300,16 @@ struct ltk_engine {
     bool pf_outstanding = false;
     unsigned long pass_seq = 0;
     std::shared_ptr<Avatar> pf_hold;  // the bank the outstanding prefetch reads
+    // knob PREFETCH_THREAD: helper thread that replays the prefetch graph on aux2 while the caller launches the pass's own graph
+    struct PfWorker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        bool stop = false, has_job = false, busy = false;
+        hipGraphExec_t exec = nullptr;
+        hipEvent_t wait_ev = nullptr;
+        int rc = 0;
+    } pfw;
     DevTables* d_tab_next = nullptr;  // faces table of the prefetched frames
     struct Prefetched { int avatar = -1, first = -1, nf = 0, parity = 0; unsigned epoch = 0; bool valid = false; } pf;
     struct LastSolo { int avatar = -1, first = -1, nf = 0; } last_solo;
@@ -503,8 +515,11 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
             rc = rowgemm_plan_create(&L->rg, we.data(), J, K, se.data(), fe.data(), &err);
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rg_y_ld = (d.transposed ? J : 0);
-        } else if (want_rowconv && flat_ld == 0 && map_w > 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) &&
-                   map_w % d.sh == 0 && map_w / d.sh <= 8 && (d.cin == 256 || d.cin == 512) && d.cout % 256 == 0) {
+        } else if (want_rowconv && flat_ld == 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.cout % 256 == 0 &&
+                   ((map_w > 0 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && map_w % d.sh == 0 && map_w / d.sh <= 8 && (d.cin == 256 || d.cin == 512)) ||
+                    // round 5: the audio encoder's last two 3 x 3 layers (audio_encoder.9: 128 -> 256, stride (3, 2), 9 x 6 -> 3 x 3; .10: 256 -> 256 on
+                    // 3 x 3): 144 output pixels per 16-frame launch behind 0.6 / 1.2 MB of weights (map_w < 0: the caller vouches for a small map)
+                    (map_w < 0 && d.cin % 32 == 0))) {
             // 3x3 conv whose output map is at most 8 x 8: W_eff[j][tap * Cin + c], tap = ky * 3 + kx (`w` carries the folded identity
             // of a residual layer, exactly as the conv3 plan above does)
             J = d.cout; K = 9 * d.cin;
@@ -516,6 +531,7 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rowconv = true;
             L->rc_stride = d.sh;
+            L->rc_stride_w = d.sw;
         } else if (want_rowconv && map_w > 0 && map_w <= 8 && d.transposed && d.k == 3 && d.sh == 2 && d.sw == 2 && d.pad == 1 && d.out_pad == 1 &&
                    (d.cin == 256 || d.cin == 512 || d.cin == 1024) && d.cout % 256 == 0) {
             // stride-2 transposed conv on the 4x4 / 8x8 maps: output pixel (2y + py, 2x + px) = sum over (dy, dx) of x[y + dy][x + dx] * w[:, :, ky, kx]
@@ -618,7 +634,9 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             // like face_encoder_blocks.7.0: rowgemm for launches of <= 32 frames (16 blocks of the first-generation kernel streamed its
             // 2.4 MB of weights in 26 us - the longest launch of the audio branch, which heads the critical path under knob PREFETCH)
             const bool flat = !d.transposed && d.pad == 0 && d.k > 1 && d.k == H && d.k == W && d.cin % 64 == 0 && !knob(K_NO_FLATTEN);
-            if ((rc = build_layer(e, d, sd, n, &L, H * W, flat ? in_ld : 0, 0))) return rc;
+            const int oh = (H + 2 * d.pad - d.k) / d.sh + 1, ow = (W + 2 * d.pad - d.k) / d.sw + 1;
+            const bool small = !flat && d.k == 3 && d.pad == 1 && oh * ow <= 16;             // audio_encoder.9 / .10: rowconv (build_layer)
+            if ((rc = build_layer(e, d, sd, n, &L, H * W, flat ? in_ld : 0, small ? -1 : 0))) return rc;
             L.audio = true;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = 0; L.H = H; L.W = W;
             if (flat) { L.Ho = 1; L.Wo = 1; L.H = 1; L.W = 1; L.in_ld = d.k * d.k * in_ld; }
@@ -785,13 +803,14 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
                               B(B_X0) + (size_t)f0 * 65536 * 8, n, io.y, L.out_ld, L.out_coff, s, &err);
         // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
         // output element whatever the launch's frame count (larger launches run these layers on conv3)
-        else if (L.rowconv && L.rg.d_w && (long long)n * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK)) {
+        else if (L.rowconv && L.rg.d_w && (long long)n * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK) &&
+                 (!L.audio || knob(K_AUDIO_ROWCONV))) {
             // 3x3 layers on the 4x4 / 8x8 maps: the same weight-streaming GEMM over gathered im2col rows (same LTK_SPLITK=0 rule)
             RowConvIO rio;
             rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;
             rio.y = io.y; rio.y_ld = L.out_ld; rio.y_coff = L.out_coff; rio.Ho = L.Ho; rio.Wo = L.Wo;
             rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
-            rio.N = n; rio.KW = 3; rio.stride = L.rc_stride; rio.pad = 1; rio.relu = 1;
+            rio.N = n; rio.KW = 3; rio.stride = L.rc_stride; rio.stride_w = L.rc_stride_w; rio.pad = 1; rio.relu = 1;
             rc = rowconv_launch(L.rg, rio, on_aux ? e->aux : s, &err);
         } else if (L.rgT[0].d_w && (long long)n * L.H * L.W <= std::min(knob(K_ROWCONVT), kRowConvMaxRows) && knob(K_ROWCONV) > 0 && knob(K_SPLITK)) {
             // stride-2 transposed convs on the 4x4 / 8x8 maps: four per-phase weight-streaming GEMMs in one launch (no split-K finish)
@@ -938,8 +957,11 @@ int ltk_engine_create(int device, ltk_engine** out) {
     return LTK_OK;
 }
 
+static void pf_worker_stop(ltk_engine* e);
+
 void ltk_engine_destroy(ltk_engine* e) {
     if (!e) return;
+    pf_worker_stop(e);
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     wav2lip_unload(e);
@@ -1204,6 +1226,70 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
 // pace).  Ordering: it starts behind the previous prefetch (stream order) and behind the pass that last READ the target set
 // (ev_main[prev]; in the call flow that pass has completed on the host already, ltk_wav2lip_time_convs issues passes back to back);
 // whoever uses the arena next waits for ev_pf_done (wait_prefetch).
+static void pf_worker_main(ltk_engine* e) {
+    (void)hipSetDevice(e->device);
+    ltk_engine::PfWorker& w = e->pfw;
+    std::unique_lock<std::mutex> lk(w.m);
+    for (;;) {
+        w.cv.wait(lk, [&] { return w.stop || w.has_job; });
+        if (w.stop) return;
+        w.has_job = false;
+        hipGraphExec_t exec = w.exec;
+        hipEvent_t wait_ev = w.wait_ev;
+        lk.unlock();
+        int rc = 0;
+        hipError_t he = hipSuccess;
+        const char* what = "";
+        if (wait_ev && (he = hipStreamWaitEvent(e->aux2, wait_ev, 0)) != hipSuccess) { rc = -2; what = "hipStreamWaitEvent"; }
+        if (!rc && (he = hipGraphLaunch(exec, e->aux2)) != hipSuccess) { rc = -2; what = "hipGraphLaunch"; }
+        if (!rc && (he = hipEventRecord(e->ev_pf_done, e->aux2)) != hipSuccess) { rc = -2; what = "hipEventRecord"; }
+        if (rc) { (void)hipGetLastError(); fprintf(stderr, "ltk: prefetch helper: %s failed (%s)\n", what, hipGetErrorString(he)); }
+        lk.lock();
+        w.rc = rc;
+        w.busy = false;
+        w.cv.notify_all();
+    }
+}
+
+// hands a replay of `exec` on aux2 to the helper thread (started on first use); pf_worker_join waits for the launch calls to have returned
+static void pf_worker_post(ltk_engine* e, hipGraphExec_t exec, hipEvent_t wait_ev) {
+    ltk_engine::PfWorker& w = e->pfw;
+    std::lock_guard<std::mutex> g(w.m);
+    if (!w.th.joinable()) w.th = std::thread(pf_worker_main, e);
+    w.exec = exec; w.wait_ev = wait_ev; w.has_job = true; w.busy = true; w.rc = 0;
+    w.cv.notify_all();
+}
+
+static int pf_worker_join(ltk_engine* e) {
+    ltk_engine::PfWorker& w = e->pfw;
+    std::unique_lock<std::mutex> lk(w.m);
+    w.cv.wait(lk, [&] { return !w.busy; });
+    return w.rc;
+}
+
+static void pf_worker_stop(ltk_engine* e) {
+    ltk_engine::PfWorker& w = e->pfw;
+    {
+        std::lock_guard<std::mutex> g(w.m);
+        w.stop = true;
+        w.cv.notify_all();
+    }
+    if (w.th.joinable()) w.th.join();
+}
+
+// the replayable prefetch graph of (nf, target set) - or null: not captured yet, knob GRAPH off, knobs changed since, or the pass it
+// runs beside (`pass_key`) is not a pure replay itself (while the calling thread captures a pass, its streams are in capture mode and
+// another thread's event / launch calls fail with "dependency created on uncaptured work in another stream")
+static hipGraphExec_t prefetch_exec(ltk_engine* e, int nf, int par_target, int pass_key) {
+    if (!knob(K_GRAPH) || !knob(K_PREFETCH_THREAD) || e->graph_epoch != knob_epoch()) return nullptr;
+    auto mp = e->graphs.find(pass_key);
+    if (mp == e->graphs.end() || !mp->second.exec) return nullptr;
+    auto it = e->graphs.find(nf | (par_target << 21) | (1 << 24));
+    if (it == e->graphs.end() || !it->second.exec) return nullptr;
+    it->second.stamp = ++e->graph_clock;
+    return it->second.exec;
+}
+
 static int wait_prefetch(ltk_engine* e) {
     if (e->pf_outstanding) { CHK(hipStreamWaitEvent(e->compute, e->ev_pf_done, 0)); e->pf_outstanding = false; }
     return 0;
@@ -1356,6 +1442,21 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         e->pf.valid = false;                    // whatever this call does, it overwrites the set the old prefetch went to or consumes it
         if (solo) { if (hit) ++e->pf_hits; else ++e->pf_misses; }
         if ((rc = wait_prefetch(e))) return rc;          // a hit needs its data; everything else needs the buffers it was writing
+        // knob PREFETCH_THREAD: the next call's face encoder is handed to the helper thread BEFORE this call's pass is launched, so that
+        // the two graphs are submitted side by side (steady state: both are captured; anything else goes the serial way below)
+        const unsigned long seq = e->pass_seq++;
+        hipGraphExec_t pf_exec = nullptr;
+        if (prefetch) {
+            FacePtrs nx;
+            const Avatar& a = *hold[0];
+            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
+            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
+            pf_exec = (total <= mbs) ? prefetch_exec(e, total, par ^ 1, total | (par << 21) | (hit ? (1 << 22) : 0)) : nullptr;
+            if (pf_exec) {
+                if (seq > 0) CHK(hipStreamWaitEvent(e->aux2, e->ev_main[(seq - 1) & 1], 0));
+                pf_worker_post(e, pf_exec, nullptr);
+            }
+        }
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
@@ -1364,21 +1465,19 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "pointer table upload failed");
             else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached, par, hit);
         }
-        const unsigned long seq = e->pass_seq++;
         if (!rc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
+        if (pf_exec) {
+            const int wrc = pf_worker_join(e);           // its launch calls have returned: ev_pf_done is recorded
+            if (wrc) { if (!rc) rc = fail(LTK_E_HIP, "prefetch launch failed"); }
+            else e->pf_outstanding = true;
+        } else if (!rc && prefetch) {
+            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);     // eager / capturing: behind the pass
+        }
         if (!rc && prefetch) {
-            // behind the pass: the next call's face encoder, on the third stream (launch_prefetch)
-            FacePtrs nx;
-            const Avatar& a = *hold[0];
-            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
-            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
-            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
-            if (!rc) {
-                ++e->pf_issued;
-                e->pf_hold = hold[0];
-                e->pf.valid = true; e->pf.avatar = reqs[0].avatar; e->pf.first = first + total; e->pf.nf = total; e->pf.parity = par ^ 1;
-                e->pf.epoch = knob_epoch();
-            }
+            ++e->pf_issued;
+            e->pf_hold = hold[0];
+            e->pf.valid = true; e->pf.avatar = reqs[0].avatar; e->pf.first = first + total; e->pf.nf = total; e->pf.parity = par ^ 1;
+            e->pf.epoch = knob_epoch();
         }
         e->last_solo = ltk_engine::LastSolo();
         if (!rc && solo) { e->last_solo.avatar = reqs[0].avatar; e->last_solo.first = first; e->last_solo.nf = total; }
@@ -1575,11 +1674,17 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
         int prc = 0;
         if (pipe) {
             if ((prc = wait_prefetch(e))) return prc;
-            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed);
-            if (prc) return prc;
             const unsigned long seq = e->pass_seq++;
-            CHK(hipEventRecord(e->ev_main[seq & 1], e->compute));
-            prc = launch_prefetch(e, frames, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
+            hipEvent_t prev = seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr;
+            hipGraphExec_t pf_exec = prefetch_exec(e, frames, par ^ 1, frames | (par << 21) | (primed ? (1 << 22) : 0));
+            if (pf_exec) {
+                if (prev) CHK(hipStreamWaitEvent(e->aux2, prev, 0));
+                pf_worker_post(e, pf_exec, nullptr);
+            }
+            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed);
+            if (!prc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) prc = fail(LTK_E_HIP, "hipEventRecord(ev_main) failed");
+            if (pf_exec) { const int wrc = pf_worker_join(e); if (wrc && !prc) prc = fail(LTK_E_HIP, "prefetch helper launch failed"); if (!wrc) e->pf_outstanding = true; }
+            else if (!prc) prc = launch_prefetch(e, frames, par ^ 1, prev);
             par ^= 1; primed = true;
             return prc;
         }

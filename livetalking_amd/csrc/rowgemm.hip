@@ -118,7 +118,7 @@ struct RowConvArgs {
     const f16* res; int res_cbt, res_cb0; // residual (same geometry as y) or nullptr
     const f16* w;                         // packed [J/16][K/32][64][8], K = taps * C ordered (tap, channel)
     const float* scale; const float* shift;
-    int N, H, W, Ho, Wo, S, pad, KW;      // KW: kernel width (taps = KW * KW)
+    int N, H, W, Ho, Wo, S, Sx, pad, KW;  // S / Sx: row / column stride; KW: kernel width (taps = KW * KW)
     int cpt;                              // C / 32: k-steps per tap (any C % 32 == 0)
     unsigned cmagic;                      // ceil(2^32 / cpt): tap = umulhi(k, cmagic) for cpt > 1
     int KT;                               // k-steps: taps * C / 32
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
         const int rr = live[ft] ? r : 0;
         const int n = rr / HWo, pix = rr - n * HWo;
         const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
-        iy0[ft] = oy * a.S - a.pad; ix0[ft] = ox * a.S - a.pad;
+        iy0[ft] = oy * a.S - a.pad; ix0[ft] = ox * a.Sx - a.pad;
         // channel block (g >> 1) and half (g & 1) of the k-step's 32 channels belong to this lane
         xn[ft] = a.x + (((size_t)n * a.x_cbt + a.x_cb0 + (g >> 1)) * HWi) * 16 + (g & 1) * 8;
     }
@@ -320,7 +320,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     a.y = io.y; a.y_cbt = io.y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
     a.res = io.res; a.res_cbt = io.res_ld >> 4; a.res_cb0 = io.res_coff >> 4;
     a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift;
-    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.pad = io.pad; a.KW = io.KW;
+    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.Sx = io.stride_w > 0 ? io.stride_w : io.stride; a.pad = io.pad; a.KW = io.KW;
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
     const int tiles = (int)((M + 15) / 16);
@@ -351,7 +351,7 @@ int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t strea
     a.y = io.y; a.y_cbt = io.y_ld >> 4; a.y_cb0 = io.y_coff >> 4;
     a.res = nullptr; a.res_cbt = 0; a.res_cb0 = 0;
     a.w = p[0].d_w; a.scale = p[0].d_scale; a.shift = p[0].d_shift;
-    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
+    a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.Sx = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
     for (int g = 0; g < 4; ++g) {

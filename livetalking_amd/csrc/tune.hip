@@ -37,6 +37,8 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_LDS_SWZ", 1},
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
+    {"LTK_PREFETCH_THREAD", 1},
+    {"LTK_AUDIO_ROWCONV", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
