@@ -1053,7 +1053,7 @@ def main():
             out["also"] = also
             out["paced"] = run_sub("paced-capacity", ["--batch", str(args.batch)])
             out["delivered"] = run_sub("delivered-capacity", ["--batch", str(args.batch)])
-            out["delivered_face_cache"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--delivered-sessions", "512,576",
+            out["delivered_face_cache"] = run_sub("delivered-capacity", ["--batch", str(args.batch), "--delivered-sessions", "512",
                                                                          "--delivered-formats", "bgr24"], env={"LTK_FACE_CACHE": "1"})
             w16 = also[0] if isinstance(also[0], dict) else {}
             out["sessions_25fps"] = {"per_gpu_delivered": (out["delivered"].get("bgr24") or {}).get("max_sessions_25fps_delivered"),
