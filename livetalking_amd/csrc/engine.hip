@@ -934,13 +934,7 @@ int ltk_engine_create(int device, ltk_engine** out) {
     e->device = device;
     CHK(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
     CHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
-    if (knob(K_PREFETCH_LOWPRIO)) {
-        int least = 0, greatest = 0;
-        CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CHK(hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, least));
-    } else {
-        CHK(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
-    }
+    CHK(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
     CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&e->ev_pf_done, hipEventDisableTiming));

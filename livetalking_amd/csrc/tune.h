@@ -64,8 +64,6 @@ enum Knob {
                           //                    pass, the prefetch reached the GPU ~270 us into it); 0: by the calling thread, behind the pass
     K_AUDIO_ROWCONV,      // LTK_AUDIO_ROWCONV  1 (default): audio_encoder.9 / .10 (3 x 3 output maps) as weight-streaming GEMMs over gathered rows (rowconv with a
                           //                    (3, 2) stride) in launches of <= ROWCONV rows; 0: first-generation kernel / conv3 + split-K finish (rounds 1-4)
-    K_PREFETCH_LOWPRIO,   // LTK_PREFETCH_LOWPRIO 1: the third stream (prefetched face encoder, knob PREFETCH) is created with the device's LOWEST stream priority,
-                          //                    read at engine creation (measurement knob of round 5; default 0)
     K_COUNT
 };
 
