@@ -515,7 +515,7 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
             rc = rowgemm_plan_create(&L->rg, we.data(), J, K, se.data(), fe.data(), &err);
             if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
             L->rg_y_ld = (d.transposed ? J : 0);
-        } else if (want_rowconv && flat_ld == 0 && !d.transposed && d.k == 3 && d.pad == 1 && d.cout % 256 == 0 &&
+        } else if (want_rowconv && flat_ld == 0 && !d.transposed && d.k == 3 && d.pad == 1 && (d.cout % 256 == 0 || (map_w < 0 && d.cout == 128)) &&
                    ((map_w > 0 && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && map_w % d.sh == 0 && map_w / d.sh <= 8 && (d.cin == 256 || d.cin == 512)) ||
                     // round 5: the audio encoder's last two 3 x 3 layers (audio_encoder.9: 128 -> 256, stride (3, 2), 9 x 6 -> 3 x 3; .10: 256 -> 256 on
                     // 3 x 3): 144 output pixels per 16-frame launch behind 0.6 / 1.2 MB of weights (map_w < 0: the caller vouches for a small map)
@@ -635,7 +635,8 @@ int build_program(ltk_engine* e, const ltk_named_tensor* sd, int n) {
             // 2.4 MB of weights in 26 us - the longest launch of the audio branch, which heads the critical path under knob PREFETCH)
             const bool flat = !d.transposed && d.pad == 0 && d.k > 1 && d.k == H && d.k == W && d.cin % 64 == 0 && !knob(K_NO_FLATTEN);
             const int oh = (H + 2 * d.pad - d.k) / d.sh + 1, ow = (W + 2 * d.pad - d.k) / d.sw + 1;
-            const bool small = !flat && d.k == 3 && d.pad == 1 && oh * ow <= 16;             // audio_encoder.9 / .10: rowconv (build_layer)
+            // audio_encoder.6 .. .10 (output maps 9 x 6 and 3 x 3: <= 864 rows per 16-frame launch): rowconv (build_layer)
+            const bool small = !flat && d.k == 3 && d.pad == 1 && oh * ow <= 54 && d.cin % 32 == 0;
             if ((rc = build_layer(e, d, sd, n, &L, H * W, flat ? in_ld : 0, small ? -1 : 0))) return rc;
             L.audio = true;
             L.in_buf = in_buf; L.in_ld = in_ld; L.in_coff = 0; L.H = H; L.W = W;
@@ -804,7 +805,7 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
         // output element whatever the launch's frame count (larger launches run these layers on conv3)
         else if (L.rowconv && L.rg.d_w && (long long)n * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK) &&
-                 (!L.audio || knob(K_AUDIO_ROWCONV))) {
+                 (!L.audio || L.Ho * L.Wo <= knob(K_AUDIO_ROWCONV))) {
             // 3x3 layers on the 4x4 / 8x8 maps: the same weight-streaming GEMM over gathered im2col rows (same LTK_SPLITK=0 rule)
             RowConvIO rio;
             rio.x = io.x; rio.x_ld = L.in_ld; rio.x_coff = L.in_coff; rio.H = L.H; rio.W = L.W;

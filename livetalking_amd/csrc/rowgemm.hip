@@ -124,6 +124,7 @@ struct RowConvArgs {
     int KT;                               // k-steps: taps * C / 32
     int M;                                // rows: N * Ho * Wo
     int NR;                               // row groups (16 * FT rows each)
+    int JB;                               // J / 32 channel pairs
     int relu;
     // Sub-pixel phases of a stride-2 transposed conv (nph = 4, gridDim.y = phase; nph = 1: a plain conv, the fields above).  Rows are
     // SOURCE pixels (n, y, x) of the H x W = Ho x Wo map; phase (py, px) owns output pixel (2y + py, 2x + px) of the 2H x 2W map and
@@ -143,8 +144,11 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: hardware block b runs on XCD b & 7; all row groups of a channel pair share their weights through that XCD's L2
+    // (JB = J / 32 channel pairs, a multiple of 8); layers with fewer pairs (JB = 4: the audio encoder's 128-channel layers) take the
+    // plain order - their weights are a few hundred KB
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int jb = xcd + 8 * (slot / a.NR), rg = slot % a.NR;  // host: (J / 32) % 8 == 0
+    const int jb = (a.JB & 7) ? (int)(blockIdx.x % (unsigned)a.JB) : xcd + 8 * (slot / a.NR);
+    const int rg = (a.JB & 7) ? (int)(blockIdx.x / (unsigned)a.JB) : slot % a.NR;
     const bool phased = a.nph > 1;
     const int pz = phased ? (int)blockIdx.y : 0;
     const int KT = phased ? a.ph[pz].KT : a.KT, KW = phased ? a.ph[pz].KW : a.KW;
@@ -309,7 +313,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     const int taps = io.KW * io.KW;
     if (!p.d_w || io.N <= 0 || taps <= 0 || p.K % taps) { if (err) *err = "rowconv: no plan / bad tap count"; return -1; }
     const int C = p.K / taps;
-    if (C % 32 || p.J % 256) { if (err) *err = "rowconv: channels must be a multiple of 32, output channels a multiple of 256"; return -1; }
+    if (C % 32 || p.J % 32 || ((p.J / 32) % 8 != 0 && p.J > 128)) { if (err) *err = "rowconv: channels must be a multiple of 32, output channels a multiple of 256 (or <= 128)"; return -1; }
     if (((io.x_ld | io.x_coff | io.y_ld | io.y_coff | io.res_ld | io.res_coff) & 15) || io.x_coff + C > io.x_ld || io.y_coff + p.J > io.y_ld) {
         if (err) *err = "rowconv: channel pitch / offset"; return -1;
     }
@@ -322,7 +326,7 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     a.w = p.d_w; a.scale = p.d_scale; a.shift = p.d_shift;
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.Sx = io.stride_w > 0 ? io.stride_w : io.stride; a.pad = io.pad; a.KW = io.KW;
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
-    a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
+    a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo; a.JB = p.J / 32;
     const int tiles = (int)((M + 15) / 16);
     const int FT = tiles * (p.J / 32) <= 512 ? 2 : 4;          // ~2 blocks per CU's worth of row groups before the tiles grow
     a.NR = (tiles + FT - 1) / FT;
@@ -353,7 +357,7 @@ int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t strea
     a.w = p[0].d_w; a.scale = p[0].d_scale; a.shift = p[0].d_shift;
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.Sx = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
-    a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo;
+    a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo; a.JB = J / 32;
     for (int g = 0; g < 4; ++g) {
         const int py = g >> 1, px = g & 1;
         if (!p[g].d_w || p[g].J != J || p[g].K != (1 + py) * (1 + px) * C) { if (err) *err = "rowconvT: phase plan mismatch"; return -1; }

@@ -62,8 +62,9 @@ enum Knob {
     K_PREFETCH_THREAD,    // LTK_PREFETCH_THREAD 1 (default): the prefetch graph of knob PREFETCH is launched by a helper thread of the engine WHILE the calling
                           //                    thread launches the call's own graph (a graph's nodes are submitted a few microseconds apiece: launched behind the
                           //                    pass, the prefetch reached the GPU ~270 us into it); 0: by the calling thread, behind the pass
-    K_AUDIO_ROWCONV,      // LTK_AUDIO_ROWCONV  1 (default): audio_encoder.9 / .10 (3 x 3 output maps) as weight-streaming GEMMs over gathered rows (rowconv with a
-                          //                    (3, 2) stride) in launches of <= ROWCONV rows; 0: first-generation kernel / conv3 + split-K finish (rounds 1-4)
+    K_AUDIO_ROWCONV,      // LTK_AUDIO_ROWCONV  audio-encoder 3 x 3 layers whose output map has at most this many pixels per frame run as weight-streaming GEMMs over
+                          //                    gathered rows (rowconv, row / column strides) in launches of <= ROWCONV rows: 54 (default) = audio_encoder.6 .. .10,
+                          //                    9 = .9 / .10 only, 0 = none (first-generation kernel / conv3 + split-K finish: rounds 1-4)
     K_COUNT
 };
 

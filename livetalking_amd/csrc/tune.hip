@@ -38,7 +38,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
     {"LTK_PREFETCH_THREAD", 1},
-    {"LTK_AUDIO_ROWCONV", 1},
+    {"LTK_AUDIO_ROWCONV", 54},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
