@@ -438,9 +438,8 @@ def run_musetalk(args, ranks: Ranks, shared=None):
         sessions.append(plugin.MuseReal(ap.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=s), model, avatar))
     d_feat = torch.from_numpy(synth.musetalk_whisper_feats(fps_step)).cuda().reshape(S, B, 50, 384)
     drv = SessionThreads(sessions, [d_feat[s] for s in range(S)], stride=3)
-    # untimed priming in front of the W warm-up steps: a frame count's pass is captured as a hipGraph the SECOND time each of its
-    # launch variants is seen (knob PREFETCH has three per frame count), and a capture inside the timed region would be timed;
-    # the steps walk the bank in the order a session does, so that priming, warm-up and timed steps are one unbroken sequence
+    # untimed priming in front of the W warm-up steps: the MuseTalk pass is captured as a hipGraph the second time a frame count is
+    # seen, and a capture inside the timed region would be timed
     PRIME = 3
     for i in range(PRIME):
         drv.step(i)

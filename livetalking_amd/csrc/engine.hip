@@ -579,6 +579,7 @@ void bump(size_t* cur, size_t v) { if (v > *cur) *cur = v; }
 // Everything ltk_wav2lip_load creates (layer plans, head weights, first-layer plan, activation arena): a failed load leaves
 // the engine as it found it, and can be retried.
 void drop_graphs(ltk_engine* e) {
+    if (e->aux2) (void)hipStreamSynchronize(e->aux2);      // a prefetch graph may still be running on the third stream
     for (auto& kv : e->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     e->graphs.clear();
@@ -605,6 +606,8 @@ void wav2lip_unload(ltk_engine* e) {
     e->alt_frames = 0;
     e->pf = ltk_engine::Prefetched();
     e->last_solo = ltk_engine::LastSolo();
+    e->pf_hold.reset();
+    e->pf_outstanding = false;
     if (e->d_tab_next) { (void)hipFree(e->d_tab_next); e->d_tab_next = nullptr; }
     if (e->d_head) { (void)hipFree(e->d_head); e->d_head = nullptr; }
     conv7_plan_destroy(e->c7);
@@ -1189,6 +1192,7 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
             if (it->second.exec && (victim == e->graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
         if (victim != e->graphs.end()) {
             CHK(hipStreamSynchronize(s));               // it may still be running for the previous call
+            if (victim->first & (1 << 24)) CHK(hipStreamSynchronize(e->aux2));     // ... a prefetch graph: on the third stream
             (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
         }
     }
