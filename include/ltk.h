@@ -295,8 +295,8 @@ int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes);
  * the previous one (same avatar, index = previous index + batch) the engine runs, beside that call's audio encoder + decoder and
  * on a third stream, the face encoder of the frames the NEXT call will ask for, into the other set of concat buffers; the next
  * call then starts at the decoder.  Every layer still runs once per frame and step and the frames are byte-identical to the
- * knob off (same kernels, same launch shapes).  The prefetch is its own hipGraph on the engine's third stream, replayed by a helper
- * thread of the engine while the calling thread launches the call's own graph.  A call that does not continue the sequence (another session, a jump of the
+ * knob off (same kernels, same launch shapes).  The prefetch is its own hipGraph on the engine's third stream, replayed right behind
+ * the call's own graph.  A call that does not continue the sequence (another session, a jump of the
  * index, a multi-request call) runs the whole pass and the unused prefetch is dropped.  Counters since engine creation:
  * single-request calls that found their encoder outputs prefetched / that did not / prefetches issued. */
 int ltk_wav2lip_prefetch_stats(ltk_engine* e, unsigned long long* hits, unsigned long long* misses, unsigned long long* issued);

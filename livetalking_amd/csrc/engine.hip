@@ -14,9 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
-#include <condition_variable>
+#include <chrono>
 #include <map>
-#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -300,20 +299,13 @@ struct ltk_engine {
     bool pf_outstanding = false;
     unsigned long pass_seq = 0;
     std::shared_ptr<Avatar> pf_hold;  // the bank the outstanding prefetch reads
-    // knob PREFETCH_THREAD: helper thread that replays the prefetch graph on aux2 while the caller launches the pass's own graph
-    struct PfWorker {
-        std::thread th;
-        std::mutex m;
-        std::condition_variable cv;
-        bool stop = false, has_job = false, busy = false;
-        hipGraphExec_t exec = nullptr;
-        hipEvent_t wait_ev = nullptr;
-        int rc = 0;
-    } pfw;
     DevTables* d_tab_next = nullptr;  // faces table of the prefetched frames
     struct Prefetched { int avatar = -1, first = -1, nf = 0, parity = 0; unsigned epoch = 0; bool valid = false; } pf;
     struct LastSolo { int avatar = -1, first = -1, nf = 0; } last_solo;
     unsigned long pf_hits = 0, pf_misses = 0, pf_issued = 0;
+    // LTK_INFER_TIMING=1 (measurement): host time of ltk_wav2lip_infer by phase, printed when the engine is destroyed
+    double tm_prep = 0, tm_launch = 0, tm_pf = 0, tm_wait = 0;
+    unsigned long tm_calls = 0;
     size_t buf_halfs[B_COUNT] = {0};  // per frame
     float* d_head = nullptr;          // 96 weights + 3 bias
     Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
@@ -961,11 +953,11 @@ int ltk_engine_create(int device, ltk_engine** out) {
     return LTK_OK;
 }
 
-static void pf_worker_stop(ltk_engine* e);
-
 void ltk_engine_destroy(ltk_engine* e) {
     if (!e) return;
-    pf_worker_stop(e);
+    if (e->tm_calls)
+        fprintf(stderr, "ltk: ltk_wav2lip_infer host time per call over %lu calls: prepare %.1f us, upload + pass launch %.1f us, prefetch join / serial launch %.1f us, wait for the device %.1f us\n",
+                e->tm_calls, e->tm_prep / e->tm_calls, e->tm_launch / e->tm_calls, e->tm_pf / e->tm_calls, e->tm_wait / e->tm_calls);
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     wav2lip_unload(e);
@@ -1231,70 +1223,6 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
 // pace).  Ordering: it starts behind the previous prefetch (stream order) and behind the pass that last READ the target set
 // (ev_main[prev]; in the call flow that pass has completed on the host already, ltk_wav2lip_time_convs issues passes back to back);
 // whoever uses the arena next waits for ev_pf_done (wait_prefetch).
-static void pf_worker_main(ltk_engine* e) {
-    (void)hipSetDevice(e->device);
-    ltk_engine::PfWorker& w = e->pfw;
-    std::unique_lock<std::mutex> lk(w.m);
-    for (;;) {
-        w.cv.wait(lk, [&] { return w.stop || w.has_job; });
-        if (w.stop) return;
-        w.has_job = false;
-        hipGraphExec_t exec = w.exec;
-        hipEvent_t wait_ev = w.wait_ev;
-        lk.unlock();
-        int rc = 0;
-        hipError_t he = hipSuccess;
-        const char* what = "";
-        if (wait_ev && (he = hipStreamWaitEvent(e->aux2, wait_ev, 0)) != hipSuccess) { rc = -2; what = "hipStreamWaitEvent"; }
-        if (!rc && (he = hipGraphLaunch(exec, e->aux2)) != hipSuccess) { rc = -2; what = "hipGraphLaunch"; }
-        if (!rc && (he = hipEventRecord(e->ev_pf_done, e->aux2)) != hipSuccess) { rc = -2; what = "hipEventRecord"; }
-        if (rc) { (void)hipGetLastError(); fprintf(stderr, "ltk: prefetch helper: %s failed (%s)\n", what, hipGetErrorString(he)); }
-        lk.lock();
-        w.rc = rc;
-        w.busy = false;
-        w.cv.notify_all();
-    }
-}
-
-// hands a replay of `exec` on aux2 to the helper thread (started on first use); pf_worker_join waits for the launch calls to have returned
-static void pf_worker_post(ltk_engine* e, hipGraphExec_t exec, hipEvent_t wait_ev) {
-    ltk_engine::PfWorker& w = e->pfw;
-    std::lock_guard<std::mutex> g(w.m);
-    if (!w.th.joinable()) w.th = std::thread(pf_worker_main, e);
-    w.exec = exec; w.wait_ev = wait_ev; w.has_job = true; w.busy = true; w.rc = 0;
-    w.cv.notify_all();
-}
-
-static int pf_worker_join(ltk_engine* e) {
-    ltk_engine::PfWorker& w = e->pfw;
-    std::unique_lock<std::mutex> lk(w.m);
-    w.cv.wait(lk, [&] { return !w.busy; });
-    return w.rc;
-}
-
-static void pf_worker_stop(ltk_engine* e) {
-    ltk_engine::PfWorker& w = e->pfw;
-    {
-        std::lock_guard<std::mutex> g(w.m);
-        w.stop = true;
-        w.cv.notify_all();
-    }
-    if (w.th.joinable()) w.th.join();
-}
-
-// the replayable prefetch graph of (nf, target set) - or null: not captured yet, knob GRAPH off, knobs changed since, or the pass it
-// runs beside (`pass_key`) is not a pure replay itself (while the calling thread captures a pass, its streams are in capture mode and
-// another thread's event / launch calls fail with "dependency created on uncaptured work in another stream")
-static hipGraphExec_t prefetch_exec(ltk_engine* e, int nf, int par_target, int pass_key) {
-    if (!knob(K_GRAPH) || !knob(K_PREFETCH_THREAD) || e->graph_epoch != knob_epoch()) return nullptr;
-    auto mp = e->graphs.find(pass_key);
-    if (mp == e->graphs.end() || !mp->second.exec) return nullptr;
-    auto it = e->graphs.find(nf | (par_target << 21) | (1 << 24));
-    if (it == e->graphs.end() || !it->second.exec) return nullptr;
-    it->second.stamp = ++e->graph_clock;
-    return it->second.exec;
-}
-
 static int wait_prefetch(ltk_engine* e) {
     if (e->pf_outstanding) { CHK(hipStreamWaitEvent(e->compute, e->ev_pf_done, 0)); e->pf_outstanding = false; }
     return 0;
@@ -1381,6 +1309,9 @@ int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes) {
 int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream) {
     if (!e || !reqs || nreq <= 0) return fail(LTK_E_INVALID, "bad arguments");
     if (!e->loaded) return fail(LTK_E_STATE, "ltk_wav2lip_load has not been called");
+    static const bool timing = getenv("LTK_INFER_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
     CHK(enter_device(e->device));
     // resolve every frame's bank crop and mel window up front
     const bool want_cache = knob(K_FACE_CACHE) != 0;
@@ -1447,21 +1378,8 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         e->pf.valid = false;                    // whatever this call does, it overwrites the set the old prefetch went to or consumes it
         if (solo) { if (hit) ++e->pf_hits; else ++e->pf_misses; }
         if ((rc = wait_prefetch(e))) return rc;          // a hit needs its data; everything else needs the buffers it was writing
-        // knob PREFETCH_THREAD: the next call's face encoder is handed to the helper thread BEFORE this call's pass is launched, so that
-        // the two graphs are submitted side by side (steady state: both are captured; anything else goes the serial way below)
+        if (timing) tp1 = std::chrono::steady_clock::now();
         const unsigned long seq = e->pass_seq++;
-        hipGraphExec_t pf_exec = nullptr;
-        if (prefetch) {
-            FacePtrs nx;
-            const Avatar& a = *hold[0];
-            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
-            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
-            pf_exec = (total <= mbs) ? prefetch_exec(e, total, par ^ 1, total | (par << 21) | (hit ? (1 << 22) : 0)) : nullptr;
-            if (pf_exec) {
-                if (seq > 0) CHK(hipStreamWaitEvent(e->aux2, e->ev_main[(seq - 1) & 1], 0));
-                pf_worker_post(e, pf_exec, nullptr);
-            }
-        }
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
@@ -1471,12 +1389,15 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached, par, hit);
         }
         if (!rc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
-        if (pf_exec) {
-            const int wrc = pf_worker_join(e);           // its launch calls have returned: ev_pf_done is recorded
-            if (wrc) { if (!rc) rc = fail(LTK_E_HIP, "prefetch launch failed"); }
-            else e->pf_outstanding = true;
-        } else if (!rc && prefetch) {
-            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);     // eager / capturing: behind the pass
+        if (timing) tp2 = std::chrono::steady_clock::now();
+        if (!rc && prefetch) {
+            // behind the pass (its launch costs the host ~40 us, this one ~15 us: the branch reaches the GPU ~55 us into the pass, beside the
+            // audio encoder): the next call's face encoder, on the third stream
+            FacePtrs nx;
+            const Avatar& a = *hold[0];
+            for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
+            launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
+            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
         }
         if (!rc && prefetch) {
             ++e->pf_issued;
@@ -1489,10 +1410,17 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         if (!rc) {
             if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
         }
+        if (timing) tp3 = std::chrono::steady_clock::now();
     }
     if (!rc) {
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+    }
+    if (timing) {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        e->tm_prep += us(tp0, tp1); e->tm_launch += us(tp1, tp2); e->tm_pf += us(tp2, tp3); e->tm_wait += us(tp3, tp4); ++e->tm_calls;
     }
     return rc;
 }
@@ -1681,15 +1609,9 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
             if ((prc = wait_prefetch(e))) return prc;
             const unsigned long seq = e->pass_seq++;
             hipEvent_t prev = seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr;
-            hipGraphExec_t pf_exec = prefetch_exec(e, frames, par ^ 1, frames | (par << 21) | (primed ? (1 << 22) : 0));
-            if (pf_exec) {
-                if (prev) CHK(hipStreamWaitEvent(e->aux2, prev, 0));
-                pf_worker_post(e, pf_exec, nullptr);
-            }
             prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed);
             if (!prc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) prc = fail(LTK_E_HIP, "hipEventRecord(ev_main) failed");
-            if (pf_exec) { const int wrc = pf_worker_join(e); if (wrc && !prc) prc = fail(LTK_E_HIP, "prefetch helper launch failed"); if (!wrc) e->pf_outstanding = true; }
-            else if (!prc) prc = launch_prefetch(e, frames, par ^ 1, prev);
+            if (!prc) prc = launch_prefetch(e, frames, par ^ 1, prev);
             par ^= 1; primed = true;
             return prc;
         }

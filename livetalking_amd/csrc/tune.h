@@ -59,9 +59,6 @@ enum Knob {
                           //                    N+1 will ask for (bank frames index+B ..) runs beside it on a third stream into the other set of concat buffers; call
                           //                    N+1 then starts at the decoder.  Every layer still runs once per frame and step; a call that does not continue the
                           //                    sequence runs the whole pass.  0: every call runs the whole pass (rounds 1-4)
-    K_PREFETCH_THREAD,    // LTK_PREFETCH_THREAD 1 (default): the prefetch graph of knob PREFETCH is launched by a helper thread of the engine WHILE the calling
-                          //                    thread launches the call's own graph (a graph's nodes are submitted a few microseconds apiece: launched behind the
-                          //                    pass, the prefetch reached the GPU ~270 us into it); 0: by the calling thread, behind the pass
     K_AUDIO_ROWCONV,      // LTK_AUDIO_ROWCONV  audio-encoder 3 x 3 layers whose output map has at most this many pixels per frame run as weight-streaming GEMMs over
                           //                    gathered rows (rowconv, row / column strides) in launches of <= ROWCONV rows: 54 (default) = audio_encoder.6 .. .10,
                           //                    9 = .9 / .10 only, 0 = none (first-generation kernel / conv3 + split-K finish: rounds 1-4)

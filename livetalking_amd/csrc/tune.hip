@@ -37,7 +37,6 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_LDS_SWZ", 1},
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
-    {"LTK_PREFETCH_THREAD", 1},
     {"LTK_AUDIO_ROWCONV", 54},
 };
 
