@@ -255,6 +255,14 @@ int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6
 
 /* After a forward with capture enabled, copy one layer's activation
  * (state_dict prefix, e.g. "face_encoder_blocks.1.0") as NCHW float32. */
+/* Saturation counters (debug; knob SAT_CHECK = 1, environment LTK_SAT_CHECK or ltk_debug_set_knob).  The conv epilogues clamp to
+ * the fp16 range (fmed3f(t, -65504, 65504)): a network whose activations reach it is no longer computing the reference's fp32
+ * numbers, and the fp16 parity tolerance does not hold from there on.  With the knob on, every layer's / op's output (Wav2Lip
+ * layers, MuseTalk ops incl. the e4m3 tensors of the fp8 path) is scanned as it is produced: `n_at_limit` = values exactly at the
+ * limit of their type (what a clamp leaves behind), `n_nonfinite` = inf / NaN (a kernel without a clamp overflowed).  Waits for
+ * the device; `reset` != 0 zeroes the counters afterwards.  Reference: the reference runs these networks in fp32 on the CPU and
+ * fp16 autocast on CUDA (avatars/wav2lip_avatar.py:51-70, avatars/musetalk_avatar.py:57-66); it has no such check. */
+int ltk_debug_saturation(ltk_engine* e, int reset, unsigned long long* n_at_limit, unsigned long long* n_nonfinite);
 int ltk_debug_capture(ltk_engine* e, int enable);
 int ltk_debug_get(ltk_engine* e, const char* layer, float* out, size_t n_floats);
 

@@ -75,6 +75,7 @@ SYMBOLS = {
     "ltk_vae_encode_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ltk_wav2lip_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ltk_debug_capture": (C.c_int, [C.c_void_p, C.c_int]),
+    "ltk_debug_saturation": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "ltk_debug_set_knob": (C.c_int, [C.c_char_p, C.c_int]),
     "ltk_debug_tile_table_check": (C.c_int, [C.c_char_p, C.c_int]),
     "ltk_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -662,6 +662,56 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             }
         }
     };
+    // GEGLU (relu == 4; diffusers FeedForward.net[0] = GEGLU: proj -> value * gelu(gate)): the host packs the projection's rows so
+    // that every 32-cout tile is [16 value channels | their 16 gate channels]; a lane holds value channel 8*eo + 4*hh + r in
+    // register group eo and its gate in group 2 + eo, so the product needs no exchange and tile i becomes ONE 16-channel block
+    // (cout0 / 32 + i) of the half-as-wide output.  1x1 layers only (scale / shift from global memory), no residual.
+    if constexpr (T == 1 && G == 1 && Q == 0) {
+        if (a.relu == 4) {
+            const int cbo2 = cout0 >> 5;
+            int obase[PXW];
+            bool okj[PXW];
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) {
+                int n;
+                const int opx = out_px(j, 0, &n, &okj[j]);
+                obase[j] = ((n * a.y_cbt + a.y_cb0 + cbo2) * HWo + opx) * 16 + hh * 8;
+            }
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) {
+                if (2 * i >= ncb_valid) continue;                    // wave-uniform
+                f32x4 scv[2], sfv[2], scg[2], sfg[2];
+#pragma unroll
+                for (int eo = 0; eo < 2; ++eo) {
+                    const int cl = cout0 + i * 32 + 8 * eo + 4 * hh;
+                    scv[eo] = *reinterpret_cast<const f32x4*>(a.scale + cl);      sfv[eo] = *reinterpret_cast<const f32x4*>(a.shift + cl);
+                    scg[eo] = *reinterpret_cast<const f32x4*>(a.scale + cl + 16); sfg[eo] = *reinterpret_cast<const f32x4*>(a.shift + cl + 16);
+                }
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int eo = 0; eo < 2; ++eo) {
+                        f16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[0][i][j][4 * eo + r] * scv[eo][r] + sfv[eo][r];
+                            const float gt = acc[0][i][j][4 * (2 + eo) + r] * scg[eo][r] + sfg[eo][r];
+                            const float t = v * gelu_as(gt);
+                            o[r] = (f16)__builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+                        }
+                        const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                        pk[eo][0] = u.x; pk[eo][1] = u.y;
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (okj[j] && do_store) *reinterpret_cast<uint4*>(a.y + obase[j] + i * HWo16) = out;
+                }
+            }
+            return;
+        }
+    }
     if (a.relu == 1) epilogue(std::integral_constant<int, 1>{});
     else if (a.relu == 2) epilogue(std::integral_constant<int, 2>{});
     else if (a.relu == 3) epilogue(std::integral_constant<int, 3>{});
@@ -949,6 +999,10 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     const int fks = io.force_ksplit ? io.force_ksplit : knob(K_KSPLIT);
     if (fks > 0 && knob(K_SPLITK)) ksplit = std::max(1, std::min(std::min(fks, kMaxKSplit), a.nchunks));
     if (io.head_w != nullptr && io.head_outs != nullptr) ksplit = 1;      // the fused head finishes in the epilogue: no partial slabs
+    if (a.relu == 4) {                                                    // GEGLU epilogue: value and gate meet in the accumulators
+        if (!(G == 1 && T == 1 && !p.q8 && p.lCout % 32 == 0 && !io.res)) { if (err) *err = "conv3: the GEGLU epilogue is a 1x1-layer feature"; return -1; }
+        ksplit = 1;
+    }
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;
     }

@@ -11,6 +11,21 @@ namespace ltk {
 
 typedef _Float16 f16;
 
+// GELU (exact / erf form, torch.nn.functional.gelu's default, which diffusers' GEGLU uses) for the GEGLU feed-forward:
+// x * Phi(x) with erfc(|x| / sqrt 2) from Abramowitz-Stegun 7.1.26 (absolute error <= 1.5e-7: 3 000x below the fp16 resolution of the
+// result), evaluated without cancellation on either side of 0: one v_rcp, one v_exp, 9 fma / mul - erff() is ~3x that and was
+// most of the GEGLU epilogue's time (21 M gates per 16-frame launch on the 32^2 level).
+__device__ __forceinline__ float gelu_as(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float pe = p * t * __expf(-z * z);          // erfc(z)
+    return 0.5f * x * (x >= 0.f ? 2.f - pe : pe);
+}
+
 constexpr int kConvBM = 256;       // output pixels per workgroup (4 waves x 64)
 constexpr int kMaxTaps = 52;       // 7x7 = 49 (+ pairing pad)
 constexpr int kMaxPhases = 4;      // sub-pixel phases of a stride-2 transposed conv

@@ -281,6 +281,7 @@ struct ltk_engine {
     float* d_partial = nullptr;           // conv3 split-K scratch of the compute stream
     float* d_partial_aux = nullptr;       // ... of the aux stream
     float* d_partial_pf = nullptr;        // ... of the prefetch stream (aux2, knob PREFETCH)
+    unsigned long long* d_sat = nullptr;  // [2] saturation counters of knob SAT_CHECK (ltk_debug_saturation): halfs at the fp16 limit, non-finite halfs
     size_t partial_cap = 0, partial_aux_cap = 0, partial_pf_cap = 0;
     std::mutex mu;            // enqueue order on `compute` + arena ownership
     std::mutex pool_mu;       // scratch / stream pools, avatar table
@@ -824,6 +825,9 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         else
             rc = conv_launch(L.plan, io, on_aux ? e->aux : s, &err);
         if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, L.name + ": " + err);
+        // debug (knob SAT_CHECK): count what this layer's epilogue clamped to the fp16 limit (a fused head writes bytes: run it unfused)
+        if (knob(K_SAT_CHECK) && !(io.head_w && io.head_outs))
+            launch_sat_scan(io.y, n, L.out_ld / 16, L.out_coff / 16, (L.plan.Cout + 15) / 16, (long long)L.Ho * L.Wo, 0, e->d_sat, on_aux ? e->aux : s);
         return 0;
     };
     // depth-first region: [df_first, end) of `order`
@@ -942,6 +946,8 @@ int ltk_engine_create(int device, ltk_engine** out) {
     CHK(hipMalloc((void**)&e->d_partial, e->partial_cap));
     CHK(hipMalloc((void**)&e->d_partial_aux, e->partial_aux_cap));
     CHK(hipMalloc((void**)&e->d_partial_pf, e->partial_pf_cap));
+    CHK(hipMalloc((void**)&e->d_sat, 2 * sizeof(unsigned long long)));
+    CHK(hipMemset(e->d_sat, 0, 2 * sizeof(unsigned long long)));
     std::vector<float> basis;
     std::vector<int32_t> lohi;
     build_mel_basis(&basis, &lohi);
@@ -981,6 +987,7 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_partial_aux) (void)hipFree(e->d_partial_aux);
     if (e->d_partial_pf) (void)hipFree(e->d_partial_pf);
+    if (e->d_sat) (void)hipFree(e->d_sat);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_pf_done) (void)hipEventDestroy(e->ev_pf_done);
@@ -1154,7 +1161,7 @@ constexpr size_t kMaxPassGraphs = 48;
 static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32,
                        bool cached = false, int par = 0, bool have_feats = false) {
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
-    const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED);
+    const bool fused = have_outs && !d_pred_f32 && !e->capture && knob(K_HEAD_FUSED) && !knob(K_SAT_CHECK);
     // knob GRAPH: 0 never, non-zero (default 1) every eligible pass.  Measured (profiles/r04_vs_r03_same_job.txt, r04_graph_auto_ab.txt): the replay of a
     // 16-frame pass is ~5-15 us (0.5-1 %) slower on the device than the same launches issued one by one (equal from 64 frames on), the host side is
     // one launch instead of ~70: a single session's step is 0..1.8 % faster end to end depending on the box's host (three interleaved pairs on the
@@ -1531,6 +1538,19 @@ int ltk_wav2lip_forward_host(ltk_engine* e, const float* mel, const float* face6
     return LTK_OK;
 }
 
+int ltk_debug_saturation(ltk_engine* e, int reset, unsigned long long* n_at_limit, unsigned long long* n_nonfinite) {
+    if (!e) return fail(LTK_E_INVALID, "bad arguments");
+    CHK(enter_device(e->device));
+    std::lock_guard<std::mutex> g(e->mu);
+    CHK(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    CHK(hipMemcpy(h, e->d_sat, sizeof(h), hipMemcpyDeviceToHost));
+    if (n_at_limit) *n_at_limit = h[0];
+    if (n_nonfinite) *n_nonfinite = h[1];
+    if (reset) CHK(hipMemset(e->d_sat, 0, sizeof(h)));
+    return LTK_OK;
+}
+
 int ltk_debug_capture(ltk_engine* e, int enable) {
     if (!e) return fail(LTK_E_INVALID, "engine is null");
     std::lock_guard<std::mutex> g(e->mu);
@@ -1826,6 +1846,7 @@ int ltk_musetalk_load(ltk_engine* e, const ltk_named_tensor* unet_sd, int n_unet
     if (e->mt) return fail(LTK_E_STATE, "a MuseTalk model is already loaded in this engine");
     CHK(enter_device(e->device));
     MtGraph* mg = mt_graph_new();
+    mt_set_sat_counter(mg, e->d_sat);
     mt_set_fp8(mg, e->mt_fp8, e->mt_fp8_ascale);
     const int rc = mt_build(mg, unet_sd, n_unet, vae_sd, n_vae, max_frames);
     if (rc) {

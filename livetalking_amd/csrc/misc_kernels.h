@@ -65,6 +65,12 @@ struct DevTables {
 void launch_upload_tables(const FacePtrs* faces, const MelPtrs* mels, const OutPtrs* outs, int nframes, DevTables* d_tab, hipStream_t s);
 
 // fp16 CB16 (or [N][H][W][8] when ld <= 8) channel range (ld, coff, C) -> float32 NCHW (debug capture).
+// Saturation scan (debug, knob SAT_CHECK): counts, over the channel-blocked tensor view [N][cbt][P][16] blocks [cb0, cb0 + CB), the
+// halfs sitting AT the fp16 limit (|v| == 65504: what an epilogue clamp `fmed3f(t, -65504, 65504)` leaves behind) into ctr[0] and
+// the non-finite ones (a kernel without a clamp overflowed) into ctr[1].  q8 != 0: e4m3 bytes of a [N][cbt][P][32] tensor
+// (|v| == 448 / NaN).  One atomic per wave that found something.
+void launch_sat_scan(const f16* x, int N, int cbt, int cb0, int CB, long long P, int q8, unsigned long long* ctr, hipStream_t s);
+
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s);
 
 // audio.py:45-51 melspectrogram columns + mel.py:56-63 window gather.

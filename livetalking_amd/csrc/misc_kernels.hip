@@ -3,6 +3,8 @@
 // in the mel DFT (frame + twiddle table in LDS).
 #include "misc_kernels.h"
 
+#include <algorithm>
+
 #include <hip/hip_fp16.h>
 
 namespace ltk {
@@ -173,6 +175,49 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict
     const int n = (int)(i / ((size_t)HW * C));
     const int cc = coff + c;   // channel-blocked [N][ld/16][HW][16]
     out[i] = (float)x[(((size_t)n * (ld >> 4) + (cc >> 4)) * HW + p) * 16 + (cc & 15)];
+}
+
+__global__ __launch_bounds__(256) void sat_scan_kernel(const f16* __restrict__ x, int cbt, int cb0, int CB, long long P, long long total,
+                                                        int q8, unsigned long long* __restrict__ ctr) {
+    unsigned hit = 0, bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int half = (int)(i & 1);
+        const long long r = i >> 1;
+        const long long p = r % P;
+        const long long r2 = r / P;
+        const int cb = (int)(r2 % CB), n = (int)(r2 / CB);
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(x) + (((size_t)n * cbt + cb0 + cb) * P + p) * 32 + half * 16);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (q8) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned m = (w[k] >> (8 * b)) & 0x7fu;
+                    hit += m == 0x7eu; bad += m == 0x7fu;          // e4m3fn: 0x7e = 448, 0x7f = NaN
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const unsigned m = (w[k] >> (16 * b)) & 0x7fffu;
+                    hit += m == 0x7bffu; bad += m >= 0x7c00u;      // fp16: 0x7bff = 65504, >= 0x7c00 = inf / NaN
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { hit += __shfl_xor(hit, m); bad += __shfl_xor(bad, m); }
+    if ((threadIdx.x & 63) == 0) {
+        if (hit) atomicAdd(ctr, (unsigned long long)hit);
+        if (bad) atomicAdd(ctr + 1, (unsigned long long)bad);
+    }
+}
+
+void launch_sat_scan(const f16* x, int N, int cbt, int cb0, int CB, long long P, int q8, unsigned long long* ctr, hipStream_t s) {
+    const long long total = (long long)N * CB * P * 2;
+    if (total <= 0 || !ctr) return;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(sat_scan_kernel, dim3(grid), dim3(256), 0, s, x, cbt, cb0, CB, P, total, q8, ctr);
 }
 
 void launch_nhwc_to_nchw_f32(const f16* x, int N, int H, int W, int ld, int coff, int C, float* out, hipStream_t s) {

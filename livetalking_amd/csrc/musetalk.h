@@ -20,6 +20,8 @@ const char* mt_graph_error(const MtGraph* g);
 // multiplied by before the saturating conversion (<= 0 keeps the default 8)
 void mt_set_fp8(MtGraph* g, int on, float act_scale);
 double mt_macs_fp8_per_frame(const MtGraph* g);
+// debug (knob SAT_CHECK): device counters [2] (halfs at the fp16 / e4m3 limit, non-finite ones) that every op's output is scanned into
+void mt_set_sat_counter(MtGraph* g, unsigned long long* d_ctr);
 // builds U-Net then VAE decoder; returns 0 or a negative code
 int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames);
 // tensors the engine feeds / reads
@@ -28,7 +30,7 @@ f16* mt_ctx_in(MtGraph* g, int* cbt);          // [N][24][50][16]
 f16* mt_unet_out(MtGraph* g, int* cbt);        // [N][1][1024][16] (4 real channels)
 f16* mt_vae_out(MtGraph* g, int* cbt);         // [N][1][65536][16] (3 real channels, RGB)
 int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s);
-// per-op view (profiling): ops in execution order; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos
+// per-op view (profiling): ops in execution order; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos, 6 value transpose (hoisted cross-attention values)
 int mt_op_count(MtGraph* g);
 const char* mt_op_name(MtGraph* g, int i, int* type);
 int mt_run_timed(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, std::vector<hipEvent_t>* evs);

@@ -27,6 +27,7 @@
 #include "tune.h"
 #include "musetalk.h"
 #include "nn_kernels.h"
+#include "misc_kernels.h"
 
 namespace ltk {
 
@@ -68,7 +69,7 @@ struct MtTensor {
     int P() const { return H * W; }
 };
 
-enum MtOpType { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_ADDPOS };
+enum MtOpType { OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_ADDPOS, OP_VT };
 
 struct MtOp {
     MtOpType type;
@@ -84,7 +85,11 @@ struct MtOp {
     float eps = 1e-5f;
     int heads = 1, d16 = 0;
     int Tk = 0;
+    int vt_buf = -1;            // OP_ATTN: the values are already transposed in this buffer (written by the pass's OP_VT), else the shared scratch
 };
+
+// one cross-attention's share of the hoisted k | v projection (MtGraph::kv_all): its value view and where the transposed values go
+struct MtVtItem { MtTensor v; int heads, d16, Tk, vt_buf; };
 
 struct MtGraph {
     std::vector<size_t> buf_halfs;           // per frame
@@ -98,6 +103,9 @@ struct MtGraph {
     size_t gn_partial_floats = 0;
     f16* vt = nullptr;                        // transposed values scratch
     size_t vt_halfs = 0;                      // per frame
+    struct KvPre { MtTensor k, v; int vt_buf; };
+    std::map<std::string, KvPre> kv_pre;      // cross-attention name -> its views of the hoisted projection
+    std::vector<MtVtItem> vt_items;           // OP_VT: every cross-attention's values, transposed by ONE launch at the head of the pass
     int frames = 0;
     // fp8 conv path (BASELINE configs[4]): the GroupNorm+SiLU in front of every ResnetBlock2D 3x3 conv writes e4m3
     // (x * fp8_ascale, saturating) and the conv runs on fp8 operands; everything else stays fp16
@@ -106,6 +114,7 @@ struct MtGraph {
     double macs = 0;                          // conv / linear MACs per frame (attention excluded)
     double macs_fp8 = 0;                      // ... of which on fp8 operands
     std::string err;
+    unsigned long long* sat_ctr = nullptr;    // debug (knob SAT_CHECK): saturation counters every op's output is scanned into
     MtTensor *t_latent = nullptr, *t_ctx = nullptr, *t_unet_out = nullptr, *t_vae_out = nullptr;
     MtTensor* whisper_states = nullptr;
 
@@ -205,7 +214,8 @@ struct MtGraph {
             op.ksz = kh;
         }
         if (res) op.r = *res;
-        if (up16(Cin) != x.C || CoutP != y.C) { err = name + ": channel mismatch (" + std::to_string(Cin) + "->" + std::to_string(Cout) + ")"; return -1; }
+        // act 4 = GEGLU in the epilogue (conv3_mfma.hip): the output is half as wide as the projection
+        if (up16(Cin) != x.C || (act == 4 ? CoutP / 2 : CoutP) != y.C) { err = name + ": channel mismatch (" + std::to_string(Cin) + "->" + std::to_string(Cout) + ")"; return -1; }
         ops.push_back(op);
         named[name] = y;
         return 0;
@@ -232,10 +242,13 @@ struct MtGraph {
         named[name] = y;
         return 0;
     }
-    void add_attn(const std::string& name, const MtTensor& q, const MtTensor& k, const MtTensor& v, const MtTensor& o, int heads, int d16) {
+    // `vt_buf` >= 0: the values were transposed into that buffer by the pass's OP_VT (hoisted cross-attention k | v, mt_build_unet)
+    void add_attn(const std::string& name, const MtTensor& q, const MtTensor& k, const MtTensor& v, const MtTensor& o, int heads, int d16,
+                  int vt_buf = -1) {
         MtOp op;
         op.type = OP_ATTN; op.name = name; op.x = q; op.k = k; op.v = v; op.y = o; op.heads = heads; op.d16 = d16; op.Tk = k.P();
-        vt_halfs = std::max(vt_halfs, (size_t)heads * attn_dv32(d16) * attn_tkp(k.P()));
+        op.vt_buf = vt_buf;
+        if (vt_buf < 0) vt_halfs = std::max(vt_halfs, (size_t)heads * attn_dv32(d16) * attn_tkp(k.P()));
         ops.push_back(op);
         named[name + ".attn"] = o;
     }
@@ -355,8 +368,10 @@ int build_resnet(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, co
 
 // diffusers Attention (to_q / to_k / to_v / to_out.0), q from x (C channels), k/v from ctx (Cctx channels);
 // out = to_out(attn) + res
+// `kv_pre` (or null): {k view, v view} of a projection that already ran (the hoisted, stacked k | v projection of every
+// cross-attention, mt_build_unet), `vt_pre` the buffer its transposed values are in
 int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& ctx, int C, int Cctx, int heads,
-                    bool qkv_bias, const MtTensor& res, const MtTensor& out) {
+                    bool qkv_bias, const MtTensor& res, const MtTensor& out, const MtTensor* kv_pre = nullptr, int vt_pre = -1) {
     const int d = C / heads, d16 = up16(d), Cp = heads * d16;
     const float scale = 1.0f / sqrtf((float)d);
     const float* wq = sd.get(p + ".to_q.weight", (size_t)C * C);
@@ -385,7 +400,11 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
     const bool fuse = !knob(K_MT_NO_QKV_FUSE);      // A/B switch
     const bool self = fuse && x.buf == ctx.buf && x.coff == ctx.coff && x.C == ctx.C;
     MtTensor q, k, v, o = g.alloc(Cp, x.H, x.W);
-    if (self) {
+    if (kv_pre) {
+        q = g.alloc(Cp, x.H, x.W);
+        if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
+        k = kv_pre[0]; v = kv_pre[1];
+    } else if (self) {
         MtTensor qkv = g.alloc(3 * Cp, x.H, x.W);
         const std::vector<float> w3 = stack({&wqp, &wkp, &wvp}), b3 = stack({&bqp, &bkp, &bvp});
         if (g.add_conv(p + ".to_qkv", w3.data(), b3.data(), C, 3 * Cp, 1, 1, 0, x, qkv, nullptr, 0, 0)) return -1;
@@ -404,7 +423,7 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
         k = MtGraph::view(kv, 0, Cp); v = MtGraph::view(kv, Cp, Cp);
     }
     g.named[p + ".to_q"] = q; g.named[p + ".to_k"] = k; g.named[p + ".to_v"] = v;
-    g.add_attn(p, q, k, v, o, heads, d16);
+    g.add_attn(p, q, k, v, o, heads, d16, kv_pre ? vt_pre : -1);
     return g.add_conv(p + ".to_out.0", wop.data(), bo, Cp, C, 1, 1, 0, o, out, &res, 0, 0);
 }
 
@@ -424,16 +443,39 @@ int build_transformer(MtGraph& g, SD& sd, const std::string& p, const MtTensor& 
     if (build_attention(g, sd, b + ".attn1", n1, n1, C, C, 8, false, h0, h1)) return -1;
     MtTensor n2 = g.alloc(C, H, W), h2 = g.alloc(C, H, W);
     if (g.add_ln(b + ".norm2", sd, b + ".norm2", h1, n2, 1e-5f)) return -1;
-    if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2)) return -1;
-    MtTensor n3 = g.alloc(C, H, W), f1 = g.alloc(8 * C, H, W), gg = g.alloc(4 * C, H, W), h3 = g.alloc(C, H, W);
+    {
+        auto kv = g.kv_pre.find(b + ".attn2");
+        if (kv != g.kv_pre.end()) {
+            const MtTensor pre[2] = {kv->second.k, kv->second.v};
+            if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2, pre, kv->second.vt_buf)) return -1;
+        } else if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2)) return -1;
+    }
+    MtTensor n3 = g.alloc(C, H, W), f1, gg = g.alloc(4 * C, H, W), h3 = g.alloc(C, H, W);
+    if (!(knob(K_MT_FUSE) & 1)) f1 = g.alloc(8 * C, H, W);
     if (g.add_ln(b + ".norm3", sd, b + ".norm3", h2, n3, 1e-5f)) return -1;
     const float* w1 = sd.get(b + ".ff.net.0.proj.weight", (size_t)8 * C * C);
     const float* b1 = sd.get(b + ".ff.net.0.proj.bias", 8 * C);
     const float* w2 = sd.get(b + ".ff.net.2.weight", (size_t)C * 4 * C);
     const float* b2 = sd.get(b + ".ff.net.2.bias", C);
     if (!w1 || !b1 || !w2 || !b2) { g.err = sd.err; return -1; }
-    if (g.add_conv(b + ".ff.net.0.proj", w1, b1, C, 8 * C, 1, 1, 0, n3, f1, nullptr, 0, 0)) return -1;
-    g.add_geglu(b + ".ff.geglu", f1, gg);
+    if (knob(K_MT_FUSE) & 1) {
+        // GEGLU in the projection's epilogue: rows permuted so that every 32-row tile is [16 value rows | their 16 gate rows]
+        // (value = rows [0, 4C), gate = rows [4C, 8C) of ff.net.0.proj: diffusers GEGLU chunks the projection in that order)
+        const int F = 4 * C;
+        std::vector<float> wp((size_t)8 * C * C), bp((size_t)8 * C);
+        for (int t = 0; t < F / 16; ++t)
+            for (int r = 0; r < 32; ++r) {
+                const int src = (r < 16) ? t * 16 + r : F + t * 16 + (r - 16);
+                memcpy(&wp[(size_t)(t * 32 + r) * C], &w1[(size_t)src * C], (size_t)C * sizeof(float));
+                bp[t * 32 + r] = b1[src];
+            }
+        if (g.add_conv(b + ".ff.net.0.proj", wp.data(), bp.data(), C, 8 * C, 1, 1, 0, n3, gg, nullptr, 4, 0)) return -1;
+        g.named.erase(b + ".ff.net.0.proj");          // the projection itself is never materialised
+        g.named[b + ".ff.geglu"] = gg;
+    } else {
+        if (g.add_conv(b + ".ff.net.0.proj", w1, b1, C, 8 * C, 1, 1, 0, n3, f1, nullptr, 0, 0)) return -1;
+        g.add_geglu(b + ".ff.geglu", f1, gg);
+    }
     if (g.add_conv(b + ".ff.net.2", w2, b2, 4 * C, C, 1, 1, 0, gg, h3, &h2, 0, 0)) return -1;
     const float* wo = sd.get(p + ".proj_out.weight", (size_t)C * C);
     const float* bo = sd.get(p + ".proj_out.bias", C);
@@ -455,6 +497,50 @@ int mt_build_unet(MtGraph& g, const ltk_named_tensor* t, int n, MtTensor* latent
     *latent_in = g.alloc(8, 32, 32);         // 16-channel block, 8 real
     *ctx_in = g.alloc(384, 50, 1);
     g.named["latent_in"] = *latent_in;
+
+    // Hoisted cross-attention k | v (MT_FUSE bit 1): the k and v projections of the 16 cross-attentions read the audio context
+    // only, so they are ONE stacked 384 -> 25 600 projection at the head of the pass (rows [k_0 | v_0 | k_1 | v_1 ...], heads padded
+    // as in build_attention) and ONE launch that transposes the 16 value tensors - instead of 16 + 16 launches on the critical
+    // path of their blocks (320 us of a 16-frame pass).
+    if (knob(K_MT_FUSE) & 2) {
+        struct Blk { std::string p; int C; };
+        std::vector<Blk> blks;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) blks.push_back({"down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), ch[i]});
+        blks.push_back({"mid_block.attentions.0", 1280});
+        const int revc[4] = {1280, 1280, 640, 320};
+        for (int i = 1; i < 4; ++i) for (int j = 0; j < 3; ++j) blks.push_back({"up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), revc[i]});
+        int total = 0;
+        for (const Blk& b : blks) total += 2 * 8 * up16(b.C / 8);
+        std::vector<float> wall((size_t)total * 384);
+        size_t row = 0;
+        std::vector<int> offs;
+        for (const Blk& b : blks) {
+            const std::string a = b.p + ".transformer_blocks.0.attn2";
+            const int d = b.C / 8, d16 = up16(d);
+            const float* wk = sd.get(a + ".to_k.weight", (size_t)b.C * 384);
+            const float* wv = sd.get(a + ".to_v.weight", (size_t)b.C * 384);
+            if (!wk || !wv) { g.err = sd.err; return -1; }
+            const std::vector<float> wkp = pad_heads_rows(wk, b.C, 384, 8, d, d16, 1.f), wvp = pad_heads_rows(wv, b.C, 384, 8, d, d16, 1.f);
+            offs.push_back((int)row);
+            memcpy(&wall[row * 384], wkp.data(), wkp.size() * sizeof(float)); row += (size_t)8 * d16;
+            memcpy(&wall[row * 384], wvp.data(), wvp.size() * sizeof(float)); row += (size_t)8 * d16;
+        }
+        MtTensor kv_all = g.alloc(total, 50, 1);
+        if (g.add_conv("attn2.to_kv_all", wall.data(), nullptr, 384, total, 1, 1, 0, *ctx_in, kv_all, nullptr, 0, 0)) return -1;
+        MtOp vt;
+        vt.type = OP_VT; vt.name = "attn2.v_transpose_all";
+        for (size_t bi = 0; bi < blks.size(); ++bi) {
+            const int d16 = up16(blks[bi].C / 8), Cp = 8 * d16;
+            MtGraph::KvPre pre;
+            pre.k = MtGraph::view(kv_all, offs[bi], Cp);
+            pre.v = MtGraph::view(kv_all, offs[bi] + Cp, Cp);
+            pre.vt_buf = (int)g.buf_halfs.size();
+            g.buf_halfs.push_back((size_t)8 * attn_dv32(d16) * attn_tkp(50));
+            g.kv_pre[blks[bi].p + ".transformer_blocks.0.attn2"] = pre;
+            g.vt_items.push_back({pre.v, 8, d16, 50, pre.vt_buf});
+        }
+        g.ops.push_back(vt);
+    }
 
     // skip tensors live inside the cat buffers of the up path: plan those first (pop order of down_block_res_samples)
     struct SkipSpec { int C, HW; };
@@ -780,77 +866,111 @@ void mt_graph_free(MtGraph& g) {
 
 f16* mt_ptr(const MtGraph& g, const MtTensor& t) { return g.bufs[t.buf]; }
 
+// one op on stream `s`
+static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
+    switch (op.type) {
+        case OP_CONV: {
+            ConvIO io;
+            io.x = g.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
+            if (op.x.q8) { io.x_ld /= 2; io.x_coff /= 2; }      // 16-bit units of the fp8 tensor (conv_mfma.h: ConvPlan::q8)
+            io.y = g.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
+            io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
+            io.relu = 0; io.act = op.act; io.ups = op.ups;
+            io.partial = partial; io.partial_cap = partial_cap;
+            // U-Net resnet convs of a <= 16-frame pass: conv3's items-per-CU rule settles on tiles that re-read weights (8x8, 32x32 levels) or
+            // under-fill the chip (16x16 level); measured per level with the tile forced for every 3x3 launch (profiles/r02_mt_tile_force_ab.txt:
+            // 8x8 1280..2560 ch 116 -> 89 us at 256-px tiles, 16x16 640 ch 67 -> 49 us at 128-px tiles, 32x32 320 ch 55 -> 44 us at 256-px tiles).
+            // The VAE decoder keeps the rule (it wants its 512-px tiles).
+            // (The 4x4 level keeps the rule: forced 256-px tiles measured 31 -> 37 us there, profiles/r04_mt_rowconv_tile_ab.txt.)
+            if (op.unet3x3 && nf <= 16 && knob(K_MT_TILE_TABLE) && op.x.P() >= 64) io.force_pxw = op.x.P() == 256 ? 1 : 2;
+            std::string e;
+            int rc;
+            if (op.rplan >= 0 && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
+                RowConvIO rio;
+                rio.x = io.x; rio.x_ld = op.x.ld; rio.x_coff = op.x.coff; rio.H = op.x.H; rio.W = op.x.W;
+                rio.y = io.y; rio.y_ld = op.y.ld; rio.y_coff = op.y.coff; rio.Ho = op.y.H; rio.Wo = op.y.W;
+                rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
+                rio.N = nf; rio.KW = op.ksz; rio.stride = 1; rio.pad = op.ksz / 2; rio.relu = 0;
+                rc = rowconv_launch(g.rplans[op.rplan], rio, s, &e);
+            } else {
+                rc = conv_launch(g.plans[op.plan], io, s, &e);
+            }
+            if (rc) { g.err = op.name + ": " + e; return rc; }
+            break;
+        }
+        case OP_GN: {
+            const int P = op.x.P();
+            if (knob(K_MT_GN1) && gn_group_fits(op.x.C, P, op.groups)) {      // one launch: block = (image, group)
+                launch_gn_group(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.vecs[op.gamma],
+                                g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.q8 ? op.y.ld / 32 : op.y.ld / 16,
+                                op.y.q8 ? op.y.coff / 32 : op.y.coff / 16, op.y.q8 ? 1 : 0, g.fp8_ascale, s);
+                break;
+            }
+            const int segs = gn_segments(nf, op.x.C, P);
+            launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
+            if (op.y.q8)
+                launch_gn_apply_fp8(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)g.bufs[op.y.buf],
+                                    op.y.ld / 32, op.y.coff / 32, s);
+            else
+                launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+            break;
+        }
+        case OP_LN:
+            launch_layernorm(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), op.eps, g.vecs[op.gamma],
+                             g.vecs[op.beta], g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+            break;
+        case OP_VT: {
+            VtMulti m;
+            m.n = (int)g.vt_items.size(); m.Tk = g.vt_items.empty() ? 0 : g.vt_items[0].Tk; m.Tkp = 0;
+            if (m.n > 16) { g.err = "too many hoisted value tensors"; return -1; }
+            for (int i = 0; i < m.n; ++i) {
+                const MtVtItem& it = g.vt_items[i];
+                m.it[i] = {g.bufs[it.v.buf], g.bufs[it.vt_buf], it.v.ld / 16, it.v.coff / 16, it.heads, it.d16, 0, 0};
+            }
+            launch_v_transpose_multi(m, nf, s);
+            break;
+        }
+        case OP_ATTN: {
+            f16* vt = g.vt;
+            if (op.vt_buf >= 0) vt = g.bufs[op.vt_buf];
+            else launch_v_transpose(g.bufs[op.v.buf], nf, op.v.ld / 16, op.v.coff / 16, op.heads, op.d16, op.Tk, g.vt, s);
+            const int rc = launch_attention(g.bufs[op.x.buf], op.x.ld / 16, op.x.coff / 16, op.x.P(), g.bufs[op.k.buf], op.k.ld / 16,
+                                            op.k.coff / 16, op.Tk, vt, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, nf, op.heads,
+                                            op.d16, s);
+            if (rc) { g.err = op.name + ": attention launch failed (head dim " + std::to_string(op.d16) + ")"; return rc; }
+            break;
+        }
+        case OP_ADDPOS:
+            launch_add_pos(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), g.vecs[op.gamma], s);
+            break;
+        case OP_GEGLU:
+            launch_geglu(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), g.bufs[op.y.buf], op.y.ld / 16,
+                         op.y.coff / 16, s);
+            break;
+    }
+    return 0;
+}
+
+static int mt_run_op(MtGraph& g, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
+    const int rc = mt_run_op_body(g, op, nf, partial, partial_cap, s);
+    if (!rc && g.sat_ctr && op.y.buf >= 0 && knob(K_SAT_CHECK)) {      // debug: what this op clamped to (or pushed past) the limit of its output type
+        const int gran = op.y.q8 ? 32 : 16;
+        launch_sat_scan(g.bufs[op.y.buf], nf, op.y.ld / gran, op.y.coff / gran, op.y.C / gran, op.y.P(), op.y.q8 ? 1 : 0, g.sat_ctr, s);
+    }
+    return rc;
+}
+
 // `evs` (measurement): one event in front of every op and one behind the last
 int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStream_t s, int op_begin, int op_end,
                  std::vector<hipEvent_t>* evs = nullptr) {
     if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
     if (op_end < 0) op_end = (int)g.ops.size();
     for (int oi = op_begin; oi < op_end; ++oi) {
-        const MtOp& op = g.ops[oi];
         if (evs) (void)hipEventRecord((*evs)[oi - op_begin], s);
-        switch (op.type) {
-            case OP_CONV: {
-                ConvIO io;
-                io.x = g.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
-                if (op.x.q8) { io.x_ld /= 2; io.x_coff /= 2; }      // 16-bit units of the fp8 tensor (conv_mfma.h: ConvPlan::q8)
-                io.y = g.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
-                io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
-                io.relu = 0; io.act = op.act; io.ups = op.ups;
-                io.partial = partial; io.partial_cap = partial_cap;
-                // U-Net resnet convs of a <= 16-frame pass: conv3's items-per-CU rule settles on tiles that re-read weights (8x8, 32x32 levels) or
-                // under-fill the chip (16x16 level); measured per level with the tile forced for every 3x3 launch (profiles/r02_mt_tile_force_ab.txt:
-                // 8x8 1280..2560 ch 116 -> 89 us at 256-px tiles, 16x16 640 ch 67 -> 49 us at 128-px tiles, 32x32 320 ch 55 -> 44 us at 256-px tiles).
-                // The VAE decoder keeps the rule (it wants its 512-px tiles).
-                // (The 4x4 level keeps the rule: forced 256-px tiles measured 31 -> 37 us there, profiles/r04_mt_rowconv_tile_ab.txt.)
-                if (op.unet3x3 && nf <= 16 && knob(K_MT_TILE_TABLE) && op.x.P() >= 64) io.force_pxw = op.x.P() == 256 ? 1 : 2;
-                std::string e;
-                int rc;
-                if (op.rplan >= 0 && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
-                    RowConvIO rio;
-                    rio.x = io.x; rio.x_ld = op.x.ld; rio.x_coff = op.x.coff; rio.H = op.x.H; rio.W = op.x.W;
-                    rio.y = io.y; rio.y_ld = op.y.ld; rio.y_coff = op.y.coff; rio.Ho = op.y.H; rio.Wo = op.y.W;
-                    rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
-                    rio.N = nf; rio.KW = op.ksz; rio.stride = 1; rio.pad = op.ksz / 2; rio.relu = 0;
-                    rc = rowconv_launch(g.rplans[op.rplan], rio, s, &e);
-                } else {
-                    rc = conv_launch(g.plans[op.plan], io, s, &e);
-                }
-                if (rc) { g.err = op.name + ": " + e; return rc; }
-                break;
-            }
-            case OP_GN: {
-                const int P = op.x.P();
-                const int segs = gn_segments(nf, op.x.C, P);
-                launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
-                if (op.y.q8)
-                    launch_gn_apply_fp8(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
-                                        g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)g.bufs[op.y.buf],
-                                        op.y.ld / 32, op.y.coff / 32, s);
-                else
-                    launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
-                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
-                break;
-            }
-            case OP_LN:
-                launch_layernorm(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), op.eps, g.vecs[op.gamma],
-                                 g.vecs[op.beta], g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
-                break;
-            case OP_ATTN: {
-                launch_v_transpose(g.bufs[op.v.buf], nf, op.v.ld / 16, op.v.coff / 16, op.heads, op.d16, op.Tk, g.vt, s);
-                const int rc = launch_attention(g.bufs[op.x.buf], op.x.ld / 16, op.x.coff / 16, op.x.P(), g.bufs[op.k.buf], op.k.ld / 16,
-                                                op.k.coff / 16, op.Tk, g.vt, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, nf, op.heads,
-                                                op.d16, s);
-                if (rc) { g.err = op.name + ": attention launch failed (head dim " + std::to_string(op.d16) + ")"; return rc; }
-                break;
-            }
-            case OP_ADDPOS:
-                launch_add_pos(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), g.vecs[op.gamma], s);
-                break;
-            case OP_GEGLU:
-                launch_geglu(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), g.bufs[op.y.buf], op.y.ld / 16,
-                             op.y.coff / 16, s);
-                break;
-        }
+        const int rc = mt_run_op(g, g.ops[oi], nf, partial, partial_cap, s);
+        if (rc) return rc;
     }
     if (evs) (void)hipEventRecord((*evs)[op_end - op_begin], s);
     if (hipGetLastError() != hipSuccess) { g.err = "a MuseTalk kernel launch failed"; return -2; }
@@ -877,6 +997,7 @@ void mt_graph_delete(MtGraph* g) {
 }
 const char* mt_graph_error(const MtGraph* g) { return g->err.c_str(); }
 
+void mt_set_sat_counter(MtGraph* g, unsigned long long* d_ctr) { g->sat_ctr = d_ctr; }
 void mt_set_fp8(MtGraph* g, int on, float act_scale) { g->fp8 = on != 0; if (act_scale > 0.f) g->fp8_ascale = act_scale; }
 double mt_macs_fp8_per_frame(const MtGraph* g) { return g->macs_fp8; }
 

@@ -23,6 +23,13 @@ void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P
                          int segs, const float* gamma, const float* beta, int silu, float out_scale, unsigned char* y, int y_cbt,
                          int y_cb0, hipStream_t s);
 
+// GroupNorm in ONE launch, block = (image, group): for maps whose (image, group) fits one block's registers (gn_group_fits: even
+// channels per group, pixels x channels-per-group <= 30 720).  fp8 != 0: e4m3 output as launch_gn_apply_fp8 (y_cbt / y_cb0 in
+// 32-channel blocks)
+bool gn_group_fits(int C, int P, int groups);
+void launch_gn_group(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* gamma, const float* beta,
+                     int silu, f16* y, int y_cbt, int y_cb0, int fp8, float out_scale, hipStream_t s);
+
 // ---- LayerNorm over channels per token (BasicTransformerBlock.norm1/2/3, Whisper layer norms)
 void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float eps, const float* gamma, const float* beta,
                       f16* y, int y_cbt, int y_cb0, hipStream_t s);
@@ -33,6 +40,12 @@ void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float
 int attn_dv32(int d16);
 int attn_tkp(int Tk);
 void launch_v_transpose(const f16* v, int N, int cbt, int cb0, int heads, int d16, int Tk, f16* vt, hipStream_t s);
+// several value tensors over the same Tk keys in ONE launch (h0 / dv32 / Tkp are filled in by the launcher)
+struct VtMulti {
+    struct Item { const f16* v; f16* vt; int cbt, cb0, heads, d16, dv32, h0; } it[16];
+    int n, Tk, Tkp;
+};
+void launch_v_transpose_multi(VtMulti m, int N, hipStream_t s);
 int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, int k_cbt, int k_cb0, int Tk, const f16* vt,
                      f16* o, int o_cbt, int o_cb0, int N, int heads, int d16, hipStream_t s);
 

@@ -12,6 +12,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 namespace ltk {
 
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
@@ -180,6 +182,94 @@ void launch_gn_apply_fp8(const f16* x, int N, int x_cbt, int x_cb0, int C, int P
                        partial, segs, gamma, beta, silu, reinterpret_cast<f16*>(y), y_cbt, y_cb0, out_scale);
 }
 
+// One launch per GroupNorm for the maps whose whole (image, group) fits the registers of one block (the U-Net's 32^2 .. 4^2 maps,
+// the VAE's 512-channel 32^2 maps): block = (image, group).  A thread owns ONE channel pair of the group (one dword per pixel:
+// groups of C/32 = 10, 20, 30 ... channels start at any even channel of a 16-channel block) and every (256 / L)-th pixel, L = the
+// power of two >= pairs per group; it keeps its <= KMAX dwords from the single read pass (fixed base pointer, constant stride),
+// the block reduces sum / sum of squares in a fixed order, and the same registers are normalised, activated and stored - one read
+// instead of two, one launch instead of two (61 of the 495 launches of a 16-frame U-Net pass were gn_stats).  Statistics are
+// summed per thread, per wave, per block: another fp32 order than gn_stats + gn_apply (per channel, then per group), same formula.
+template <int KMAX, int NT, bool FP8>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int P, int cpg, int log2L,
+                                                       float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int silu, f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale, int groups) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int j = tid & ((1 << log2L) - 1), slot = tid >> log2L;
+    const int ppi = NT >> log2L;                        // pixels per iteration
+    const bool live = 2 * j < cpg && slot < P;
+    const int c = g * cpg + 2 * (live ? j : 0);
+    const unsigned* xp = reinterpret_cast<const unsigned*>(x + ((size_t)(n * x_cbt + x_cb0 + (c >> 4)) * P + (live ? slot : 0)) * 16 + (c & 15));
+    const int stride = ppi * 8;                         // dwords between this thread's pixels
+    const int iters = live ? (P - slot + ppi - 1) / ppi : 0;
+    unsigned v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = (k < iters) ? xp[k * stride] : 0u;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const __half2 h = *reinterpret_cast<const __half2*>(&v[k]);
+        const float f0 = __low2float(h), f1 = __high2float(h);
+        s += f0 + f1;
+        q += f0 * f0 + f1 * f1;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); q += __shfl_xor(q, m); }
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = q; }
+    __syncthreads();
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { S += red[w][0]; Q += red[w][1]; }          // fixed order
+    const float cnt = (float)cpg * (float)P;
+    const float mean = S / cnt;
+    const float rstd = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + eps);
+    const float a0 = gamma[c] * rstd, a1 = gamma[c + 1] * rstd;
+    const float b0 = beta[c] - mean * a0, b1 = beta[c + 1] - mean * a1;
+    const int slot0 = live ? slot : 0;
+    unsigned* yp = reinterpret_cast<unsigned*>(y + ((size_t)(n * y_cbt + y_cb0 + (c >> 4)) * P + slot0) * 16 + (c & 15));
+    unsigned short* yq = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(y) + ((size_t)(n * y_cbt + y_cb0 + (c >> 5)) * P + slot0) * 32 + (c & 31));
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < iters) {
+            const __half2 h = *reinterpret_cast<const __half2*>(&v[k]);
+            float t0 = __low2float(h) * a0 + b0;
+            float t1 = __high2float(h) * a1 + b1;
+            if (silu) { t0 = silu_f(t0); t1 = silu_f(t1); }
+            if (FP8) {
+                const float f0 = fminf(fmaxf(t0 * out_scale, -448.f), 448.f), f1 = fminf(fmaxf(t1 * out_scale, -448.f), 448.f);
+                const int w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+                yq[(size_t)k * ppi * 16] = (unsigned short)(w & 0xffff);
+            } else {
+                const __half2 o = __floats2half2_rn(t0, t1);
+                yp[k * stride] = *reinterpret_cast<const unsigned*>(&o);
+            }
+        }
+    }
+}
+
+static int gn_group_log2L(int cpg) { int l = 0; while ((1 << l) < cpg / 2) ++l; return l; }
+
+bool gn_group_fits(int C, int P, int groups) {
+    const int cpg = C / groups;
+    if (C % groups || (cpg & 1) || cpg > 128) return false;
+    return ((long long)P << gn_group_log2L(cpg)) <= 16 * 1024;        // <= 16 dwords per thread of a 1024-thread block
+}
+
+void launch_gn_group(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* gamma, const float* beta,
+                     int silu, f16* y, int y_cbt, int y_cb0, int fp8, float out_scale, hipStream_t s) {
+    const int cpg = C / groups, l2 = gn_group_log2L(cpg);
+    const long long work = (long long)P << l2;           // thread slots one (image, group) needs
+    const dim3 grid((unsigned)(N * groups));
+#define GNG(K, NT, F) hipLaunchKernelGGL((gn_group_kernel<K, NT, F>), grid, dim3(NT), 0, s, x, x_cbt, x_cb0, P, cpg, l2, eps, gamma, beta, silu, y, y_cbt, y_cb0, out_scale, groups)
+    // small maps: 256-thread blocks (<= 8 dwords per thread); the 32^2 / 16^2 maps: 1024-thread blocks, so that a thread's chain of
+    // loads stays <= 16 deep (256-thread blocks with 32..64 loads per thread measured 17-24 us per launch on the 32^2 level)
+    if (fp8) { if (work <= 2048) GNG(8, 256, true); else if (work <= 8192) GNG(8, 1024, true); else GNG(16, 1024, true); }
+    else { if (work <= 2048) GNG(8, 256, false); else if (work <= 8192) GNG(8, 1024, false); else GNG(16, 1024, false); }
+#undef GNG
+}
+
 // =============================================================================================== LayerNorm
 // 16 tokens x 16 channel slices per block: the transformer maps are small (1024 / 256 / 64 tokens per image), so the grid
 // needs short blocks to cover 256 CUs (64-token blocks left the 32^2 level at one block per CU, 1 TB/s)
@@ -233,12 +323,9 @@ int attn_tkp(int Tk) { return (Tk + 63) / 64 * 64; }
 
 // V [N][cbt][Tk][16] (head h at blocks cb0 + h*d16/16) -> VT [N][heads][dv32][Tkp], channel-major, the 16 keys of
 // every group in MFMA B-operand slot order {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}; padding rows / keys are zero.
-__global__ __launch_bounds__(256) void v_transpose_kernel(const f16* __restrict__ v, int cbt, int cb0, int heads, int d16, int dv32,
-                                                           int Tk, int Tkp, f16* __restrict__ vt) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_vt[];
-    f16* tile = reinterpret_cast<f16*>(smem_vt);         // [d16][66]
+__device__ __forceinline__ void v_transpose_body(const f16* __restrict__ v, int cbt, int cb0, int heads, int d16, int dv32, int Tk, int Tkp,
+                                                 f16* __restrict__ vt, int key0, int h, int n, f16* tile) {
     const int tid = threadIdx.x;
-    const int key0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
     const int ncb = d16 >> 4;
     const f16* vb = v + ((size_t)(n * cbt + cb0 + h * ncb) * Tk) * 16;
     for (int i = tid; i < ncb * 128; i += 256) {
@@ -266,6 +353,30 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const f16* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void v_transpose_kernel(const f16* __restrict__ v, int cbt, int cb0, int heads, int d16, int dv32,
+                                                           int Tk, int Tkp, f16* __restrict__ vt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_vt[];
+    v_transpose_body(v, cbt, cb0, heads, d16, dv32, Tk, Tkp, vt, blockIdx.x * 64, blockIdx.y, blockIdx.z, reinterpret_cast<f16*>(smem_vt));   // tile [d16][66]
+}
+
+// the value tensors of several attentions over the SAME keys (the 16 cross-attentions of MuseTalk's U-Net: views of one stacked
+// k | v projection of the audio context) in one launch: blockIdx.y walks the heads of all of them
+__global__ __launch_bounds__(256) void v_transpose_multi_kernel(const VtMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_vt[];
+    int it = 0;
+    while (it + 1 < m.n && (int)blockIdx.y >= m.it[it + 1].h0) ++it;
+    const VtMulti::Item& a = m.it[it];
+    v_transpose_body(a.v, a.cbt, a.cb0, a.heads, a.d16, a.dv32, m.Tk, m.Tkp, a.vt, blockIdx.x * 64, blockIdx.y - a.h0, blockIdx.z,
+                     reinterpret_cast<f16*>(smem_vt));
+}
+
+void launch_v_transpose_multi(VtMulti m, int N, hipStream_t s) {
+    int heads = 0, dmax = 0;
+    for (int i = 0; i < m.n; ++i) { m.it[i].h0 = heads; heads += m.it[i].heads; m.it[i].dv32 = attn_dv32(m.it[i].d16); dmax = std::max(dmax, m.it[i].d16); }
+    m.Tkp = attn_tkp(m.Tk);
+    hipLaunchKernelGGL(v_transpose_multi_kernel, dim3(m.Tkp / 64, heads, N), dim3(256), (size_t)dmax * 66 * sizeof(f16), s, m);
+}
+
 void launch_v_transpose(const f16* v, int N, int cbt, int cb0, int heads, int d16, int Tk, f16* vt, hipStream_t s) {
     const int dv32 = attn_dv32(d16), Tkp = attn_tkp(Tk);
     hipLaunchKernelGGL(v_transpose_kernel, dim3(Tkp / 64, heads, N), dim3(256), (size_t)d16 * 66 * sizeof(f16), s, v, cbt, cb0, heads,
@@ -282,7 +393,7 @@ struct AttnArgs {
 // holds 16 keys of ONE query, so the softmax statistics are per lane (+ one exchange with the partner lane), and
 // the probabilities already sit in B-operand order for O^T += V^T P^T.  SHARE: the 4 waves of a block take the
 // same query tile and a quarter of the value channels each (head dim 512 of the VAE mid-block attention).
-template <int DT, int DVT, bool SHARE>
+template <int DT, int DVT, bool SHARE, bool PF = false>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -309,49 +420,93 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float m = -1e30f, l = 0.f;
 
-    for (int key0 = 0; key0 < Tk; key0 += 32) {
+    // Round 6: (a) PF: the K and V^T fragments of key tile t+1 are loaded while tile t is computed (register double buffer; they were
+    // loaded right in front of their MFMAs: one exposed L2 round trip per tile and contraction; knob ATTN_PF, head dims <= 80); (b) the key-range mask is a
+    // wave-uniform branch taken on a ragged last tile only; (c) the running maximum rarely moves after the first tiles: the
+    // accumulators are rescaled only when some lane's maximum did (wave-uniform test), with alpha == 1 exactly otherwise.
+    // Values are identical to the straight loop: (a) and (b) change no arithmetic, (c) skips multiplications by exactly 1.0f.
+    constexpr int KF = SHARE ? 1 : DT;
+    struct Frag { f16x8 k[KF], v[2][DVT]; };
+    auto load_tile = [&](int key0, Frag& f) {
         const int krow = min(key0 + l31, Tk - 1);
+        if constexpr (!SHARE) {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) f.k[j] = *reinterpret_cast<const f16x8*>(kb + ((size_t)j * Tk + krow) * 16);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) f.v[s2][t] = *reinterpret_cast<const f16x8*>(vtb + (size_t)t * 32 * Tkp + key0 + s2 * 16);
+    };
+    auto tile = [&](int key0, const Frag& f) {
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        if constexpr (SHARE) {
+            const int krow = min(key0 + l31, Tk - 1);
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + ((size_t)j * Tk + krow) * 16);
-            f16x8 qj;
-            if constexpr (SHARE) qj = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
-            else qj = qf[j];
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qj, st, 0, 0, 0);
+            for (int j = 0; j < DT; ++j) {
+                const f16x8 kj = *reinterpret_cast<const f16x8*>(kb + ((size_t)j * Tk + krow) * 16);
+                const f16x8 qj = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kj, qj, st, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.k[j], qf[j], st, 0, 0, 0);
+        }
+        if (key0 + 32 > Tk) {                   // ragged last tile (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                if (key >= Tk) st[r] = -1e30f;
+            }
         }
         float mx = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 8 * (r >> 2) + 4 * hh + (r & 3);
-            if (key >= Tk) st[r] = -1e30f;
-            mx = fmaxf(mx, st[r]);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);
         float ls = 0.f;
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
-        l = l * alpha + ls;
+        if (__any(m_new > m)) {
+            const float alpha = __expf(m - m_new);
+            l = l * alpha;
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+        }
+        l += ls;
         m = m_new;
-#pragma unroll
-        for (int t = 0; t < DVT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { pf[r] = (f16)p[8 * s + r]; pf[4 + r] = (f16)p[8 * s + 4 + r]; }
 #pragma unroll
-            for (int t = 0; t < DVT; ++t) {
-                const f16x8 vf = *reinterpret_cast<const f16x8*>(vtb + (size_t)t * 32 * Tkp + key0 + s * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc[t], 0, 0, 0);
+            for (int t = 0; t < DVT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[s][t], pf, acc[t], 0, 0, 0);
+        }
+    };
+    // two tiles per trip, so that the double buffer is two NAMED register sets (a runtime buffer index would send them to scratch)
+    if constexpr (PF) {
+        Frag fa, fb;
+        load_tile(0, fa);
+        for (int key0 = 0; key0 < Tk; key0 += 64) {
+            const bool second = key0 + 32 < Tk;
+            if (second) load_tile(key0 + 32, fb);
+            tile(key0, fa);
+            if (second) {
+                if (key0 + 64 < Tk) load_tile(key0 + 64, fa);
+                tile(key0 + 32, fb);
             }
+        }
+    } else {
+        for (int key0 = 0; key0 < Tk; key0 += 32) {
+            Frag f;
+            load_tile(key0, f);
+            tile(key0, f);
         }
     }
     const float inv = 1.f / (l + __shfl_xor(l, 32));
@@ -514,9 +669,18 @@ int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, i
     const int qtiles = (Tq + 31) / 32;
     const dim3 grid4((qtiles + 3) / 4, heads, N), grid1(qtiles, heads, N);
     switch (d16) {
-        case 48: hipLaunchKernelGGL((attn_kernel<3, 2, false>), grid4, dim3(256), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((attn_kernel<4, 2, false>), grid4, dim3(256), 0, s, a); break;
-        case 80: hipLaunchKernelGGL((attn_kernel<5, 3, false>), grid4, dim3(256), 0, s, a); break;
+        case 48:
+            if (knob(K_ATTN_PF)) hipLaunchKernelGGL((attn_kernel<3, 2, false, true>), grid4, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_kernel<3, 2, false>), grid4, dim3(256), 0, s, a);
+            break;
+        case 64:
+            if (knob(K_ATTN_PF)) hipLaunchKernelGGL((attn_kernel<4, 2, false, true>), grid4, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_kernel<4, 2, false>), grid4, dim3(256), 0, s, a);
+            break;
+        case 80:
+            if (knob(K_ATTN_PF)) hipLaunchKernelGGL((attn_kernel<5, 3, false, true>), grid4, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_kernel<5, 3, false>), grid4, dim3(256), 0, s, a);
+            break;
         case 160: hipLaunchKernelGGL((attn_kernel<10, 5, false>), grid4, dim3(256), 0, s, a); break;
         case 512:
             if (knob(K_ATTN_WIDE)) hipLaunchKernelGGL(attn_wide_kernel, grid1, dim3(256), 0, s, a);
@@ -541,7 +705,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const f16* __restrict__ x, i
     const f16x8 gv = *reinterpret_cast<const f16x8*>(x + ((size_t)(n * x_cbt + x_cb0 + CB + cb) * P + p) * 16 + half * 8);
     f16x8 o;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (f16)((float)av[c] * gelu_f((float)gv[c]));
+    for (int c = 0; c < 8; ++c) o[c] = (f16)((float)av[c] * gelu_as((float)gv[c]));
     *reinterpret_cast<f16x8*>(y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p) * 16 + half * 8) = o;
 }
 

@@ -62,6 +62,17 @@ enum Knob {
     K_AUDIO_ROWCONV,      // LTK_AUDIO_ROWCONV  audio-encoder 3 x 3 layers whose output map has at most this many pixels per frame run as weight-streaming GEMMs over
                           //                    gathered rows (rowconv, row / column strides) in launches of <= ROWCONV rows: 54 (default) = audio_encoder.6 .. .10,
                           //                    9 = .9 / .10 only, 0 = none (first-generation kernel / conv3 + split-K finish: rounds 1-4)
+    K_MT_FUSE,            // LTK_MT_FUSE        MuseTalk program, read when the program is BUILT (weights are packed for it): bit 0 = GEGLU in the epilogue of
+                          //                    ff.net.0.proj (no 8C-wide intermediate, no geglu launch); bit 1 = the k | v projections of the 16 cross-attentions
+                          //                    (they read the audio context only) as ONE stacked projection + ONE value-transpose launch at the head of the pass;
+                          //                    0 = the launch list of rounds 2-5
+    K_MT_GN1,             // LTK_MT_GN1         1 (default): GroupNorm of the maps whose (image, group) fits one block's registers (U-Net levels, the VAE's 32^2
+                          //                    maps) as ONE launch (nn_kernels.hip gn_group_kernel) instead of gn_stats + gn_apply
+    K_ATTN_PF,            // LTK_ATTN_PF        1 (default): multi-head attention (head dims 48 / 64 / 80) loads the K / V^T fragments of key tile t+1 while tile t
+                          //                    is computed (register double buffer); 0: loaded in front of their MFMAs (rounds 2-5)
+    K_SAT_CHECK,          // LTK_SAT_CHECK      debug, default 0: behind every layer / op its output is scanned for values AT the limit of its type (what an epilogue's
+                          //                    clamp to +-65504 leaves behind; +-448 for e4m3) and for non-finite values; counters through ltk_debug_saturation.
+                          //                    The fused Wav2Lip head (which writes bytes) runs unfused under it.
     K_COUNT
 };
 

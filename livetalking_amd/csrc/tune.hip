@@ -38,6 +38,10 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
     {"LTK_AUDIO_ROWCONV", 54},
+    {"LTK_MT_FUSE", 3},
+    {"LTK_MT_GN1", 1},
+    {"LTK_ATTN_PF", 1},
+    {"LTK_SAT_CHECK", 0},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -268,7 +268,7 @@ class Engine:
         return macs.value, macs8.value
 
     def musetalk_ops(self):
-        """[(name, type)] of the MuseTalk launch program; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos."""
+        """[(name, type)] of the MuseTalk launch program; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos, 6 value transpose."""
         out = []
         for i in range(self._lib.ltk_musetalk_op_count(self._h)):
             buf, t = C.create_string_buffer(160), C.c_int()
@@ -338,6 +338,13 @@ class Engine:
         """Process-wide tuning knob (csrc/tune.h); sweeps and A/B tests only."""
         lib = _lib.load()
         _lib.check(lib.ltk_debug_set_knob(name.encode(), int(value)))
+
+    def saturation(self, reset: bool = True):
+        """(values at the fp16 / e4m3 limit, non-finite values) seen in layer / op outputs since the last reset; counted only while
+        knob SAT_CHECK is on (include/ltk.h: ltk_debug_saturation)."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _lib.check(self._lib.ltk_debug_saturation(self._h, 1 if reset else 0, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def debug_capture(self, enable: bool):
         _lib.check(self._lib.ltk_debug_capture(self._h, 1 if enable else 0))

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth_inputs as synth  # noqa: E402
 from livetalking_amd.engine import Engine  # noqa: E402
 
-TYPES = ["conv/linear", "GroupNorm", "LayerNorm", "attention", "GEGLU", "add-pos"]
+TYPES = ["conv/linear", "GroupNorm", "LayerNorm", "attention", "GEGLU", "add-pos", "v-transpose"]
 
 
 def main():
