@@ -84,7 +84,9 @@ def main():
         f.write("# last inference pass of the profiled run: start_us dur_us stream grid lds_bytes kernel\n")
         if ends:
             last = ends[-1]
-            first = ends[-2] + 1 if len(ends) > 1 else 0
+            # LIST_PASSES=2: the last TWO end-delimited segments (a staggered MuseTalk call ends twice: once per half-batch)
+            back = 1 + int(os.environ.get("LIST_PASSES", "1"))
+            first = ends[-back] + 1 if len(ends) >= back else 0
             # the pointer-table upload belongs to the pass it precedes; skip host-side blits between passes
             seg = [r for r in rows[first:last + 1] if "__amd_rocclr" not in r[0]]
             t0 = seg[0][1]

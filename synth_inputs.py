@@ -54,8 +54,14 @@ def _layers():
 OUTPUT_HEAD_PREFIX = "output_block.1"
 
 
-def wav2lip_state_dict(seed: int = 1234) -> Dict[str, np.ndarray]:
-    """Reference-named fp32 state_dict as numpy arrays (380 tensors)."""
+def wav2lip_state_dict(seed: int = 1234, gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Reference-named fp32 state_dict as numpy arrays (380 tensors).
+
+    `gain` (parity-stress family, tests/test_parity_stress_gpu.py): the BatchNorm affine of the two input layers
+    (face_encoder_blocks.0.0, audio_encoder.0) is multiplied by it, so every activation behind them grows about
+    linearly with it (peak |activation| of the fp32 forward: ~70 at gain 1, ~1.2e3 at 16, ~1.9e4 at 256, past the
+    fp16 limit 65 504 from ~1024 on), and the output head's weights are divided by it so that the sigmoid keeps
+    working across its range.  gain = 1 is the draw every other test uses."""
     rng = np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     for prefix, kind, cin, cout, k, sprod, residual in _layers():
@@ -79,6 +85,12 @@ def wav2lip_state_dict(seed: int = 1234) -> Dict[str, np.ndarray]:
     # output head: plain conv 32->3; scaled so the sigmoid is used across its range
     sd[OUTPUT_HEAD_PREFIX + ".weight"] = (rng.standard_normal((3, 32, 1, 1)) * 0.04).astype(np.float32)
     sd[OUTPUT_HEAD_PREFIX + ".bias"] = (rng.standard_normal(3) * 0.2).astype(np.float32)
+    if gain != 1.0:
+        g = np.float32(gain)
+        for p in ("face_encoder_blocks.0.0", "audio_encoder.0"):
+            sd[p + ".conv_block.1.weight"] = sd[p + ".conv_block.1.weight"] * g
+            sd[p + ".conv_block.1.bias"] = sd[p + ".conv_block.1.bias"] * g
+        sd[OUTPUT_HEAD_PREFIX + ".weight"] = sd[OUTPUT_HEAD_PREFIX + ".weight"] / g
     return sd
 
 
@@ -263,7 +275,22 @@ def _transformer(rng, sd, p, c, ctx):
     _conv(rng, sd, p + ".proj_out", c, c, 1, gain=0.5)
 
 
-def musetalk_unet_state_dict(seed: int = 4321, shapes_only: bool = False) -> Dict[str, np.ndarray]:
+def _gn_gain(sd, gain):
+    """Parity-stress family: the affine of every ResnetBlock2D GroupNorm (norm1 / norm2) times `gain`.  GroupNorm renormalises
+    whatever reaches it, so the network does not blow up: the tensors BETWEEN a norm and the next one (norm outputs, conv
+    outputs, the residual stream) grow about linearly with the gain - fp32 peak |activation| U-Net / VAE decoder: 13 / 14 at gain 1,
+    92 / 122 at 16, 1.5e3 / 1.9e3 at 256, 1.2e4 / 1.5e4 at 2048, past the fp16 limit at 16 384."""
+    if gain == 1.0:
+        return sd
+    import re
+    g = np.float32(gain)
+    for k in list(sd):
+        if re.search(r"resnets\.\d+\.norm[12]\.(weight|bias)$", k):
+            sd[k] = sd[k] * g
+    return sd
+
+
+def musetalk_unet_state_dict(seed: int = 4321, shapes_only: bool = False, gn_gain: float = 1.0) -> Dict[str, np.ndarray]:
     rng = _ShapeRng() if shapes_only else np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     ch = UNET_CH
@@ -297,10 +324,12 @@ def musetalk_unet_state_dict(seed: int = 4321, shapes_only: bool = False) -> Dic
             _conv(rng, sd, f"up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
     _norm(rng, sd, "conv_norm_out", cin)
     _conv(rng, sd, "conv_out", cin, 4, 3, gain=0.5)
+    if not shapes_only:
+        _gn_gain(sd, gn_gain)
     return _finish(sd, shapes_only)
 
 
-def vae_decoder_state_dict(seed: int = 987, shapes_only: bool = False) -> Dict[str, np.ndarray]:
+def vae_decoder_state_dict(seed: int = 987, shapes_only: bool = False, gn_gain: float = 1.0) -> Dict[str, np.ndarray]:
     rng = _ShapeRng() if shapes_only else np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
     _conv(rng, sd, "post_quant_conv", 4, 4, 1)
@@ -322,6 +351,8 @@ def vae_decoder_state_dict(seed: int = 987, shapes_only: bool = False) -> Dict[s
             _conv(rng, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
     _norm(rng, sd, "decoder.conv_norm_out", cin)
     _conv(rng, sd, "decoder.conv_out", cin, 3, 3, gain=0.7)
+    if not shapes_only:
+        _gn_gain(sd, gn_gain)
     return _finish(sd, shapes_only)
 
 
