@@ -320,12 +320,7 @@ struct ltk_engine {
     unsigned long graph_clock = 0;
     // captured MuseTalk / Whisper programs (run_program): the static launch list of a program over its persistent buffers, one
     // executable graph per (program, frame count); the kernels that carry per-call pointers stay outside the graph
-    std::map<std::pair<const void*, int>, PassGraph> prog_graphs;      // key.second = frames | arena << 16 | part << 20
-    // knob MT_STAGGER: a large MuseTalk pass as two half-batches on two streams (mt_enqueue_pass): the second half's split-K scratch and
-    // the events that order the two pipelines
-    float* d_partial_b = nullptr;
-    size_t partial_b_cap = 0;
-    hipEvent_t ev_mt[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::map<std::pair<const void*, int>, PassGraph> prog_graphs;
     unsigned prog_graph_epoch = 0;
     // debug capture
     bool capture = false;
@@ -993,8 +988,6 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_partial_aux) (void)hipFree(e->d_partial_aux);
     if (e->d_partial_pf) (void)hipFree(e->d_partial_pf);
     if (e->d_sat) (void)hipFree(e->d_sat);
-    if (e->d_partial_b) (void)hipFree(e->d_partial_b);
-    for (hipEvent_t ev : e->ev_mt) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_pf_done) (void)hipEventDestroy(e->ev_pf_done);
@@ -1932,21 +1925,18 @@ int ltk_musetalk_avatar_register(ltk_engine* e, const float* latents, const uint
 // every kernel's dynamic-LDS attribute, which a capture must not do).  The kernels that carry per-call pointers - latent / token
 // gather in front, uint8 frame writer behind - stay outside the graph.  What this buys is the host side: one launch per pass
 // instead of hundreds, on a host that also runs the sessions' Python.
-static int run_program(ltk_engine* e, MtGraph* prog, int nf, hipStream_t s = nullptr, int arena = 0, int part = 0, float* partial = nullptr,
-                       size_t partial_cap = 0) {
-    if (!s) s = e->compute;
-    if (!partial) { partial = e->d_partial; partial_cap = e->partial_cap; }
-    auto eager = [&]() { return mt_run_part(prog, nf, partial, partial_cap, s, arena, part); };
-    if (!knob(K_GRAPH)) return eager();
+static int run_program(ltk_engine* e, MtGraph* prog, int nf) {
+    hipStream_t s = e->compute;
+    if (!knob(K_GRAPH)) return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
     if (e->prog_graph_epoch != knob_epoch()) {
-        if (hipDeviceSynchronize() != hipSuccess) return -2;
+        if (hipStreamSynchronize(s) != hipSuccess) return -2;
         drop_prog_graphs(e);
         e->prog_graph_epoch = knob_epoch();
     }
-    ltk_engine::PassGraph& g = e->prog_graphs[{(const void*)prog, nf | (arena << 16) | (part << 20)}];
+    ltk_engine::PassGraph& g = e->prog_graphs[{(const void*)prog, nf}];
     g.stamp = ++e->graph_clock;
     if (g.exec) return hipGraphLaunch(g.exec, s) == hipSuccess ? 0 : -2;
-    if (g.seen < 0 || g.seen++ == 0) return eager();
+    if (g.seen < 0 || g.seen++ == 0) return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
     size_t live = 0;
     for (auto& kv : e->prog_graphs) live += kv.second.exec ? 1 : 0;
     if (live >= kMaxPassGraphs) {
@@ -1954,14 +1944,13 @@ static int run_program(ltk_engine* e, MtGraph* prog, int nf, hipStream_t s = nul
         for (auto it = e->prog_graphs.begin(); it != e->prog_graphs.end(); ++it)
             if (it->second.exec && (victim == e->prog_graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
         if (victim != e->prog_graphs.end()) {
-            if (hipDeviceSynchronize() != hipSuccess) return -2;
+            if (hipStreamSynchronize(s) != hipSuccess) return -2;
             (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
         }
     }
     hipGraph_t graph = nullptr;
-    // thread-local capture mode: another stream of this engine may be executing the other half-batch meanwhile
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); g.seen = -1; return eager(); }
-    const int rc = eager();
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); g.seen = -1; return mt_run(prog, nf, e->d_partial, e->partial_cap, s); }
+    const int rc = mt_run(prog, nf, e->d_partial, e->partial_cap, s);
     const hipError_t ce = hipStreamEndCapture(s, &graph);       // always: the stream must leave capture mode
     if (rc) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
     hipGraphExec_t exec = nullptr;
@@ -1972,81 +1961,28 @@ static int run_program(ltk_engine* e, MtGraph* prog, int nf, hipStream_t s = nul
         (void)hipGetLastError();
         g.seen = -1;
         fprintf(stderr, "ltk: hipGraph capture of a %d-frame program failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
-        return eager();
+        return mt_run(prog, nf, e->d_partial, e->partial_cap, s);
     }
     g.exec = exec;
     return hipGraphLaunch(exec, s) == hipSuccess ? 0 : -2;
 }
 
-// One MuseTalk pass of `nf` frames under e->mu.  lp / fp / op (or null: timing runs on whatever the buffers hold): per-frame latent,
-// audio-feature and output-frame pointers; d_feat (when fp is null): fp32 [nf][50][384] on the device; d_image_f32: test hook.
-// Knob MT_STAGGER (default 32): a pass of at least 2 x that many frames runs as TWO half-batches a | b, each in its own arena (a second
-// instance of every activation buffer, shared weights) on its own stream, b one phase behind a:
-//     compute : gather(a) U-Net(a) ............ VAE(a) write(a)
-//     aux     :                    gather(b) U-Net(b) ........ VAE(b) write(b)
-// The U-Net of a pass is a chain of ~390 launch-latency-bound launches (0.12 of the MFMA peak), the VAE decoder 90 throughput-bound
-// ones: side by side the second half's U-Net runs in the shadow of the first half's decoder (the overlap that knob PREFETCH gave
-// the Wav2Lip pass).  Each half is exactly the launch sequence a call of nf / 2 frames runs: frames are byte-identical to two calls of
-// that size.
-static int mt_enqueue_pass(ltk_engine* e, int nf, const PtrList64* lp, const PtrList64* fp, const float* d_feat, const OutList64* op,
-                           float* d_image_f32) {
-    auto half = [&](int f0, int n, int arena, hipStream_t s, float* partial, size_t cap, hipEvent_t after_unet, hipEvent_t wait_before_unet) -> int {
-        int cbt;
-        if (lp) {
-            PtrList64 l;
-            for (int i = 0; i < 64; ++i) l.p[i] = i < n ? lp->p[f0 + i] : nullptr;
-            f16* lat = mt_latent_in(e->mt, &cbt, arena);
-            launch_gather_latents(l, n, 8, 1024, lat, cbt, s);
-        }
-        f16* ctx = mt_ctx_in(e->mt, &cbt, arena);
-        if (fp) {
-            PtrList64 f;
-            for (int i = 0; i < 64; ++i) f.p[i] = i < n ? fp->p[f0 + i] : nullptr;
-            launch_tokens_gather_to_cb16(f, n, 50, 384, e->d_pe, ctx, cbt, s);
-        } else if (d_feat) {
-            launch_tokens_to_cb16(d_feat + (size_t)f0 * 50 * 384, n, 50, 384, e->d_pe, ctx, cbt, 0, s);
-        }
-        if (wait_before_unet && hipStreamWaitEvent(s, wait_before_unet, 0) != hipSuccess) return -2;
-        int rc;
-        if (after_unet) {
-            rc = run_program(e, e->mt, n, s, arena, 1, partial, cap);
-            if (!rc && hipEventRecord(after_unet, s) != hipSuccess) rc = -2;
-            if (!rc) rc = run_program(e, e->mt, n, s, arena, 2, partial, cap);
-        } else {
-            rc = run_program(e, e->mt, n, s, arena, 0, partial, cap);
-        }
-        if (rc) return rc;
-        if (op || d_image_f32) {
-            OutList64 o;
-            for (int i = 0; i < 64; ++i) o.p[i] = (op && i < n) ? op->p[f0 + i] : nullptr;
-            f16* img = mt_vae_out(e->mt, &cbt, arena);
-            launch_vae_post(img, cbt, n, 65536, o, d_image_f32 ? d_image_f32 + (size_t)f0 * 3 * 65536 : nullptr, s);
-        }
-        return 0;
-    };
-    const int st = knob(K_MT_STAGGER);
-    // (the host-input test hook places all its latents in arena 0 itself: never staggered)
-    const bool stagger = st > 0 && nf >= 2 * st && !e->capture && e->aux && !(d_feat && !lp);
-    int rc = 0;
-    if (stagger) {
-        const int na = (nf + 1) / 2, nb = nf - na;
-        if (mt_alloc_second_arena(e->mt, (e->mt_max_frames + 1) / 2)) return fail(LTK_E_NOMEM, std::string("musetalk: second arena: ") + mt_graph_error(e->mt));
-        if (!e->d_partial_b) {
-            e->partial_b_cap = e->partial_cap;
-            CHK(hipMalloc((void**)&e->d_partial_b, e->partial_b_cap));
-        }
-        for (hipEvent_t& ev : e->ev_mt) if (!ev) CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        // aux joins behind whatever `compute` has queued (the caller's inputs), b's U-Net starts when a's has finished
-        CHK(hipEventRecord(e->ev_mt[0], e->compute));
-        CHK(hipStreamWaitEvent(e->aux, e->ev_mt[0], 0));
-        rc = half(0, na, 0, e->compute, e->d_partial, e->partial_cap, e->ev_mt[1], nullptr);
-        if (!rc) rc = half(na, nb, 1, e->aux, e->d_partial_b, e->partial_b_cap, nullptr, e->ev_mt[1]);
-        // `compute` (whose event the caller waits for) ends behind both halves - also on an error path, so that no work is left unordered
-        if (hipEventRecord(e->ev_mt[2], e->aux) != hipSuccess || hipStreamWaitEvent(e->compute, e->ev_mt[2], 0) != hipSuccess) { if (!rc) rc = -2; }
-    } else {
-        rc = half(0, nf, 0, e->compute, e->d_partial, e->partial_cap, nullptr, nullptr);
-    }
+// latents already gathered into the graph's latent tensor; d_feat = fp32 [nf][50][384] on the device
+static int mt_run_locked(ltk_engine* e, const float* d_feat, const PtrList64* feat_ptrs, int nf, const OutList64* outs,
+                         float* d_image_f32) {
+    hipStream_t s = e->compute;
+    int cbt;
+    f16* ctx = mt_ctx_in(e->mt, &cbt);
+    if (feat_ptrs) launch_tokens_gather_to_cb16(*feat_ptrs, nf, 50, 384, e->d_pe, ctx, cbt, s);
+    else launch_tokens_to_cb16(d_feat, nf, 50, 384, e->d_pe, ctx, cbt, 0, s);
+    const int rc = run_program(e, e->mt, nf);
     if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    if (outs || d_image_f32) {
+        OutList64 none;
+        for (int i = 0; i < 64; ++i) none.p[i] = nullptr;
+        f16* img = mt_vae_out(e->mt, &cbt);
+        launch_vae_post(img, cbt, nf, 65536, outs ? *outs : none, d_image_f32, s);
+    }
     CHK(hipGetLastError());
     return 0;
 }
@@ -2093,7 +2029,10 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
             OutList64 op;
             for (int i = 0; i < 64; ++i) { lp.p[i] = nullptr; fp.p[i] = nullptr; op.p[i] = nullptr; }
             for (int i = 0; i < nf; ++i) { lp.p[i] = lptr[f0 + i]; fp.p[i] = fptr[f0 + i]; op.p[i] = optr[f0 + i]; }
-            rc = mt_enqueue_pass(e, nf, &lp, &fp, nullptr, &op, nullptr);
+            int cbt;
+            f16* lat = mt_latent_in(e->mt, &cbt);
+            launch_gather_latents(lp, nf, 8, 1024, lat, cbt, e->compute);
+            rc = mt_run_locked(e, nullptr, &fp, nf, &op, nullptr);
         }
         if (!rc && hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
     }
@@ -2353,7 +2292,7 @@ int ltk_musetalk_forward_host(ltk_engine* e, const float* latents, const float* 
     if (frames) CHK(hipMalloc((void**)&d_frames, (size_t)B * 65536 * 3));
     OutList64 op;
     for (int i = 0; i < 64; ++i) op.p[i] = (frames && i < B) ? d_frames + (size_t)i * 65536 * 3 : nullptr;
-    int rc = mt_enqueue_pass(e, B, nullptr, nullptr, e->d_mt_feat, &op, d_img);
+    int rc = mt_run_locked(e, e->d_mt_feat, nullptr, B, &op, d_img);
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(LTK_E_HIP, "stream sync failed");
     if (!rc && unet_out) {
         int C, ld, coff, H, W;
@@ -2437,14 +2376,13 @@ int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, 
     hipEvent_t t0, t1;
     CHK(hipEventCreate(&t0));
     CHK(hipEventCreate(&t1));
-    // as ltk_musetalk_infer enqueues the program (incl. the staggered half-batch schedule of a large pass): eagerly the first time a
-    // frame count is seen, then captured, then replayed; the per-call gather / write kernels are left out
-    int rc = mt_enqueue_pass(e, frames, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (!rc) rc = mt_enqueue_pass(e, frames, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
+    // as ltk_musetalk_infer enqueues the program: eagerly the first time a frame count is seen, then captured, then replayed
+    int rc = run_program(e, e->mt, frames);
+    if (!rc) rc = run_program(e, e->mt, frames);
+    if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     CHK(hipEventRecord(t0, e->compute));
-    for (int i = 0; i < iters && !rc; ++i) rc = mt_enqueue_pass(e, frames, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
+    for (int i = 0; i < iters && !rc; ++i) rc = run_program(e, e->mt, frames);
+    if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     CHK(hipEventRecord(t1, e->compute));
     CHK(hipEventSynchronize(t1));
     float ms = 0.f;

@@ -25,17 +25,11 @@ void mt_set_sat_counter(MtGraph* g, unsigned long long* d_ctr);
 // builds U-Net then VAE decoder; returns 0 or a negative code
 int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames);
 // tensors the engine feeds / reads
-f16* mt_latent_in(MtGraph* g, int* cbt, int arena = 0);       // [N][1][1024][16] (8 real channels)
-f16* mt_ctx_in(MtGraph* g, int* cbt, int arena = 0);          // [N][24][50][16]
-f16* mt_unet_out(MtGraph* g, int* cbt, int arena = 0);        // [N][1][1024][16] (4 real channels)
-f16* mt_vae_out(MtGraph* g, int* cbt, int arena = 0);         // [N][1][65536][16] (3 real channels, RGB)
+f16* mt_latent_in(MtGraph* g, int* cbt);       // [N][1][1024][16] (8 real channels)
+f16* mt_ctx_in(MtGraph* g, int* cbt);          // [N][24][50][16]
+f16* mt_unet_out(MtGraph* g, int* cbt);        // [N][1][1024][16] (4 real channels)
+f16* mt_vae_out(MtGraph* g, int* cbt);         // [N][1][65536][16] (3 real channels, RGB)
 int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s);
-// A second instance of every activation buffer (arena 1), sized for `frames`: lets two half-batches of a large pass be in flight on
-// two streams (engine.hip: the staggered schedule U(a) | VAE(a) beside U(b) | VAE(b)).  Weights and plans are shared.
-int mt_alloc_second_arena(MtGraph* g, int frames);
-int mt_arena_frames(const MtGraph* g, int arena);
-// part 0: the whole program, 1: the U-Net ops only, 2: the VAE decoder ops only - on arena 0 / 1
-int mt_run_part(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, int arena, int part);
 // per-op view (profiling): ops in execution order; type 0 conv/linear, 1 GroupNorm, 2 LayerNorm, 3 attention, 4 GEGLU, 5 add-pos, 6 value transpose (hoisted cross-attention values)
 int mt_op_count(MtGraph* g);
 const char* mt_op_name(MtGraph* g, int i, int* type);

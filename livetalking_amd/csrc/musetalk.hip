@@ -93,17 +93,15 @@ struct MtVtItem { MtTensor v; int heads, d16, Tk, vt_buf; };
 
 struct MtGraph {
     std::vector<size_t> buf_halfs;           // per frame
-    // activation arenas: [0] sized for `frames`, [1] (optional, mt_graph_alloc_second) a second instance of every buffer for the
-    // staggered half-batch schedule of a large pass (engine.hip mt_enqueue_pass): the two halves run on two streams
-    struct Arena { std::vector<f16*> bufs; float* gn_partial = nullptr; f16* vt = nullptr; int frames = 0; };
-    Arena ar[2];
-    std::vector<f16*>& bufs = ar[0].bufs;    // arena 0 (debug taps, single-arena programs)
+    std::vector<f16*> bufs;
     std::vector<ConvPlan> plans;
     std::vector<RowGemmPlan> rplans;         // small-map layers (<= 64 pixels / tokens per frame) also as rowconv plans (add_conv2)
     std::vector<float*> vecs;                // device fp32 vectors (norm affine)
     std::vector<MtOp> ops;
     std::map<std::string, MtTensor> named;
-    size_t gn_partial_floats = 0;             // per arena: GroupNorm partial statistics, transposed-values scratch (Arena)
+    float* gn_partial = nullptr;
+    size_t gn_partial_floats = 0;
+    f16* vt = nullptr;                        // transposed values scratch
     size_t vt_halfs = 0;                      // per frame
     struct KvPre { MtTensor k, v; int vt_buf; };
     std::map<std::string, KvPre> kv_pre;      // cross-attention name -> its views of the hoisted projection
@@ -116,7 +114,6 @@ struct MtGraph {
     double macs = 0;                          // conv / linear MACs per frame (attention excluded)
     double macs_fp8 = 0;                      // ... of which on fp8 operands
     std::string err;
-    int n_unet_ops = 0;                       // ops [0, n_unet_ops) = U-Net, the rest = VAE decoder (mt_build; 0 for other programs)
     unsigned long long* sat_ctr = nullptr;    // debug (knob SAT_CHECK): saturation counters every op's output is scanned into
     MtTensor *t_latent = nullptr, *t_ctx = nullptr, *t_unet_out = nullptr, *t_vae_out = nullptr;
     MtTensor* whisper_states = nullptr;
@@ -834,56 +831,50 @@ int mt_build_whisper(MtGraph& g, const ltk_named_tensor* t, int n, MtTensor* mel
 }
 
 // ------------------------------------------------------------------------------------------ allocate / run / free
-static int mt_arena_alloc(MtGraph& g, MtGraph::Arena& A, int frames) {
-    A.frames = frames;
-    A.bufs.assign(g.buf_halfs.size(), nullptr);
+int mt_graph_alloc(MtGraph& g, int frames) {
+    g.frames = frames;
+    g.bufs.assign(g.buf_halfs.size(), nullptr);
     for (size_t i = 0; i < g.buf_halfs.size(); ++i) {
         const size_t bytes = g.buf_halfs[i] * frames * sizeof(f16) + 256;
-        if (hipMalloc((void**)&A.bufs[i], bytes) != hipSuccess) { g.err = "activation allocation failed"; return -4; }
-        (void)hipMemset(A.bufs[i], 0, bytes);
+        if (hipMalloc((void**)&g.bufs[i], bytes) != hipSuccess) { g.err = "activation allocation failed"; return -4; }
+        (void)hipMemset(g.bufs[i], 0, bytes);
     }
-    // GroupNorm partial stats: [N][C/16][segs][32] floats, C <= 2560, segs <= 256; the segment count is chosen per launch from the
-    // launch's frame count: size for the worst case (1 frame)
+    // GroupNorm partial stats: [N][C/16][segs][32] floats, C <= 2560, segs <= 256 -> bound by the op list
     size_t need = 0;
     for (const MtOp& op : g.ops)
+        if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * gn_segments(frames, op.x.C, op.x.P()) * 32);
+    // the segment count is chosen per launch from the launch's frame count: size for the worst case (1 frame)
+    for (const MtOp& op : g.ops)
         if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 256 * 32);
-    g.gn_partial_floats = std::max(g.gn_partial_floats, need);
-    if (need && hipMalloc((void**)&A.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+    g.gn_partial_floats = need;
+    if (hipMalloc((void**)&g.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     if (g.vt_halfs) {
-        if (hipMalloc((void**)&A.vt, g.vt_halfs * frames * sizeof(f16)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+        if (hipMalloc((void**)&g.vt, g.vt_halfs * frames * sizeof(f16)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     }
     return 0;
 }
 
-int mt_graph_alloc(MtGraph& g, int frames) {
-    g.frames = frames;
-    return mt_arena_alloc(g, g.ar[0], frames);
-}
-
 void mt_graph_free(MtGraph& g) {
-    for (MtGraph::Arena& A : g.ar) {
-        for (f16* b : A.bufs) if (b) (void)hipFree(b);
-        if (A.gn_partial) (void)hipFree(A.gn_partial);
-        if (A.vt) (void)hipFree(A.vt);
-        A.bufs.clear(); A.gn_partial = nullptr; A.vt = nullptr; A.frames = 0;
-    }
+    for (f16* b : g.bufs) if (b) (void)hipFree(b);
     for (ConvPlan& p : g.plans) conv_plan_destroy(&p);
     for (RowGemmPlan& p : g.rplans) rowgemm_plan_destroy(&p);
     for (float* v : g.vecs) if (v) (void)hipFree(v);
-    g.plans.clear(); g.rplans.clear(); g.vecs.clear();
+    if (g.gn_partial) (void)hipFree(g.gn_partial);
+    if (g.vt) (void)hipFree(g.vt);
+    g.bufs.clear(); g.plans.clear(); g.rplans.clear(); g.vecs.clear();
 }
 
 f16* mt_ptr(const MtGraph& g, const MtTensor& t) { return g.bufs[t.buf]; }
 
 // one op on stream `s`
-static int mt_run_op_body(MtGraph& g, MtGraph::Arena& A, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
+static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
     switch (op.type) {
         case OP_CONV: {
             ConvIO io;
-            io.x = A.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
+            io.x = g.bufs[op.x.buf]; io.N = nf; io.H = op.x.H; io.W = op.x.W; io.x_ld = op.x.ld; io.x_coff = op.x.coff;
             if (op.x.q8) { io.x_ld /= 2; io.x_coff /= 2; }      // 16-bit units of the fp8 tensor (conv_mfma.h: ConvPlan::q8)
-            io.y = A.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
-            io.res = op.r.buf >= 0 ? A.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
+            io.y = g.bufs[op.y.buf]; io.y_ld = op.y.ld; io.y_coff = op.y.coff;
+            io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
             io.relu = 0; io.act = op.act; io.ups = op.ups;
             io.partial = partial; io.partial_cap = partial_cap;
             // U-Net resnet convs of a <= 16-frame pass: conv3's items-per-CU rule settles on tiles that re-read weights (8x8, 32x32 levels) or
@@ -910,25 +901,25 @@ static int mt_run_op_body(MtGraph& g, MtGraph::Arena& A, const MtOp& op, int nf,
         case OP_GN: {
             const int P = op.x.P();
             if (knob(K_MT_GN1) && gn_group_fits(op.x.C, P, op.groups)) {      // one launch: block = (image, group)
-                launch_gn_group(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.vecs[op.gamma],
-                                g.vecs[op.beta], op.silu, A.bufs[op.y.buf], op.y.q8 ? op.y.ld / 32 : op.y.ld / 16,
+                launch_gn_group(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.vecs[op.gamma],
+                                g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.q8 ? op.y.ld / 32 : op.y.ld / 16,
                                 op.y.q8 ? op.y.coff / 32 : op.y.coff / 16, op.y.q8 ? 1 : 0, g.fp8_ascale, s);
                 break;
             }
             const int segs = gn_segments(nf, op.x.C, P);
-            launch_gn_stats(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, A.gn_partial, s);
+            launch_gn_stats(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, segs, g.gn_partial, s);
             if (op.y.q8)
-                launch_gn_apply_fp8(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, A.gn_partial, segs,
-                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)A.bufs[op.y.buf],
+                launch_gn_apply_fp8(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                    g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.fp8_ascale, (unsigned char*)g.bufs[op.y.buf],
                                     op.y.ld / 32, op.y.coff / 32, s);
             else
-                launch_gn_apply(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, A.gn_partial, segs,
-                                g.vecs[op.gamma], g.vecs[op.beta], op.silu, A.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+                launch_gn_apply(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_partial, segs,
+                                g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
             break;
         }
         case OP_LN:
-            launch_layernorm(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), op.eps, g.vecs[op.gamma],
-                             g.vecs[op.beta], A.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
+            launch_layernorm(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), op.eps, g.vecs[op.gamma],
+                             g.vecs[op.beta], g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, s);
             break;
         case OP_VT: {
             VtMulti m;
@@ -936,51 +927,49 @@ static int mt_run_op_body(MtGraph& g, MtGraph::Arena& A, const MtOp& op, int nf,
             if (m.n > 16) { g.err = "too many hoisted value tensors"; return -1; }
             for (int i = 0; i < m.n; ++i) {
                 const MtVtItem& it = g.vt_items[i];
-                m.it[i] = {A.bufs[it.v.buf], A.bufs[it.vt_buf], it.v.ld / 16, it.v.coff / 16, it.heads, it.d16, 0, 0};
+                m.it[i] = {g.bufs[it.v.buf], g.bufs[it.vt_buf], it.v.ld / 16, it.v.coff / 16, it.heads, it.d16, 0, 0};
             }
             launch_v_transpose_multi(m, nf, s);
             break;
         }
         case OP_ATTN: {
-            f16* vt = A.vt;
-            if (op.vt_buf >= 0) vt = A.bufs[op.vt_buf];
-            else launch_v_transpose(A.bufs[op.v.buf], nf, op.v.ld / 16, op.v.coff / 16, op.heads, op.d16, op.Tk, A.vt, s);
-            const int rc = launch_attention(A.bufs[op.x.buf], op.x.ld / 16, op.x.coff / 16, op.x.P(), A.bufs[op.k.buf], op.k.ld / 16,
-                                            op.k.coff / 16, op.Tk, vt, A.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, nf, op.heads,
+            f16* vt = g.vt;
+            if (op.vt_buf >= 0) vt = g.bufs[op.vt_buf];
+            else launch_v_transpose(g.bufs[op.v.buf], nf, op.v.ld / 16, op.v.coff / 16, op.heads, op.d16, op.Tk, g.vt, s);
+            const int rc = launch_attention(g.bufs[op.x.buf], op.x.ld / 16, op.x.coff / 16, op.x.P(), g.bufs[op.k.buf], op.k.ld / 16,
+                                            op.k.coff / 16, op.Tk, vt, g.bufs[op.y.buf], op.y.ld / 16, op.y.coff / 16, nf, op.heads,
                                             op.d16, s);
             if (rc) { g.err = op.name + ": attention launch failed (head dim " + std::to_string(op.d16) + ")"; return rc; }
             break;
         }
         case OP_ADDPOS:
-            launch_add_pos(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), g.vecs[op.gamma], s);
+            launch_add_pos(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, op.x.P(), g.vecs[op.gamma], s);
             break;
         case OP_GEGLU:
-            launch_geglu(A.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), A.bufs[op.y.buf], op.y.ld / 16,
+            launch_geglu(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.y.C, op.x.P(), g.bufs[op.y.buf], op.y.ld / 16,
                          op.y.coff / 16, s);
             break;
     }
     return 0;
 }
 
-static int mt_run_op(MtGraph& g, MtGraph::Arena& A, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
-    const int rc = mt_run_op_body(g, A, op, nf, partial, partial_cap, s);
+static int mt_run_op(MtGraph& g, const MtOp& op, int nf, float* partial, size_t partial_cap, hipStream_t s) {
+    const int rc = mt_run_op_body(g, op, nf, partial, partial_cap, s);
     if (!rc && g.sat_ctr && op.y.buf >= 0 && knob(K_SAT_CHECK)) {      // debug: what this op clamped to (or pushed past) the limit of its output type
         const int gran = op.y.q8 ? 32 : 16;
-        launch_sat_scan(A.bufs[op.y.buf], nf, op.y.ld / gran, op.y.coff / gran, op.y.C / gran, op.y.P(), op.y.q8 ? 1 : 0, g.sat_ctr, s);
+        launch_sat_scan(g.bufs[op.y.buf], nf, op.y.ld / gran, op.y.coff / gran, op.y.C / gran, op.y.P(), op.y.q8 ? 1 : 0, g.sat_ctr, s);
     }
     return rc;
 }
 
-// `evs` (measurement): one event in front of every op and one behind the last.  `arena`: which instance of the buffers (MtGraph::ar)
+// `evs` (measurement): one event in front of every op and one behind the last
 int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStream_t s, int op_begin, int op_end,
-                 std::vector<hipEvent_t>* evs = nullptr, int arena = 0) {
-    if (arena < 0 || arena > 1 || g.ar[arena].bufs.empty()) { g.err = "no such arena"; return -1; }
-    MtGraph::Arena& A = g.ar[arena];
-    if (nf > A.frames) { g.err = "more frames than the graph was sized for"; return -1; }
+                 std::vector<hipEvent_t>* evs = nullptr) {
+    if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
     if (op_end < 0) op_end = (int)g.ops.size();
     for (int oi = op_begin; oi < op_end; ++oi) {
         if (evs) (void)hipEventRecord((*evs)[oi - op_begin], s);
-        const int rc = mt_run_op(g, A, g.ops[oi], nf, partial, partial_cap, s);
+        const int rc = mt_run_op(g, g.ops[oi], nf, partial, partial_cap, s);
         if (rc) return rc;
     }
     if (evs) (void)hipEventRecord((*evs)[op_end - op_begin], s);
@@ -996,7 +985,7 @@ const char* mt_op_name(MtGraph* g, int i, int* type) {
     return g->ops[i].name.c_str();
 }
 int mt_run_timed(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, std::vector<hipEvent_t>* evs) {
-    return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1, evs, 0);
+    return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1, evs);
 }
 MtGraph* mt_graph_new() { return new MtGraph(); }
 void mt_graph_delete(MtGraph* g) {
@@ -1015,35 +1004,15 @@ double mt_macs_fp8_per_frame(const MtGraph* g) { return g->macs_fp8; }
 int mt_build(MtGraph* g, const ltk_named_tensor* unet_sd, int n_unet, const ltk_named_tensor* vae_sd, int n_vae, int frames) {
     g->t_latent = new MtTensor(); g->t_ctx = new MtTensor(); g->t_unet_out = new MtTensor(); g->t_vae_out = new MtTensor();
     if (mt_build_unet(*g, unet_sd, n_unet, g->t_latent, g->t_ctx, g->t_unet_out)) return -1;
-    g->n_unet_ops = (int)g->ops.size();
     if (mt_build_vae(*g, vae_sd, n_vae, *g->t_unet_out, g->t_vae_out)) return -1;
     return mt_graph_alloc(*g, frames);
 }
-static f16* tptr(MtGraph* g, const MtTensor* t, int* cbt, int arena = 0) { if (cbt) *cbt = t->ld / 16; return g->ar[arena].bufs[t->buf]; }
-f16* mt_latent_in(MtGraph* g, int* cbt, int arena) { return tptr(g, g->t_latent, cbt, arena); }
-f16* mt_ctx_in(MtGraph* g, int* cbt, int arena) { return tptr(g, g->t_ctx, cbt, arena); }
-f16* mt_unet_out(MtGraph* g, int* cbt, int arena) { return tptr(g, g->t_unet_out, cbt, arena); }
-f16* mt_vae_out(MtGraph* g, int* cbt, int arena) { return tptr(g, g->t_vae_out, cbt, arena); }
+static f16* tptr(MtGraph* g, const MtTensor* t, int* cbt) { if (cbt) *cbt = t->ld / 16; return g->bufs[t->buf]; }
+f16* mt_latent_in(MtGraph* g, int* cbt) { return tptr(g, g->t_latent, cbt); }
+f16* mt_ctx_in(MtGraph* g, int* cbt) { return tptr(g, g->t_ctx, cbt); }
+f16* mt_unet_out(MtGraph* g, int* cbt) { return tptr(g, g->t_unet_out, cbt); }
+f16* mt_vae_out(MtGraph* g, int* cbt) { return tptr(g, g->t_vae_out, cbt); }
 int mt_run(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s) { return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1); }
-int mt_run_part(MtGraph* g, int nf, float* partial, size_t partial_cap, hipStream_t s, int arena, int part) {
-    const int cut = g->n_unet_ops > 0 ? g->n_unet_ops : (int)g->ops.size();
-    if (part == 1) return mt_graph_run(*g, nf, partial, partial_cap, s, 0, cut, nullptr, arena);
-    if (part == 2) return mt_graph_run(*g, nf, partial, partial_cap, s, cut, -1, nullptr, arena);
-    return mt_graph_run(*g, nf, partial, partial_cap, s, 0, -1, nullptr, arena);
-}
-int mt_alloc_second_arena(MtGraph* g, int frames) {
-    if (!g->ar[1].bufs.empty()) return g->ar[1].frames >= frames ? 0 : -1;
-    const int rc = mt_arena_alloc(*g, g->ar[1], frames);
-    if (rc) {                       // roll back: a half-allocated arena must not be used
-        MtGraph::Arena& A = g->ar[1];
-        for (f16* b : A.bufs) if (b) (void)hipFree(b);
-        if (A.gn_partial) (void)hipFree(A.gn_partial);
-        if (A.vt) (void)hipFree(A.vt);
-        A = MtGraph::Arena();
-    }
-    return rc;
-}
-int mt_arena_frames(const MtGraph* g, int arena) { return (arena >= 0 && arena < 2) ? g->ar[arena].frames : 0; }
 f16* mt_named(MtGraph* g, const char* name, int* C, int* ld, int* coff, int* H, int* W) {
     auto it = g->named.find(name);
     if (it == g->named.end()) return nullptr;

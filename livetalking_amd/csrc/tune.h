@@ -73,9 +73,6 @@ enum Knob {
     K_SAT_CHECK,          // LTK_SAT_CHECK      debug, default 0: behind every layer / op its output is scanned for values AT the limit of its type (what an epilogue's
                           //                    clamp to +-65504 leaves behind; +-448 for e4m3) and for non-finite values; counters through ltk_debug_saturation.
                           //                    The fused Wav2Lip head (which writes bytes) runs unfused under it.
-    K_MT_STAGGER,         // LTK_MT_STAGGER     a MuseTalk pass of at least 2 x this many frames runs as two half-batches in two arenas on two streams, the second
-                          //                    half one phase behind the first (its launch-bound U-Net beside the first half's throughput-bound VAE decoder);
-                          //                    0 = never.  Default 32: the 64-frame calls of BASELINE configs[4]'s per-GPU share
     K_COUNT
 };
 
