@@ -163,6 +163,7 @@ class SessionThreads:
             self._done = threading.Barrier(self.S + 1)
             self._stop = False
             self._due = None
+            self._stagger = 0.0             # paced: session i asks i * _stagger seconds after the period starts
             self._threads = [threading.Thread(target=self._run, args=(i,), daemon=True) for i in range(self.S)]
             for t in self._threads:
                 t.start()
@@ -181,7 +182,7 @@ class SessionThreads:
                 return
             try:
                 if self._due is not None:                      # paced: every session asks at its own due time
-                    while time.perf_counter() < self._due:
+                    while time.perf_counter() < self._due + i * self._stagger:
                         time.sleep(0.0005)
                 for st in range(self._nsteps):                 # free-running: no hand-shake with the other sessions between steps
                     self._one(i, self._step + st)
@@ -209,12 +210,16 @@ class SessionThreads:
             self._go.wait()
 
 
-def paced_sessions(drv: SessionThreads, first_step: int, periods: int, B: int):
+def paced_sessions(drv: SessionThreads, first_step: int, periods: int, B: int, stagger: bool = False):
     """Every session asks for its next B frames once per B/25 s (what a 25 fps render loop does).  A period is met when
-    the last session's frames are ready before the next period starts."""
+    the last session's frames are ready before the next period starts.  `stagger`: the sessions' request times are spread
+    evenly over the period (sessions that were started at different moments - the deployment case - instead of all at
+    once): every request is then a call of its own, and `call_ms_mean` is the time a session waits inside inference_batch."""
     period = B / 25.0
     drv.busy = [0.0] * drv.S
     drv.frames = [0] * drv.S
+    if drv.S > 1:
+        drv._stagger = period / drv.S if stagger else 0.0
     lat = []
     t0 = time.perf_counter() + 0.05
     for p in range(periods):
@@ -223,9 +228,12 @@ def paced_sessions(drv: SessionThreads, first_step: int, periods: int, B: int):
             while time.perf_counter() < due:
                 time.sleep(0.0005)
         drv.step(first_step + p, due=due)
-        lat.append(time.perf_counter() - due)
+        lat.append(time.perf_counter() - due - (drv._stagger * (drv.S - 1) if drv.S > 1 else 0.0))
+    if drv.S > 1:
+        drv._stagger = 0.0
     per_session = [f / b if b > 0 else 0.0 for f, b in zip(drv.frames, drv.busy)]
-    return {"sessions": drv.S, "fps_per_session_required": 25, "periods": periods, "period_ms": period * 1e3,
+    return {"sessions": drv.S, "fps_per_session_required": 25, "periods": periods, "period_ms": period * 1e3, "staggered": bool(stagger),
+            "call_ms_mean": round(1e3 * sum(drv.busy) / max(1, drv.S * periods), 4),
             "latency_ms_mean": round(1e3 * sum(lat) / len(lat), 2), "latency_ms_max": round(1e3 * max(lat), 2),
             "inferfps_per_session_min": round(min(per_session), 1), "inferfps_per_session_mean": round(sum(per_session) / len(per_session), 1),
             "sustained": bool(max(lat) < period and min(per_session) >= 25.0),
@@ -311,7 +319,7 @@ def run_wav2lip(args, ranks: Ranks):
                      "seconds": round(sus_max, 3), "ms_per_step": round(sus_max / n_sus * 1e3, 4),
                      "note": "same loop as the timed region, run for >= --sustain seconds directly behind it; not `value`"}
 
-    paced = paced_sessions(drv, PRIME + args.warmup + args.steps + 4096, args.paced, B) if args.paced > 0 else None
+    paced = paced_sessions(drv, PRIME + args.warmup + args.steps + 4096, args.paced, B, stagger=args.paced_stagger) if args.paced > 0 else None
     sched = dict(sessions[0]._sched.stats)
     # PCIe-inclusive rate of one session (outside the timed region): mel windows start on the HOST (the reference's ASR hands
     # numpy arrays over, mel.py:34-67) and every frame comes back composited into its full frame as a host array, as
@@ -953,6 +961,7 @@ def main():
                     help="wav2lip = BASELINE.json configs[1] (default, the driver's line); musetalk = configs[2]")
     ap.add_argument("--fp8", action="store_true", help="musetalk: BASELINE configs[4] fp8 conv path")
     ap.add_argument("--paced", type=int, default=0, help="after the timed run: N periods of B/25 s with every session paced at 25 fps")
+    ap.add_argument("--paced-stagger", action="store_true", help="--paced with the sessions' request times spread evenly over the period (every request a call of its own)")
     ap.add_argument("--sustain", type=float, default=None,
                     help="seconds of the `sustained` twin behind the timed region (default 2.0 for the primary wav2lip line, 0 = off)")
     ap.add_argument("--no-whole-pass", action="store_true", help="skip the comparison timing with knob PREFETCH off (profiler runs: the last pass of "

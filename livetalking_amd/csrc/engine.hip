@@ -291,18 +291,32 @@ struct ltk_engine {
     int micro_batch = 0;
     std::vector<Layer> layers;
     f16* buf[B_COUNT] = {nullptr};
-    // knob PREFETCH: second instance of what the prefetched face encoder touches - its temporaries (X0, T0, T1) and the eight concat
-    // buffers ("parity 1"; a call's decoder works in the set its skip tensors were written to) - sized for alt_frames frames
-    f16* alt[B_COUNT] = {nullptr};
+    // knob PREFETCH: kPfSlots further instances of the eight concat buffers ("slots" 1..kPfSlots; set 0 = buf, where a call that runs
+    // the whole network works), sized for alt_frames frames, each holding the prefetched face-encoder outputs of ONE upcoming call,
+    // keyed by (avatar, first bank index, frame count): interleaved solo calls of several paced sessions each find their own slot
+    // (round 5 kept one engine-wide slot, which only a lone session's calls ever hit).  pf_tmp: the prefetched encoder's own
+    // temporaries (prefetches are serialised on aux2).  A call's decoder works in the set its skip tensors were written to.
+    struct PfSlot {
+        f16* cat[B_COUNT] = {nullptr};
+        bool valid = false;               // holds the outputs for (avatar, first, nf) computed under `epoch`
+        int avatar = -1, first = -1, nf = 0;
+        unsigned epoch = 0;
+        unsigned long stamp = 0;          // LRU clock of the last fill / use
+        hipEvent_t ev_done = nullptr;     // the prefetch into this slot has finished (recorded on aux2)
+        hipEvent_t ev_read = nullptr;     // the last pass that worked in this slot has finished (recorded on compute)
+        bool filled = false, read = false;
+        std::shared_ptr<Avatar> hold;     // the bank a prefetch into this slot reads
+    };
+    static constexpr int kPfSlots = 8;
+    PfSlot pfs[kPfSlots + 1];             // [0] unused
+    f16* pf_tmp[B_COUNT] = {nullptr};
     int alt_frames = 0;
     hipStream_t aux2 = nullptr;
-    hipEvent_t ev_pf_done = nullptr, ev_main[2] = {nullptr, nullptr};   // prefetch finished / a pass finished (alternating)
-    bool pf_outstanding = false;
-    unsigned long pass_seq = 0;
-    std::shared_ptr<Avatar> pf_hold;  // the bank the outstanding prefetch reads
+    unsigned long pf_clock = 0;
     DevTables* d_tab_next = nullptr;  // faces table of the prefetched frames
-    struct Prefetched { int avatar = -1, first = -1, nf = 0, parity = 0; unsigned epoch = 0; bool valid = false; } pf;
-    struct LastSolo { int avatar = -1, first = -1, nf = 0; } last_solo;
+    // recent solo calls, per session position: a call that starts where one of them ended (same avatar, same size) continues a session
+    struct SoloSeq { int avatar = -1, next = -1, nf = 0; unsigned long stamp = 0; };
+    SoloSeq solo_seq[2 * kPfSlots];
     unsigned long pf_hits = 0, pf_misses = 0, pf_issued = 0;
     // LTK_INFER_TIMING=1 (measurement): host time of ltk_wav2lip_infer by phase, printed when the engine is destroyed
     double tm_prep = 0, tm_launch = 0, tm_pf = 0, tm_wait = 0;
@@ -585,6 +599,7 @@ void drop_prog_graphs(ltk_engine* e) {
 }
 
 void wav2lip_unload(ltk_engine* e) {
+    if (e->aux2) (void)hipStreamSynchronize(e->aux2);        // an outstanding prefetch writes buffers that go away below
     drop_graphs(e);
     if (e->d_tab) { (void)hipFree(e->d_tab); e->d_tab = nullptr; }
     for (Layer& L : e->layers) {
@@ -594,13 +609,17 @@ void wav2lip_unload(ltk_engine* e) {
     e->layers.clear();
     for (int i = 0; i < B_COUNT; ++i) {
         if (e->buf[i]) { (void)hipFree(e->buf[i]); e->buf[i] = nullptr; }
-        if (e->alt[i]) { (void)hipFree(e->alt[i]); e->alt[i] = nullptr; }
+        if (e->pf_tmp[i]) { (void)hipFree(e->pf_tmp[i]); e->pf_tmp[i] = nullptr; }
+        for (ltk_engine::PfSlot& sl : e->pfs)
+            if (sl.cat[i]) { (void)hipFree(sl.cat[i]); sl.cat[i] = nullptr; }
+    }
+    for (ltk_engine::PfSlot& sl : e->pfs) {
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.ev_read) (void)hipEventDestroy(sl.ev_read);
+        sl = ltk_engine::PfSlot();
     }
     e->alt_frames = 0;
-    e->pf = ltk_engine::Prefetched();
-    e->last_solo = ltk_engine::LastSolo();
-    e->pf_hold.reset();
-    e->pf_outstanding = false;
+    for (ltk_engine::SoloSeq& q : e->solo_seq) q = ltk_engine::SoloSeq();
     if (e->d_tab_next) { (void)hipFree(e->d_tab_next); e->d_tab_next = nullptr; }
     if (e->d_head) { (void)hipFree(e->d_head); e->d_head = nullptr; }
     conv7_plan_destroy(e->c7);
@@ -746,12 +765,11 @@ f16* bufp(ltk_engine* e, int id, int frame0) { return e->buf[id] + (size_t)frame
 // 2 everything but the face encoder (its skip tensors are already in the concat buffers).
 int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = nullptr, std::vector<hipEvent_t>* evs = nullptr,
               const FacePtrs* faces = nullptr, int part = 0, int par = 0, bool pf_enc = false) {
-    // `par`: which set of concat buffers the launched layers use (knob PREFETCH); `pf_enc`: the launched layers are a prefetched face
-    // encoder running beside another call's decoder: its temporaries come from the second set as well
-    if (!pf_enc && part != 2) e->pf.valid = false;      // the face encoder is about to overwrite a concat-buffer set (any entry point)
+    // `par`: which set of concat buffers the launched layers use (0 = the arena's own, 1..kPfSlots = a prefetch slot, knob PREFETCH);
+    // `pf_enc`: the launched layers are a prefetched face encoder running beside another call's decoder, with temporaries of its own
     auto B = [&](int id) -> f16* {
-        if (id >= B_CAT0) return par ? e->alt[id] : e->buf[id];
-        if (pf_enc && (id == B_X0 || id == B_T0 || id == B_T1)) return e->alt[id];
+        if (id >= B_CAT0) return par ? e->pfs[par].cat[id] : e->buf[id];
+        if (pf_enc && (id == B_X0 || id == B_T0 || id == B_T1)) return e->pf_tmp[id];
         return e->buf[id];
     };
     std::string err;
@@ -937,9 +955,6 @@ int ltk_engine_create(int device, ltk_engine** out) {
     CHK(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
     CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&e->ev_pf_done, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&e->ev_main[0], hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&e->ev_main[1], hipEventDisableTiming));
     e->partial_cap = (size_t)128 << 20;
     e->partial_aux_cap = (size_t)16 << 20;
     e->partial_pf_cap = (size_t)64 << 20;
@@ -990,9 +1005,6 @@ void ltk_engine_destroy(ltk_engine* e) {
     if (e->d_sat) (void)hipFree(e->d_sat);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->ev_pf_done) (void)hipEventDestroy(e->ev_pf_done);
-    if (e->ev_main[0]) (void)hipEventDestroy(e->ev_main[0]);
-    if (e->ev_main[1]) (void)hipEventDestroy(e->ev_main[1]);
     if (e->aux2) (void)hipStreamDestroy(e->aux2);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->compute) (void)hipStreamDestroy(e->compute);
@@ -1027,13 +1039,24 @@ int ltk_wav2lip_load(ltk_engine* e, const ltk_named_tensor* sd, int n, int max_f
             if (hipMalloc((void**)&e->buf[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "activation arena allocation failed");
             CHK(hipMemset(e->buf[i], 0, bytes));
         }
-        if (knob(K_PREFETCH)) {       // second set of the prefetched face encoder's buffers (0.5 GB at 32 frames)
+        if (knob(K_PREFETCH)) {       // the prefetch slots (8 x 0.13 GB of concat buffers at 32 frames) + the prefetched encoder's temporaries
             e->alt_frames = std::min(arena_frames, kPrefetchMaxFrames);
             for (int i = 0; i < B_COUNT; ++i) {
                 if (!e->buf_halfs[i] || !(i >= B_CAT0 || i == B_X0 || i == B_T0 || i == B_T1)) continue;
                 const size_t bytes = e->buf_halfs[i] * e->alt_frames * sizeof(f16) + 4096;
-                if (hipMalloc((void**)&e->alt[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "prefetch arena allocation failed");
-                CHK(hipMemset(e->alt[i], 0, bytes));
+                if (i < B_CAT0) {
+                    if (hipMalloc((void**)&e->pf_tmp[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "prefetch arena allocation failed");
+                    CHK(hipMemset(e->pf_tmp[i], 0, bytes));
+                    continue;
+                }
+                for (int k = 1; k <= ltk_engine::kPfSlots; ++k) {
+                    if (hipMalloc((void**)&e->pfs[k].cat[i], bytes) != hipSuccess) return fail(LTK_E_NOMEM, "prefetch arena allocation failed");
+                    CHK(hipMemset(e->pfs[k].cat[i], 0, bytes));
+                }
+            }
+            for (int k = 1; k <= ltk_engine::kPfSlots; ++k) {
+                CHK(hipEventCreateWithFlags(&e->pfs[k].ev_done, hipEventDisableTiming));
+                CHK(hipEventCreateWithFlags(&e->pfs[k].ev_read, hipEventDisableTiming));
             }
             if (hipMalloc((void**)&e->d_tab_next, sizeof(DevTables)) != hipSuccess) return fail(LTK_E_NOMEM, "pointer table allocation failed");
             CHK(hipMemset(e->d_tab_next, 0, sizeof(DevTables)));
@@ -1074,6 +1097,16 @@ int ltk_avatar_register(ltk_engine* e, const uint8_t* face_bank, const uint8_t* 
 
 int ltk_avatar_release(ltk_engine* e, int avatar_id) {
     if (!e) return fail(LTK_E_INVALID, "engine is null");
+    {   // prefetch slots keyed by this avatar: their data will never be asked for again, and their hold on the bank goes once the
+        // prefetch that reads it has finished (ids are never reused, so a stale key could not match anyway)
+        std::lock_guard<std::mutex> ge(e->mu);
+        for (ltk_engine::PfSlot& sl : e->pfs)
+            if (sl.avatar == avatar_id && (sl.valid || sl.hold)) {
+                if (sl.filled && sl.ev_done) (void)hipEventSynchronize(sl.ev_done);
+                sl.valid = false;
+                sl.hold.reset();
+            }
+    }
     std::lock_guard<std::mutex> g(e->pool_mu);
     auto it = e->avatars.find(avatar_id);
     if (it != e->avatars.end()) { e->avatars.erase(it); return LTK_OK; }      // buffers go with the last call that still uses them
@@ -1151,13 +1184,27 @@ static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, c
     return 0;
 }
 
-constexpr size_t kMaxPassGraphs = 48;
+constexpr size_t kMaxPassGraphs = 64;
 
 // enqueue_pass, replayed from a captured hipGraph where the pass has no per-call arguments: the product configuration (bank crops
 // in, fused head out) on the engine's own streams.  A frame count runs eagerly the first time it is seen (which also sets every
 // kernel's dynamic-LDS attribute) and is captured the second time; a dependent launch costs ~3.1 us on a stream and ~2.0 us inside a
 // graph (profiles/r03_ubench_launch_chain.txt), and the host issues one launch instead of ~70.  The audio-encoder branch on the aux
 // stream becomes a branch of the graph (its fork / join events are captured as dependencies).
+// the table of captured Wav2Lip passes (passes, pipelined variants per slot, prefetch graphs) is full: the least recently used one goes
+static void evict_graph_if_full(ltk_engine* e) {
+    size_t live = 0;
+    for (auto& kv : e->graphs) live += kv.second.exec ? 1 : 0;
+    if (live < kMaxPassGraphs) return;
+    auto victim = e->graphs.end();
+    for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
+        if (it->second.exec && (victim == e->graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
+    if (victim == e->graphs.end()) return;
+    (void)hipStreamSynchronize(e->compute);            // it may still be running for the previous call ...
+    if (victim->first & (1 << 22)) (void)hipStreamSynchronize(e->aux2);     // ... a prefetch graph: on the third stream
+    (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
+}
+
 static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, const float* d_face6, bool have_outs, float* d_pred_f32,
                        bool cached = false, int par = 0, bool have_feats = false) {
     // the float32 NCHW output (test hook) and layer capture need the 32-channel map in memory: unfused
@@ -1179,22 +1226,11 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
         e->graph_epoch = knob_epoch();
     }
     // the cached pass and the pipelined variants of a frame count are different launch sequences
-    ltk_engine::PassGraph& g = e->graphs[nf | (cached ? (1 << 20) : 0) | (par << 21) | (have_feats ? (1 << 22) : 0)];
+    ltk_engine::PassGraph& g = e->graphs[nf | (cached ? (1 << 20) : 0) | (have_feats ? (1 << 21) : 0) | (par << 24)];
     g.stamp = ++e->graph_clock;
     if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); return 0; }
     if (g.seen < 0 || g.seen++ == 0) return enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats);
-    size_t live = 0;
-    for (auto& kv : e->graphs) live += kv.second.exec ? 1 : 0;
-    if (live >= kMaxPassGraphs) {                       // least recently used out
-        auto victim = e->graphs.end();
-        for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
-            if (it->second.exec && (victim == e->graphs.end() || it->second.stamp < victim->second.stamp)) victim = it;
-        if (victim != e->graphs.end()) {
-            CHK(hipStreamSynchronize(s));               // it may still be running for the previous call
-            if (victim->first & (1 << 24)) CHK(hipStreamSynchronize(e->aux2));     // ... a prefetch graph: on the third stream
-            (void)hipGraphExecDestroy(victim->second.exec); victim->second.exec = nullptr; victim->second.seen = 1;
-        }
-    }
+    evict_graph_if_full(e);
     hipGraph_t graph = nullptr;
     CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_pass(e, nf, s, bank_faces, d_face6, fused, have_outs, d_pred_f32, cached, par, have_feats);
@@ -1224,46 +1260,47 @@ static int launch_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, co
     return 0;
 }
 
-// Knob PREFETCH: the face encoder of the frames the session's NEXT call will ask for (bank crops in e->d_tab_next), on the third
-// stream, into concat-buffer set `par_target` - its own launch sequence and its own graph, issued BEHIND the call's pass (whose
-// launches reach the GPU first: a graph's nodes go out a few microseconds apiece, and the call's latency-bound head runs at that
-// pace).  Ordering: it starts behind the previous prefetch (stream order) and behind the pass that last READ the target set
-// (ev_main[prev]; in the call flow that pass has completed on the host already, ltk_wav2lip_time_convs issues passes back to back);
-// whoever uses the arena next waits for ev_pf_done (wait_prefetch).
-static int wait_prefetch(ltk_engine* e) {
-    if (e->pf_outstanding) { CHK(hipStreamWaitEvent(e->compute, e->ev_pf_done, 0)); e->pf_outstanding = false; }
-    return 0;
-}
-
-static int launch_prefetch(ltk_engine* e, int nf, int par_target, hipEvent_t reader_done) {
+// Knob PREFETCH.  A whole-pass call works in set 0; the prefetched encoder has temporaries, split-K scratch and a pointer table of its
+// own and writes prefetch slots only, so nothing but a slot's own users has to wait for it (PfSlot::ev_done / ev_read).
+// The face encoder of `nf` frames (bank crops in e->d_tab_next, uploaded on aux2 by the caller) into slot `slot`, on the third stream,
+// its own graph per (frame count, slot).  Ordering: behind the previous prefetch (stream order) and behind the pass that last worked in
+// the slot (ev_read); whoever then works in the slot waits for ev_done.
+static int launch_prefetch(ltk_engine* e, int nf, int slot) {
     hipStream_t s = e->aux2;
-    if (reader_done) CHK(hipStreamWaitEvent(s, reader_done, 0));
-    auto enq = [&]() -> int { return run_convs(e, nf, s, nullptr, nullptr, &e->d_tab_next->faces, 1, par_target, true); };
+    ltk_engine::PfSlot& sl = e->pfs[slot];
+    if (sl.read) CHK(hipStreamWaitEvent(s, sl.ev_read, 0));
+    auto enq = [&]() -> int { return run_convs(e, nf, s, nullptr, nullptr, &e->d_tab_next->faces, 1, slot, true); };
     int rc = 0;
-    if (!knob(K_GRAPH)) rc = enq();
+    bool launched = false;
+    if (!knob(K_GRAPH)) { rc = enq(); launched = true; }
     else {
-        ltk_engine::PassGraph& g = e->graphs[nf | (par_target << 21) | (1 << 24)];
+        ltk_engine::PassGraph& g = e->graphs[nf | (1 << 22) | (slot << 24)];
         g.stamp = ++e->graph_clock;
-        if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); }
-        else if (g.seen < 0 || g.seen++ == 0) rc = enq();
+        if (g.exec) { CHK(hipGraphLaunch(g.exec, s)); launched = true; }
+        else if (g.seen < 0 || g.seen++ == 0) { rc = enq(); launched = true; }
         else {
+            evict_graph_if_full(e);
             hipGraph_t graph = nullptr;
             CHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             rc = enq();
             const hipError_t ce = hipStreamEndCapture(s, &graph);
-            if (rc) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }
+            if (rc) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); g.seen = -1; return rc; }      // nothing was launched
             hipGraphExec_t exec = nullptr;
             hipError_t ie = ce;
             if (ce == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (graph) (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess || !exec) { (void)hipGetLastError(); g.seen = -1; rc = enq(); }
-            else { g.exec = exec; CHK(hipGraphLaunch(exec, s)); }
+            if (ie != hipSuccess || !exec) {
+                (void)hipGetLastError();
+                g.seen = -1;
+                fprintf(stderr, "ltk: hipGraph capture of the %d-frame prefetch failed (%s); running it as separate launches\n", nf, hipGetErrorString(ie));
+                rc = enq();
+            } else { g.exec = exec; CHK(hipGraphLaunch(exec, s)); }
+            launched = true;
         }
     }
-    if (rc) return rc;
-    CHK(hipEventRecord(e->ev_pf_done, s));
-    e->pf_outstanding = true;
-    return 0;
+    // whatever reached the stream (also part of a failed eager sequence) is ordered in front of the slot's next user
+    if (launched) { CHK(hipEventRecord(sl.ev_done, s)); sl.filled = true; }
+    return rc;
 }
 
 int ltk_debug_tile_table_check(char* msg, int cap) {
@@ -1371,22 +1408,32 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             if (!rc)
                 for (int i = 0; i < total; ++i) fptr[i] = hold[fidx[2 * i]]->d_feat + (size_t)fidx[2 * i + 1] * hold[fidx[2 * i]]->feat_rec_bytes;
         }
-        // knob PREFETCH: a single-request call of <= 32 frames that continues its session's sequence (same avatar, index advanced
-        // by the batch size) finds its face-encoder outputs prefetched by the previous call and prefetches the next call's in turn
+        // knob PREFETCH: a single-request call of <= 32 frames finds the face-encoder outputs of its frames in the slot a previous call of
+        // its session prefetched them into (key: avatar, first bank index, frame count), and - when it continues a session's sequence
+        // (it was a hit, or it starts where a recent solo call of the same avatar and size ended) - prefetches the next call's in turn
         const bool solo = nreq == 1 && !cached && knob(K_PREFETCH) && e->alt_frames > 0 && total <= std::min(e->alt_frames, mbs) &&
                           !e->capture && knob(K_HEAD_FUSED) && e->c7 && knob(K_CONV7);
         const int first = reqs[0].index;
-        const bool hit = solo && e->pf.valid && e->pf.avatar == reqs[0].avatar && e->pf.first == first && e->pf.nf == total &&
-                         e->pf.epoch == knob_epoch();
-        const bool continues = solo && e->last_solo.avatar == reqs[0].avatar && e->last_solo.first + e->last_solo.nf == first &&
-                               e->last_solo.nf == total;
-        const bool prefetch = solo && (hit || continues);
-        const int par = hit ? e->pf.parity : 0;
-        e->pf.valid = false;                    // whatever this call does, it overwrites the set the old prefetch went to or consumes it
+        int slot = 0;
+        if (solo)
+            for (int k = 1; k <= ltk_engine::kPfSlots && !slot; ++k) {
+                const ltk_engine::PfSlot& sl = e->pfs[k];
+                if (sl.valid && sl.avatar == reqs[0].avatar && sl.first == first && sl.nf == total && sl.epoch == knob_epoch()) slot = k;
+            }
+        const bool hit = slot > 0;
+        ltk_engine::SoloSeq* seq_rec = nullptr;
+        if (solo)
+            for (ltk_engine::SoloSeq& q : e->solo_seq)
+                if (q.avatar == reqs[0].avatar && q.next == first && q.nf == total) { seq_rec = &q; break; }
+        const bool prefetch = solo && (hit || seq_rec != nullptr);
+        const int par = slot;
         if (solo) { if (hit) ++e->pf_hits; else ++e->pf_misses; }
-        if ((rc = wait_prefetch(e))) return rc;          // a hit needs its data; everything else needs the buffers it was writing
+        if (hit) {                              // the slot's data must have landed; the slot is consumed by this call
+            CHK(hipStreamWaitEvent(e->compute, e->pfs[slot].ev_done, 0));
+            e->pfs[slot].valid = false;
+            e->pfs[slot].stamp = ++e->pf_clock;
+        }
         if (timing) tp1 = std::chrono::steady_clock::now();
-        const unsigned long seq = e->pass_seq++;
         for (int f0 = 0; f0 < total && !rc; f0 += mbs) {
             const int nf = std::min(mbs, total - f0);
             FacePtrs fp; MelPtrs mp; OutPtrs op;
@@ -1395,25 +1442,43 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             if (hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, "pointer table upload failed");
             else rc = launch_pass(e, nf, e->compute, true, nullptr, true, nullptr, cached, par, hit);
         }
-        if (!rc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
+        if (hit) {                              // the next prefetch into this slot starts behind this pass
+            if (hipEventRecord(e->pfs[slot].ev_read, e->compute) != hipSuccess) { if (!rc) rc = fail(LTK_E_HIP, "hipEventRecord failed"); }
+            else e->pfs[slot].read = true;
+        }
         if (timing) tp2 = std::chrono::steady_clock::now();
         if (!rc && prefetch) {
             // behind the pass (its launch costs the host ~40 us, this one ~15 us: the branch reaches the GPU ~55 us into the pass, beside the
-            // audio encoder): the next call's face encoder, on the third stream
+            // audio encoder): the next call's face encoder, on the third stream, into the least recently used slot other than this call's
+            int victim = 0;
+            for (int k = 1; k <= ltk_engine::kPfSlots; ++k) {
+                if (k == slot) continue;
+                const ltk_engine::PfSlot& sl = e->pfs[k];
+                if (!victim) { victim = k; continue; }
+                const ltk_engine::PfSlot& v = e->pfs[victim];
+                if ((v.valid && !sl.valid) || (v.valid == sl.valid && sl.stamp < v.stamp)) victim = k;
+            }
+            ltk_engine::PfSlot& sl = e->pfs[victim];
+            sl.valid = false;
             FacePtrs nx;
             const Avatar& a = *hold[0];
             for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
+            sl.hold = hold[0];                  // (a previous prefetch into this slot is behind us on aux2: its bank may go now)
             launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
-            rc = launch_prefetch(e, total, par ^ 1, seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr);
+            rc = launch_prefetch(e, total, victim);
+            if (!rc) {
+                ++e->pf_issued;
+                sl.valid = true; sl.avatar = reqs[0].avatar; sl.first = first + total; sl.nf = total; sl.epoch = knob_epoch();
+                sl.stamp = ++e->pf_clock;
+            }
         }
-        if (!rc && prefetch) {
-            ++e->pf_issued;
-            e->pf_hold = hold[0];
-            e->pf.valid = true; e->pf.avatar = reqs[0].avatar; e->pf.first = first + total; e->pf.nf = total; e->pf.parity = par ^ 1;
-            e->pf.epoch = knob_epoch();
+        if (!rc && solo) {                      // where this session's next call will start
+            if (!seq_rec) {
+                seq_rec = &e->solo_seq[0];
+                for (ltk_engine::SoloSeq& q : e->solo_seq) if (q.stamp < seq_rec->stamp) seq_rec = &q;
+            }
+            seq_rec->avatar = reqs[0].avatar; seq_rec->next = first + total; seq_rec->nf = total; seq_rec->stamp = ++e->pf_clock;
         }
-        e->last_solo = ltk_engine::LastSolo();
-        if (!rc && solo) { e->last_solo.avatar = reqs[0].avatar; e->last_solo.first = first; e->last_solo.nf = total; }
         if (!rc) {
             if (hipEventRecord(done, e->compute) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventRecord failed");
         }
@@ -1613,33 +1678,32 @@ int ltk_wav2lip_time_convs(ltk_engine* e, int frames, int iters, float* ms_per_p
     // knob PREFETCH: a session's consecutive <= 32-frame calls are pipelined across calls (tune.h); what is timed is then that steady
     // state - every pass finds its face-encoder outputs prefetched and prefetches the next pass's (dummy bank crops here) - which
     // is what the session's calls enqueue from the third call on
-    e->pf.valid = false;
-    e->last_solo = ltk_engine::LastSolo();
+    for (ltk_engine::PfSlot& sl : e->pfs) sl.valid = false;        // the timing passes fill slots 1 and 2 with dummy crops
     const bool pipe = knob(K_PREFETCH) && e->alt_frames > 0 && frames <= std::min(e->alt_frames, mbs) && knob(K_HEAD_FUSED) && e->c7 && knob(K_CONV7);
     if (pipe) {
         FacePtrs nx;
         for (int i = 0; i < frames; ++i) nx.p[i] = (const uint8_t*)tio.face.p;
         launch_upload_tables(&nx, nullptr, nullptr, frames, e->d_tab_next, e->aux2);
     }
-    int par = 0;
-    bool primed = false;
+    int cur = 0;              // slot this pass works in (0: the priming pass runs the whole network in the arena's own set)
     auto pass = [&]() -> int {
         int prc = 0;
         if (pipe) {
-            if ((prc = wait_prefetch(e))) return prc;
-            const unsigned long seq = e->pass_seq++;
-            hipEvent_t prev = seq > 0 ? e->ev_main[(seq - 1) & 1] : nullptr;
-            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, par, primed);
-            if (!prc && hipEventRecord(e->ev_main[seq & 1], e->compute) != hipSuccess) prc = fail(LTK_E_HIP, "hipEventRecord(ev_main) failed");
-            if (!prc) prc = launch_prefetch(e, frames, par ^ 1, prev);
-            par ^= 1; primed = true;
+            if (cur) CHK(hipStreamWaitEvent(e->compute, e->pfs[cur].ev_done, 0));
+            prc = launch_pass(e, frames, e->compute, true, nullptr, true, nullptr, false, cur, cur != 0);
+            if (cur) {
+                if (hipEventRecord(e->pfs[cur].ev_read, e->compute) != hipSuccess) { if (!prc) prc = fail(LTK_E_HIP, "hipEventRecord failed"); }
+                else e->pfs[cur].read = true;
+            }
+            const int nxt = cur == 1 ? 2 : 1;
+            if (!prc) prc = launch_prefetch(e, frames, nxt);
+            cur = nxt;
             return prc;
         }
         for (int f0 = 0; f0 < frames && !prc; f0 += mbs) prc = launch_pass(e, std::min(mbs, frames - f0), e->compute, true, nullptr, true, nullptr);
         return prc;
     };
-    if ((rc = wait_prefetch(e))) return rc;
-    if (pipe) { rc = pass(); if (!rc) rc = pass(); if (!rc) rc = pass(); if (rc) return rc; }     // prime, then both parities seen once (eager)
+    if (pipe) { rc = pass(); if (!rc) rc = pass(); if (!rc) rc = pass(); if (rc) return rc; }     // prime, then both slots seen once (eager)
     rc = pass();              // warm (eager)
     if (!rc) rc = pass();     // warm (captures the graph under knob GRAPH)
     if (rc) return rc;
@@ -1710,7 +1774,6 @@ int ltk_wav2lip_time_layers(ltk_engine* e, int frames, int iters, float* ms_per_
     if (n_layers != (int)e->layers.size()) return fail(LTK_E_INVALID, "n_layers != ltk_wav2lip_layer_count");
     CHK(enter_device(e->device));
     std::lock_guard<std::mutex> g(e->mu);
-    { const int wrc = wait_prefetch(e); if (wrc) return wrc; }
     if (e->capture) return fail(LTK_E_STATE, "disable capture before timing");
     std::vector<hipEvent_t> evs(e->layers.size() + 1);
     for (auto& ev : evs) CHK(hipEventCreate(&ev));

@@ -554,6 +554,78 @@ def test_face_cache_mode_equals_mode_off(golden_dir):
 
 
 @pytest.mark.gpu
+def test_prefetch_slots_serve_interleaved_sessions(golden_dir):
+    """Round 6: the prefetched face-encoder outputs live in an LRU of slots keyed by (avatar, next bank index, frame count)
+    (csrc/engine.hip PfSlot; round 5 kept ONE engine-wide slot, which interleaved sessions never hit).  Three paced sessions call
+    round-robin - two of them on the SAME avatar at different bank positions, one on another avatar - then one session jumps, one
+    avatar is released and a new session starts on a new avatar.  Every call's frames equal the knob off byte for byte, and every
+    call except the first two of each sequence (the one that starts it, the one that proves it continues) starts at the decoder."""
+    from livetalking_amd.engine import Engine
+    banks = [synth.wav2lip_avatar(n_frames=20, full_hw=(180, 320), box=96, seed=4), synth.wav2lip_avatar(n_frames=7, full_hw=(180, 320), box=96, seed=6),
+             synth.wav2lip_avatar(n_frames=11, full_hw=(180, 320), box=96, seed=8)]
+    gm = np.load(os.path.join(golden_dir, "mel_golden.npz"))
+    feats = gm["ref_chunks"].reshape(-1, 80, 16).astype(np.float32)
+    B = 16
+    # script: ("call", session) | ("jump", session, new index) | ("release", bank) | ("start", session, bank, index)
+    script = [("start", "a", 0, 0), ("start", "b", 0, 5), ("start", "c", 1, 2)]
+    script += [("call", s) for _ in range(6) for s in "abc"]
+    script += [("jump", "b", 3)] + [("call", s) for _ in range(4) for s in "abc"]
+    script += [("release", 1), ("start", "d", 2, 1)] + [("call", s) for _ in range(5) for s in "abd"]
+    n_calls = sum(1 for st in script if st[0] == "call")
+    starts = 3 + 1 + 1          # three sessions, the jump, the new session: two misses each
+    mels = [torch.from_numpy(np.roll(feats, 3 * k, axis=0)[:B].copy() * (1.0 - 0.004 * k)).cuda() for k in range(n_calls)]
+    eng = Engine(0)
+    try:
+        eng.load_wav2lip(synth.wav2lip_state_dict(1234), max_frames=32)
+
+        def run_all():
+            aids = {}
+            sess = {}
+            outs = []
+            k = 0
+            for st in script:
+                if st[0] == "start":
+                    _, name, bank, index = st
+                    if bank not in aids:
+                        fr, fa, co = banks[bank]
+                        aids[bank] = eng.register_avatar(fa, fr, co)
+                    sess[name] = [bank, index]
+                elif st[0] == "jump":
+                    sess[st[1]][1] = st[2]
+                elif st[0] == "release":
+                    eng.release_avatar(aids.pop(st[1]))
+                    for name in [n for n, v in sess.items() if v[0] == st[1]]:
+                        del sess[name]
+                else:
+                    bank, index = sess[st[1]]
+                    pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+                    eng.wav2lip_infer([(aids[bank], index, B, mels[k].data_ptr(), pred.data_ptr())])
+                    outs.append(pred.cpu())
+                    sess[st[1]][1] = index + B
+                    k += 1
+            for a in aids.values():
+                eng.release_avatar(a)
+            return outs
+
+        try:
+            Engine.set_knob("PREFETCH", 0)
+            whole = run_all()
+            st0 = eng.prefetch_stats()
+            Engine.set_knob("PREFETCH", 1)
+            piped = run_all()
+            st = eng.prefetch_stats()
+            hits, misses = st["hits"] - st0["hits"], st["misses"] - st0["misses"]
+            print(f"[prefetch slots] {n_calls} calls of 3 interleaved sessions: hits {hits}, misses {misses} ({100.0 * hits / n_calls:.1f} % of all calls)")
+            for k in range(n_calls):
+                assert torch.equal(piped[k], whole[k]), f"call {k}: max diff {int((piped[k].to(torch.int16) - whole[k].to(torch.int16)).abs().max())} LSB"
+            assert misses == 2 * starts and hits == n_calls - 2 * starts, (hits, misses)
+        finally:
+            Engine.set_knob("PREFETCH", 1)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("graph", [1, 0])
 def test_prefetched_face_encoder_equals_whole_pass(golden_dir, graph):
     """Knob PREFETCH (default on): a session's consecutive single-request calls are pipelined across calls - the face encoder of
