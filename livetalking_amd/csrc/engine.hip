@@ -291,7 +291,7 @@ struct ltk_engine {
     int micro_batch = 0;
     std::vector<Layer> layers;
     f16* buf[B_COUNT] = {nullptr};
-    // knob PREFETCH: kPfSlots further instances of the eight concat buffers ("slots" 1..kPfSlots; set 0 = buf, where a call that runs
+    // knob PREFETCH: kPfSlots (16 x 0.13 GB at 32 frames) further instances of the eight concat buffers ("slots" 1..kPfSlots; set 0 = buf, where a call that runs
     // the whole network works), sized for alt_frames frames, each holding the prefetched face-encoder outputs of ONE upcoming call,
     // keyed by (avatar, first bank index, frame count): interleaved solo calls of several paced sessions each find their own slot
     // (round 5 kept one engine-wide slot, which only a lone session's calls ever hit).  pf_tmp: the prefetched encoder's own
@@ -302,12 +302,13 @@ struct ltk_engine {
         int avatar = -1, first = -1, nf = 0;
         unsigned epoch = 0;
         unsigned long stamp = 0;          // LRU clock of the last fill / use
+        double filled_at = 0;             // host time of the last fill (seconds): a valid slot nobody came for is reclaimed after kPfStale
         hipEvent_t ev_done = nullptr;     // the prefetch into this slot has finished (recorded on aux2)
         hipEvent_t ev_read = nullptr;     // the last pass that worked in this slot has finished (recorded on compute)
         bool filled = false, read = false;
         std::shared_ptr<Avatar> hold;     // the bank a prefetch into this slot reads
     };
-    static constexpr int kPfSlots = 8;
+    static constexpr int kPfSlots = 16;
     PfSlot pfs[kPfSlots + 1];             // [0] unused
     f16* pf_tmp[B_COUNT] = {nullptr};
     int alt_frames = 0;
@@ -1449,15 +1450,21 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
         if (timing) tp2 = std::chrono::steady_clock::now();
         if (!rc && prefetch) {
             // behind the pass (its launch costs the host ~40 us, this one ~15 us: the branch reaches the GPU ~55 us into the pass, beside the
-            // audio encoder): the next call's face encoder, on the third stream, into the least recently used slot other than this call's
+            // audio encoder): the next call's face encoder, on the third stream, into a free slot other than this call's.
+            // Victim: a slot nobody is waiting for - consumed, never used, or filled for a call that did not come within kPfStale seconds
+            // (a session that jumped or left).  A slot another session still waits for is NOT taken: round-robin sessions are the worst
+            // case of plain LRU (the oldest slot belongs to the session that calls next), so with more interleaved sessions than free
+            // slots the surplus sessions simply run whole passes instead of evicting each other.
+            constexpr double kPfStale = 1.5;
+            const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
             int victim = 0;
             for (int k = 1; k <= ltk_engine::kPfSlots; ++k) {
                 if (k == slot) continue;
                 const ltk_engine::PfSlot& sl = e->pfs[k];
-                if (!victim) { victim = k; continue; }
-                const ltk_engine::PfSlot& v = e->pfs[victim];
-                if ((v.valid && !sl.valid) || (v.valid == sl.valid && sl.stamp < v.stamp)) victim = k;
+                if (sl.valid && now - sl.filled_at < kPfStale) continue;
+                if (!victim || sl.stamp < e->pfs[victim].stamp) victim = k;
             }
+            if (victim) {
             ltk_engine::PfSlot& sl = e->pfs[victim];
             sl.valid = false;
             FacePtrs nx;
@@ -1470,6 +1477,8 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
                 ++e->pf_issued;
                 sl.valid = true; sl.avatar = reqs[0].avatar; sl.first = first + total; sl.nf = total; sl.epoch = knob_epoch();
                 sl.stamp = ++e->pf_clock;
+                sl.filled_at = now;
+            }
             }
         }
         if (!rc && solo) {                      // where this session's next call will start
