@@ -675,8 +675,18 @@ def delivered_capacity(args):
     from livetalking_amd.hostshim import mirror_index
     import synth_inputs as synth
     B = args.batch
-    model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
-    eng = model.engine
+    # --pool N: the reference's deployment shape widened to N engines in ONE process (sharding.EnginePool: what app.py's single
+    # process runs on an N-GPU node); on a 1-GPU box the N engines all live on GPU 0 (LTK_DEVICES=0,0,...): what is measured is then
+    # the HOST side of the pool - N schedulers, N enqueue locks, one GIL - the GPU being shared
+    pool = max(0, int(getattr(args, "pool", 0) or 0))
+    if pool > 1:
+        os.environ["LTK_DEVICES"] = ",".join(["0"] * pool)
+        model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256)
+        assert len(model.engines) == pool
+        eng = model.engines[0]
+    else:
+        model = plugin.load_model(None, state_dict=synth.wav2lip_state_dict(1234), max_frames=256, device=0)
+        eng = model.engine
     plugin.warm_up(B, model, 256)
     avatar = synth.wav2lip_bank(n_frames=BANK_FRAMES, full_hw=(720, 1280), box=320, seed=0)
     H, W = avatar[0][0].shape[:2]
@@ -764,13 +774,21 @@ def delivered_capacity(args):
 
     custom = [int(v) for v in args.delivered_sessions.split(",")] if args.delivered_sessions else None
     fmts = [f for f in args.delivered_formats.split(",") if f]
-    out = {"period_ms": period * 1e3, "bank_frames": BANK_FRAMES,
+    out = {"period_ms": period * 1e3, "bank_frames": BANK_FRAMES, "pool_engines": max(1, pool),
            "face_cache": os.environ.get("LTK_FACE_CACHE", "0") not in ("", "0"),
            "bgr24": run_format("", custom or [384, 448, 512]) if "bgr24" in fmts else None,
            "i420": run_format("i420", custom or [384, 448, 512]) if "i420" in fmts else None,
            "note": "plugin level: per session and 0.64-s period one LipReal.inference_batch (16 frames) + 16 host frames (bgr24: paste_back_frame - "
                    "the batch's composites on the GPU, one pinned device-to-host copy; i420: the plugin's opt.egress path, + watermark + BGR->I420 "
                    "on the GPU); one Python thread per session; pinned pool warmed, period 0 excluded"}
+    if pool > 1:       # per engine: sessions placed on it and what its scheduler coalesced
+        per = []
+        for k in range(pool):
+            ss = [x for x in sessions if x._slot == k]
+            st = dict(ss[0]._sched.stats) if ss else {}
+            per.append({"engine": k, "sessions": len(ss), "calls": st.get("calls"), "requests": st.get("requests"), "frames": st.get("frames"),
+                        "max_requests_per_call": st.get("max_requests_per_call")})
+        out["per_engine"] = per
     for g in egs:
         if g is not None:
             g.close()
@@ -972,6 +990,7 @@ def main():
     ap.add_argument("--dry-ranks", action="store_true", help="launcher / barrier protocol only, no GPU (CPU test)")
     ap.add_argument("--delivered-sessions", default="", help="session counts of the delivered-capacity run (default: 384,448,512 for both frame formats)")
     ap.add_argument("--delivered-formats", default="bgr24,i420", help="frame formats of the delivered-capacity run")
+    ap.add_argument("--pool", type=int, default=0, help="--sub delivered-capacity: N engines in this one process (EnginePool; on a 1-GPU box all on GPU 0)")
     ap.add_argument("--sub", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sustain is None:

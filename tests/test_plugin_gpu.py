@@ -165,6 +165,68 @@ def test_two_engines_two_sessions_render_concurrently(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_pool_of_four_engines_32_sessions_equals_single_engine(monkeypatch):
+    """The reference deploys ONE process (app.py:62-63,99; server/session_manager.py:56-94): on an N-GPU node that process holds an
+    EnginePool of N engines.  Here N = 4 (all on GPU 0: the box has one), 8 sessions per engine, 32 session threads rendering
+    three steps each through inference_batch + paste_back_frame at once: the placement is 8 / 8 / 8 / 8, every engine's scheduler
+    coalesces only its own sessions, and every session's composited frames are byte-identical to the same session rendered alone
+    on a single engine.  (LTK_SPLITK=0: one summation order per output element whatever a call was coalesced with - without it
+    frames differ by <= 1 LSB with the coalescing pattern, which is timing dependent.)"""
+    import threading
+    import livetalking_amd.avatars.wav2lip_avatar as plugin
+    from livetalking_amd.engine import Engine
+    E, per, B, steps = 4, 8, 4, 3
+    sd_np = synth.wav2lip_state_dict(1234)
+    avatars = [synth.wav2lip_avatar(n_frames=5, full_hw=(180, 320), box=96, seed=20 + k) for k in range(3)]
+    rng = np.random.default_rng(7)
+    feats = [torch.from_numpy(rng.standard_normal((B, 80, 16)).astype(np.float32)).cuda() for _ in range(E * per)]
+
+    def render(sess, i, out):
+        frames = []
+        for step in range(steps):
+            index = step * B + i
+            pred = sess.inference_batch(index, feats[i])
+            frames += [sess.paste_back_frame(pred[k], plugin.mirror_index(5, index + k)).copy() for k in range(B)]
+        out[i] = np.stack(frames)
+
+    Engine.set_knob("SPLITK", 0)
+    try:
+        # reference run: one engine, the sessions one after the other
+        monkeypatch.setenv("LTK_DEVICES", "0")
+        model1 = plugin.load_model(None, state_dict=sd_np, max_frames=64)
+        ref = {}
+        for i in range(E * per):
+            opt = argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=i)
+            render(plugin.LipReal(opt, model1, avatars[i % 3]), i, ref)
+        for e in model1.engines:
+            e.close()
+        # the pool: 4 engines, 32 sessions at once
+        monkeypatch.setenv("LTK_DEVICES", "0,0,0,0")
+        model = plugin.load_model(None, state_dict=sd_np, max_frames=64)
+        assert len(model.engines) == E and len({id(e) for e in model.engines}) == E
+        sessions = [plugin.LipReal(argparse.Namespace(fps=25, batch_size=B, l=10, r=10, sessionid=i), model, avatars[i % 3]) for i in range(E * per)]
+        assert sorted(s._slot for s in sessions) == sorted(list(range(E)) * per), "least-loaded placement: 8 sessions per engine"
+        got = {}
+        ts = [threading.Thread(target=render, args=(sessions[i], i, got)) for i in range(E * per)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=180)
+        assert len(got) == E * per
+        for i in range(E * per):
+            assert np.array_equal(got[i], ref[i]), f"session {i} (engine {sessions[i]._slot})"
+        scheds = {id(s._sched): s._sched for s in sessions}
+        assert len(scheds) == E
+        tot = sum(sc.stats["requests"] for sc in scheds.values())
+        print("[pool] per-engine scheduler stats: " + "; ".join(f"calls {sc.stats['calls']} requests {sc.stats['requests']} max/call {sc.stats['max_requests_per_call']}" for sc in scheds.values()))
+        assert tot == E * per * steps and all(sc.stats["requests"] == per * steps for sc in scheds.values())
+        for e in model.engines:
+            e.close()
+    finally:
+        Engine.set_knob("SPLITK", 1)
+
+
+@pytest.mark.gpu
 def test_paste_back_batch_equals_per_frame_and_frames_stay_valid():
     """LipReal.paste_back_frame through the batch path (B composites on the device + ONE pinned device-to-host copy on the first
     request of a batch: ltk_paste_back_batch) returns, frame by frame, exactly what the per-frame entry point returns, the
