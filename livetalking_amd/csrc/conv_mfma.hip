@@ -63,6 +63,10 @@ struct KArgs {
     unsigned magicPW, magicPHW;
     int nchunks, Tp, relu;
     int lds_bytes;
+    int s2half;                       // > 0: column-parity split of the patch rows (stride-2 3x3 layers): patch column px sits at slot
+                                      // (px >> 1) + (px & 1) * s2half of its row, so the 16 lanes of a ds_read_b128 group - 16 consecutive
+                                      // output pixels, i.e. every OTHER patch pixel - read 256 contiguous bytes instead of two 16-byte
+                                      // items per 32 (a 2-way bank conflict on every A read: 30.7 % of this kernel's LDS cycles in round 5)
 };
 
 // A-patch staging registers per thread (16-byte items): the largest variant a configuration has.
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
 
     // ---- A staging descriptors (chunk independent)
     int a_goff[MAXA];
+    int a_slot[MAXA];                 // LDS pixel slot of the item (the identity unless s2half)
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
         const int i = tid + k * 256;
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         const int py = (a.PW == 1) ? rem : (int)__umulhi((unsigned)rem, a.magicPW);
         const int px = rem - py * a.PW;
         const int n = n0 + b, iy = iy0 + py, ix = ix0 + px;
+        a_slot[k] = a.s2half ? b * PHW + py * a.PW + (px >> 1) + (px & 1) * a.s2half : pix;
         const bool ok = (i < nitemsA) && (n < a.N) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
         if constexpr (NC8 == 1)   // the two network inputs (packed face crops, mel windows) are plain [N][H][W][8]
             a_goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * 8) : -1;
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         for (int k = 0; k < MAXA; ++k) {
             const int i = tid + k * 256;
             if (i < nitemsA) {
-                const int pix = i >> LOG2NC8, c8 = i & (NC8 - 1);
-                *reinterpret_cast<uint4*>(Ab + (c8 * a.NPIXP + pix) * 16) = ra[k];
+                const int c8 = i & (NC8 - 1);
+                *reinterpret_cast<uint4*>(Ab + (c8 * a.NPIXP + a_slot[k]) * 16) = ra[k];
             }
         }
 #pragma unroll
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
         const int ty = (m >> a.log2TW) & THm;
         const int b = m >> (a.log2TW + a.log2TH);
         const bool inb = b < a.NB;
-        pixb[j] = inb ? ((b * a.PH + ty * a.sh) * a.PW + tx * a.sw) * 16 : 0;
+        pixb[j] = inb ? ((b * a.PH + ty * a.sh) * a.PW + (a.s2half ? tx : tx * a.sw)) * 16 : 0;      // s2half: column 2 tx sits at slot tx
         const int n = n0 + b, oy = ty0 + ty, ox = tx0 + tx;
         const bool rowok = inb && n < a.N && oy < a.Ho && ox < a.Wo;
         const int opx = (oy * a.osy + ooy) * a.WoA + ox * a.osx + oox;
@@ -272,8 +278,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs a) {
                 }
             };
             if constexpr (TT9) {
+                const int dxo1 = a.s2half ? a.s2half : 1, dxo2 = a.s2half ? 1 : 2;     // slot offset of patch column +1 / +2 (wave-uniform)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) tap_body(t, ((t / 3) * a.PW + (t % 3)) * 16);
+                for (int t = 0; t < 9; ++t) tap_body(t, ((t / 3) * a.PW + ((t % 3) == 0 ? 0 : (t % 3) == 1 ? dxo1 : dxo2)) * 16);
             } else {
                 for (int t = 0; t < T; ++t) tap_body(t, (int)tapl[t] * 16);
             }
@@ -814,6 +821,8 @@ int conv_launch(const ConvPlan& p, const ConvIO& io, hipStream_t stream, std::st
     lds = (lds + 255) / 256 * 256;
     if (lds > (size_t)kLdsLimit) { if (err) *err = "LDS budget exceeded"; return -1; }
     a.lds_bytes = (int)lds;
+    // stride-2 3x3 layers whose tile rows hold >= 16 output pixels: column-parity split of the patch rows (KArgs::s2half)
+    a.s2half = (p.tt9 && a.sw == 2 && l2w >= 4 && knob(K_CONV_S2SPLIT)) ? (PW + 1) / 2 : 0;
     // largest 32-bit element offset the kernel forms
     if ((double)io.N * io.H * io.W * io.x_ld >= 2147483647.0) { if (err) *err = "input tensor too large for 32-bit offsets"; return -1; }
 

@@ -73,6 +73,8 @@ enum Knob {
     K_SAT_CHECK,          // LTK_SAT_CHECK      debug, default 0: behind every layer / op its output is scanned for values AT the limit of its type (what an epilogue's
                           //                    clamp to +-65504 leaves behind; +-448 for e4m3) and for non-finite values; counters through ltk_debug_saturation.
                           //                    The fused Wav2Lip head (which writes bytes) runs unfused under it.
+    K_CONV_S2SPLIT,       // LTK_CONV_S2SPLIT   1 (default): the first-generation kernel's stride-2 3x3 layers (face_encoder_blocks.1.0 / 2.0) stage their patch rows
+                          //                    split by column parity, so that a ds_read_b128 lane group reads 256 contiguous bytes (conv_mfma.hip KArgs::s2half)
     K_COUNT
 };
 

@@ -42,6 +42,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_MT_GN1", 1},
     {"LTK_ATTN_PF", 1},
     {"LTK_SAT_CHECK", 0},
+    {"LTK_CONV_S2SPLIT", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
