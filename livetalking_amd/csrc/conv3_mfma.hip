@@ -88,6 +88,15 @@ struct K3Args {
     int lds_scale_off;               // byte offset of the [2][BN] fp32 scale/shift image behind the stages
     int swz_x, swz_row;              // stride-1 LDS image: the two 16-B halves of a patch pixel swap where bit 3 of its COLUMN is set (swz_x: tile rows of 32
                                      // pixels) / where its patch ROW is odd (swz_row: narrower tiles, where a 16-lane read group spans several rows)
+    // LayerNorm folded into the two linear layers around it (1x1 layers, MuseTalk transformer blocks; musetalk.hip build_transformer):
+    //   ln_out: this layer's output is a tensor a LayerNorm normalises - the epilogue also writes, per token and 32-channel tile, the sum
+    //           and the sum of squares of the fp16 values it stores ([Mtot][ln_out_tiles] float2; one writer per entry, no atomics);
+    //   ln_in:  this layer CONSUMES a LayerNorm'ed tensor but reads the RAW one: with W' = W diag(gamma) packed as the weights,
+    //           scale[co] = sum_ci W'[co][ci] and shift[co] = sum_ci W[co][ci] beta[ci] + bias[co], the epilogue computes
+    //           rstd_t * (acc - mean_t * scale[co]) + shift[co] = W LN(x)_t + bias, mean_t / rstd_t from the producer's partials.
+    float* ln_out; const float* ln_in;
+    int ln_out_tiles, ln_in_tiles;
+    float ln_eps;
     int ablate;                      // measurement builds only (make ABLATE=1, knob LTK_ABLATE): 1 no A DMA, 2 no B DMA, 4 no MFMA,
                                      // 8 no residual read, 16 no output store, 32 no LDS zero fill, 64 no epilogue, 128 epilogue math only
     long long Mtot;                  // N*HoA*WoA (slab pitch in pixels)
@@ -580,6 +589,18 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
 
     // the activation is a compile-time parameter of the epilogue body (one wave-uniform branch selects the copy):
     // as a per-value runtime test hipcc if-converted it and every value paid for erff and exp
+    // LayerNorm fold, consumer side: mean / rstd of this lane's token in subtile j from the producer's per-tile partial sums (the two
+    // lanes of a pixel read alternate tiles, fixed order: deterministic)
+    auto ln_token_stats = [&](int tok, float* mean, float* rstd) {
+        const float2* pp = reinterpret_cast<const float2*>(a.ln_in) + (size_t)tok * a.ln_in_tiles;
+        float su = 0.f, sq = 0.f;
+        for (int t = hh; t < a.ln_in_tiles; t += 2) { const float2 v = pp[t]; su += v.x; sq += v.y; }
+        su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+        const float invC = 1.f / (float)(a.ln_in_tiles * 32);
+        const float m = su * invC;
+        *mean = m;
+        *rstd = rsqrtf(fmaxf(sq * invC - m * m, 0.f) + a.ln_eps);
+    };
     auto epilogue = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         // Loop order: (phase, cout block) outside, the wave's PXW pixel subtiles inside.  The folded-BN scale/shift of a cout
@@ -590,15 +611,26 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
         for (int g = 0; g < G; ++g) {
             int obase[PXW], rbase[PXW];
             bool okj[PXW];
+            int tok[PXW];                               // T == 1, LayerNorm fold: token index (image, pixel) of this lane's pixel
+            float lmean[PXW], lrstd[PXW];
+            const bool ln_cons = T == 1 && a.ln_in != nullptr, ln_prod = T == 1 && a.ln_out != nullptr;
 #pragma unroll
             for (int j = 0; j < PXW; ++j) {
                 int n;
                 const int opx = out_px(j, g, &n, &okj[j]);
                 obase[j] = ((n * a.y_cbt + a.y_cb0 + cbo) * HWo + opx) * 16 + hh * 8;
                 rbase[j] = ((n * a.res_cbt + a.res_cb0 + cbo) * HWo + opx) * 16 + hh * 4;
+                if constexpr (T == 1) {
+                    tok[j] = okj[j] ? n * HWo + opx : 0;
+                    lmean[j] = 0.f; lrstd[j] = 1.f;
+                    if (ln_cons) ln_token_stats(tok[j], &lmean[j], &lrstd[j]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NBT; ++i) {
+                float ls[PXW], lq[PXW];                 // producer side: sums of this lane's 16 stored values of tile i
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) { ls[j] = 0.f; lq[j] = 0.f; }
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {        // channel block 2i+pr of this block's BN
                     if ((2 * i + pr) >= ncb_valid) continue;         // wave-uniform
@@ -629,8 +661,18 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                         for (int eo = 0; eo < 2; ++eo) {
                             const int q4 = 2 * pr + eo;
                             float v[4];
+                            if constexpr (T == 1) {
+                                if (ln_cons) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[eo][r] + sf[eo][r];
+                                    for (int r = 0; r < 4; ++r) v[r] = lrstd[j] * (acc[g][i][j][4 * q4 + r] - lmean[j] * sc[eo][r]) + sf[eo][r];
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[eo][r] + sf[eo][r];
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = acc[g][i][j][4 * q4 + r] * sc[eo][r] + sf[eo][r];
+                            }
                             if (has_res && okj[j]) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[j][eo][r];
@@ -648,6 +690,12 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                                 }
                                 o[r] = (f16)t;
                             }
+                            if constexpr (T == 1) {
+                                if (ln_prod) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; ls[j] += f; lq[j] += f * f; }
+                                }
+                            }
                             const uint2 u = *reinterpret_cast<const uint2*>(&o);
                             pk[eo][0] = u.x; pk[eo][1] = u.y;
                         }
@@ -657,6 +705,16 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
                         const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         if (okj[j] && do_store) *reinterpret_cast<uint4*>(a.y + obase[j] + (2 * i + pr) * HWo16) = out;
+                    }
+                }
+                if constexpr (T == 1) {
+                    if (ln_prod && 2 * i < ncb_valid) {
+#pragma unroll
+                        for (int j = 0; j < PXW; ++j) {
+                            const float su = ls[j] + __shfl_xor(ls[j], 32), sq = lq[j] + __shfl_xor(lq[j], 32);
+                            if (okj[j] && hh == 0)
+                                reinterpret_cast<float2*>(a.ln_out)[(size_t)tok[j] * a.ln_out_tiles + (cout0 >> 5) + i] = make_float2(su, sq);
+                        }
                     }
                 }
             }
@@ -671,11 +729,15 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
             const int cbo2 = cout0 >> 5;
             int obase[PXW];
             bool okj[PXW];
+            float lmean[PXW], lrstd[PXW];
+            const bool ln_cons = a.ln_in != nullptr;
 #pragma unroll
             for (int j = 0; j < PXW; ++j) {
                 int n;
                 const int opx = out_px(j, 0, &n, &okj[j]);
                 obase[j] = ((n * a.y_cbt + a.y_cb0 + cbo2) * HWo + opx) * 16 + hh * 8;
+                lmean[j] = 0.f; lrstd[j] = 1.f;
+                if (ln_cons) ln_token_stats(okj[j] ? n * HWo + opx : 0, &lmean[j], &lrstd[j]);
             }
 #pragma unroll
             for (int i = 0; i < NBT; ++i) {
@@ -695,8 +757,14 @@ __device__ __forceinline__ void conv3_item(const K3Args& a, const int bid, unsig
                         f16x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = acc[0][i][j][4 * eo + r] * scv[eo][r] + sfv[eo][r];
-                            const float gt = acc[0][i][j][4 * (2 + eo) + r] * scg[eo][r] + sfg[eo][r];
+                            float v, gt;
+                            if (ln_cons) {
+                                v = lrstd[j] * (acc[0][i][j][4 * eo + r] - lmean[j] * scv[eo][r]) + sfv[eo][r];
+                                gt = lrstd[j] * (acc[0][i][j][4 * (2 + eo) + r] - lmean[j] * scg[eo][r]) + sfg[eo][r];
+                            } else {
+                                v = acc[0][i][j][4 * eo + r] * scv[eo][r] + sfv[eo][r];
+                                gt = acc[0][i][j][4 * (2 + eo) + r] * scg[eo][r] + sfg[eo][r];
+                            }
                             const float t = v * gelu_as(gt);
                             o[r] = (f16)__builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
                         }
@@ -999,6 +1067,13 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     const int fks = io.force_ksplit ? io.force_ksplit : knob(K_KSPLIT);
     if (fks > 0 && knob(K_SPLITK)) ksplit = std::max(1, std::min(std::min(fks, kMaxKSplit), a.nchunks));
     if (io.head_w != nullptr && io.head_outs != nullptr) ksplit = 1;      // the fused head finishes in the epilogue: no partial slabs
+    a.ln_out = io.ln_out; a.ln_in = io.ln_in; a.ln_out_tiles = io.ln_out_tiles; a.ln_in_tiles = io.ln_in_tiles; a.ln_eps = io.ln_eps;
+    if (io.ln_out || io.ln_in) {                                          // LayerNorm fold: 1x1 layers, the epilogue sees whole sums
+        if (!(G == 1 && T == 1 && !p.q8) || (io.ln_out && (p.lCout % 32 || io.ln_out_tiles != p.lCout / 32)) || (io.ln_in && io.ln_in_tiles <= 0)) {
+            if (err) *err = "conv3: the LayerNorm fold is a 1x1-layer feature (32-channel tiles)"; return -1;
+        }
+        ksplit = 1;
+    }
     if (a.relu == 4) {                                                    // GEGLU epilogue: value and gate meet in the accumulators
         if (!(G == 1 && T == 1 && !p.q8 && p.lCout % 32 == 0 && !io.res)) { if (err) *err = "conv3: the GEGLU epilogue is a 1x1-layer feature"; return -1; }
         ksplit = 1;

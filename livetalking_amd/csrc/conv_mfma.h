@@ -139,6 +139,12 @@ struct ConvIO {
     const float* head_w = nullptr;     // conv3, 3x3 stride-1 layers of 32 output channels only: fuse the Wav2Lip output head
     const void* head_outs = nullptr;   // (1x1 conv 32->3 + sigmoid + uint8 truncation; wav2lip_v2.py:90-91): device [3][32]+[3]
                                        // weights and a DEVICE table (OutPtrs, misc_kernels.h) of per-frame uint8 [256][256][3] outputs; `y` unused
+    // conv3 1x1 / rowconv: LayerNorm folded into the linear layers around it (conv3_mfma.hip K3Args): ln_out = per (token, 32-channel
+    // tile) sum / sum of squares of the stored output, [tokens][ln_out_tiles] float2; ln_in = the same of the INPUT tensor, with
+    // ln_in_tiles = its channels / 32: the layer then computes W LN(x) + b from the raw x (weights / scale / shift folded by the caller)
+    float* ln_out = nullptr; const float* ln_in = nullptr;
+    int ln_out_tiles = 0, ln_in_tiles = 0;
+    float ln_eps = 1e-5f;
     float* partial = nullptr;      // split-K scratch (fp32 slabs) and its capacity in bytes; conv3 splits the
     size_t partial_cap = 0;        // channel loop of under-filled launches only when this is large enough
 };
@@ -176,6 +182,9 @@ struct RowConvIO {
     const f16* res = nullptr; int res_ld = 0, res_coff = 0;              // residual with the output's geometry, or nullptr
     int N = 0, KW = 3, stride = 1, pad = 1, relu = 1;
     int stride_w = 0;                                                    // column stride when it differs from `stride` (0 = the same)
+    float* ln_out = nullptr; const float* ln_in = nullptr;               // LayerNorm fold, as ConvIO (1x1 plans only)
+    int ln_out_tiles = 0, ln_in_tiles = 0;
+    float ln_eps = 1e-5f;
 };
 int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream, std::string* err);
 // ConvTranspose2d(k3, s2, p1, op1) on a source map of <= 8 x 8 pixels: four per-phase plans p[py * 2 + px] over

@@ -85,6 +85,10 @@ struct MtOp {
     float eps = 1e-5f;
     int heads = 1, d16 = 0;
     int Tk = 0;
+    // LayerNorm fold (MT_FUSE bit 2; conv3_mfma.hip K3Args::ln_*): ln_out_buf = this linear layer also writes its output's per-token
+    // partial sums there; ln_in_buf = it consumes a LayerNorm'ed tensor but reads the raw one, statistics from that buffer
+    int ln_out_buf = -1, ln_in_buf = -1, ln_in_tiles = 0;
+    float ln_eps = 1e-5f;
     int vt_buf = -1;            // OP_ATTN: the values are already transposed in this buffer (written by the pass's OP_VT), else the shared scratch
 };
 
@@ -148,9 +152,16 @@ struct MtGraph {
         return (int)vecs.size() - 1;
     }
     // conv / linear: weight [Cout][Cin][k][k] fp32 host, bias [Cout] or null
+    // `scale` (or null = 1): per-output-channel factor of the epilogue (the LayerNorm fold passes sum_ci W'[co][ci] here)
     int add_conv(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int k, int stride, int pad,
-                 const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups) {
-        return add_conv2(name, w, bias, Cin, Cout, k, k, stride, stride, pad, pad, x, y, res, act, ups);
+                 const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups, const float* scale = nullptr) {
+        return add_conv2(name, w, bias, Cin, Cout, k, k, stride, stride, pad, pad, x, y, res, act, ups, 0, scale);
+    }
+    // per-token partial statistics of a C-channel tensor on an H x W map: [tokens][C / 32] float2 (LayerNorm fold)
+    int alloc_ln_stats(int C, int H, int W) {
+        const int b = (int)buf_halfs.size();
+        buf_halfs.push_back((size_t)H * W * (C / 32) * 4);          // float2 = 4 halfs
+        return b;
     }
     // diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + Conv2d(k3, s2, p0)  (AutoencoderKL encoder)
     int add_conv_down_asym(const std::string& name, const float* w, const float* bias, int C, const MtTensor& x, const MtTensor& y) {
@@ -158,7 +169,8 @@ struct MtGraph {
     }
     // rectangular kernel / stride (Conv1d over a [T][1] token map: kh x 1)
     int add_conv2(const std::string& name, const float* w, const float* bias, int Cin, int Cout, int kh, int kw, int sh, int sw,
-                  int ph, int pw, const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups, int pad_br = 0) {
+                  int ph, int pw, const MtTensor& x, const MtTensor& y, const MtTensor* res, int act, int ups, int pad_br = 0,
+                  const float* scale = nullptr) {
         const int k = kh, stride = sh;
         const int kk = kh * kw;
         (void)k;
@@ -178,6 +190,7 @@ struct MtGraph {
         if (x.q8) macs_fp8 += (double)CinR * Cout * kk * y.P();
         std::vector<float> sc(CoutP, 1.f), sf(CoutP, 0.f);
         if (bias) memcpy(sf.data(), bias, Cout * sizeof(float));
+        if (scale) memcpy(sc.data(), scale, Cout * sizeof(float));
         ConvPlan p;
         std::string e;
         int rc = conv_plan_create(&p, wuse, Cin, CoutP, kh, kw, sh, sw, ph, pw, false, pad_br, sc.data(), sf.data(), &e, x.P(),
@@ -291,6 +304,29 @@ std::vector<float> pad_heads_cols(const float* w, int Cout, int heads, int d, in
     return o;
 }
 
+// LayerNorm folded into the linear layer behind it (MT_FUSE bit 2): y = W LN(x) + b = rstd * (W' x - mean * scale) + shift with
+//   W'[co][ci] = W[co][ci] gamma[ci]   (what is packed as the layer's fp16 weights),
+//   scale[co]  = sum_ci fp16(W'[co][ci])   (of the ROUNDED weights, so that the mean term cancels exactly what the MFMAs summed),
+//   shift[co]  = sum_ci W[co][ci] beta[ci] + b[co];
+// mean / rstd per token come from the partial sums the producer of x wrote (stats_buf).
+struct LnFold { const float* gamma; const float* beta; int C; int stats_buf; float eps; };
+void ln_fold(const float* w, const float* bias, int Cout, const LnFold& ln, std::vector<float>* wf, std::vector<float>* scale,
+             std::vector<float>* shift) {
+    const int C = ln.C;
+    wf->resize((size_t)Cout * C); scale->assign(Cout, 0.f); shift->assign(Cout, 0.f);
+    for (int co = 0; co < Cout; ++co) {
+        double ssum = 0.0, bsum = bias ? (double)bias[co] : 0.0;
+        for (int ci = 0; ci < C; ++ci) {
+            const float v = w[(size_t)co * C + ci] * ln.gamma[ci];
+            (*wf)[(size_t)co * C + ci] = v;
+            ssum += (double)(float)(f16)v;
+            bsum += (double)w[(size_t)co * C + ci] * ln.beta[ci];
+        }
+        (*scale)[co] = (float)ssum;
+        (*shift)[co] = (float)bsum;
+    }
+}
+
 float silu_h(float v) { return v / (1.f + expf(-v)); }
 
 // UNet2DConditionModel time_proj(flip_sin_to_cos=True, freq_shift=0) + time_embedding at timestep t, then SiLU
@@ -371,7 +407,10 @@ int build_resnet(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, co
 // `kv_pre` (or null): {k view, v view} of a projection that already ran (the hoisted, stacked k | v projection of every
 // cross-attention, mt_build_unet), `vt_pre` the buffer its transposed values are in
 int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x, const MtTensor& ctx, int C, int Cctx, int heads,
-                    bool qkv_bias, const MtTensor& res, const MtTensor& out, const MtTensor* kv_pre = nullptr, int vt_pre = -1) {
+                    bool qkv_bias, const MtTensor& res, const MtTensor& out, const MtTensor* kv_pre = nullptr, int vt_pre = -1,
+                    const LnFold* ln = nullptr, int ln_out_buf = -1) {
+    // `ln`: x is the RAW tensor of a LayerNorm in front of this attention; the projections that read it are built folded (ln_fold).
+    // `ln_out_buf` >= 0: to_out.0 (+ residual) also writes the per-token partial statistics of its output there (the next LayerNorm's)
     const int d = C / heads, d16 = up16(d), Cp = heads * d16;
     const float scale = 1.0f / sqrtf((float)d);
     const float* wq = sd.get(p + ".to_q.weight", (size_t)C * C);
@@ -400,14 +439,25 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
     const bool fuse = !knob(K_MT_NO_QKV_FUSE);      // A/B switch
     const bool self = fuse && x.buf == ctx.buf && x.coff == ctx.coff && x.C == ctx.C;
     MtTensor q, k, v, o = g.alloc(Cp, x.H, x.W);
+    // a projection of x: plain, or with the LayerNorm in front of it folded in
+    auto proj_x = [&](const std::string& name, const std::vector<float>& w, const std::vector<float>& b, int Cout, const MtTensor& y) -> int {
+        if (!ln) return g.add_conv(name, w.data(), b.data(), C, Cout, 1, 1, 0, x, y, nullptr, 0, 0);
+        std::vector<float> wf, sc, sf;
+        ln_fold(w.data(), b.data(), Cout, *ln, &wf, &sc, &sf);
+        if (g.add_conv(name, wf.data(), sf.data(), C, Cout, 1, 1, 0, x, y, nullptr, 0, 0, sc.data())) return -1;
+        MtOp& op = g.ops.back();
+        op.ln_in_buf = ln->stats_buf; op.ln_in_tiles = ln->C / 32; op.ln_eps = ln->eps;
+        return 0;
+    };
+    if (ln && !(kv_pre || self)) { g.err = p + ": the LayerNorm fold needs the stacked q|k|v projection or a hoisted k|v"; return -1; }
     if (kv_pre) {
         q = g.alloc(Cp, x.H, x.W);
-        if (g.add_conv(p + ".to_q", wqp.data(), bqp.data(), C, Cp, 1, 1, 0, x, q, nullptr, 0, 0)) return -1;
+        if (proj_x(p + ".to_q", wqp, bqp, Cp, q)) return -1;
         k = kv_pre[0]; v = kv_pre[1];
     } else if (self) {
         MtTensor qkv = g.alloc(3 * Cp, x.H, x.W);
         const std::vector<float> w3 = stack({&wqp, &wkp, &wvp}), b3 = stack({&bqp, &bkp, &bvp});
-        if (g.add_conv(p + ".to_qkv", w3.data(), b3.data(), C, 3 * Cp, 1, 1, 0, x, qkv, nullptr, 0, 0)) return -1;
+        if (proj_x(p + ".to_qkv", w3, b3, 3 * Cp, qkv)) return -1;
         q = MtGraph::view(qkv, 0, Cp); k = MtGraph::view(qkv, Cp, Cp); v = MtGraph::view(qkv, 2 * Cp, Cp);
     } else if (!fuse) {
         q = g.alloc(Cp, x.H, x.W); k = g.alloc(Cp, ctx.H, ctx.W); v = g.alloc(Cp, ctx.H, ctx.W);
@@ -424,7 +474,9 @@ int build_attention(MtGraph& g, SD& sd, const std::string& p, const MtTensor& x,
     }
     g.named[p + ".to_q"] = q; g.named[p + ".to_k"] = k; g.named[p + ".to_v"] = v;
     g.add_attn(p, q, k, v, o, heads, d16, kv_pre ? vt_pre : -1);
-    return g.add_conv(p + ".to_out.0", wop.data(), bo, Cp, C, 1, 1, 0, o, out, &res, 0, 0);
+    if (g.add_conv(p + ".to_out.0", wop.data(), bo, Cp, C, 1, 1, 0, o, out, &res, 0, 0)) return -1;
+    g.ops.back().ln_out_buf = ln_out_buf;
+    return 0;
 }
 
 // diffusers Transformer2DModel (conv proj_in/out) with one BasicTransformerBlock (GEGLU feed-forward)
@@ -438,44 +490,82 @@ int build_transformer(MtGraph& g, SD& sd, const std::string& p, const MtTensor& 
     MtTensor h0 = g.alloc(C, H, W);
     if (g.add_conv(p + ".proj_in", wi, bi, C, C, 1, 1, 0, t, h0, nullptr, 0, 0)) return -1;
     const std::string b = p + ".transformer_blocks.0";
-    MtTensor n1 = g.alloc(C, H, W), h1 = g.alloc(C, H, W);
-    if (g.add_ln(b + ".norm1", sd, b + ".norm1", h0, n1, 1e-5f)) return -1;
-    if (build_attention(g, sd, b + ".attn1", n1, n1, C, C, 8, false, h0, h1)) return -1;
-    MtTensor n2 = g.alloc(C, H, W), h2 = g.alloc(C, H, W);
-    if (g.add_ln(b + ".norm2", sd, b + ".norm2", h1, n2, 1e-5f)) return -1;
-    {
+    // MT_FUSE bit 2: the three LayerNorms disappear into the linear layers around them - the producer of a normalised tensor
+    // (proj_in, attn1.to_out.0, attn2.to_out.0) writes per-token partial sums beside its output, the consumer (to_qkv, attn2.to_q,
+    // ff.net.0.proj) reads the raw tensor with gamma folded into its weights and normalises in its epilogue (ln_fold).  48 launches
+    // and as many tensor round trips of a pass; needs the stacked q|k|v projection and the hoisted cross-attention k|v (bit 1).
+    const bool fold = (knob(K_MT_FUSE) & 4) && (knob(K_MT_FUSE) & 2) && !knob(K_MT_NO_QKV_FUSE) && C % 32 == 0 &&
+                      g.kv_pre.find(b + ".attn2") != g.kv_pre.end();
+    LnFold l1{nullptr, nullptr, C, -1, 1e-5f}, l2 = l1, l3 = l1;
+    if (fold) {
+        const char* nm[3] = {".norm1", ".norm2", ".norm3"};
+        LnFold* ls[3] = {&l1, &l2, &l3};
+        for (int i = 0; i < 3; ++i) {
+            ls[i]->gamma = sd.get(b + nm[i] + ".weight", C);
+            ls[i]->beta = sd.get(b + nm[i] + ".bias", C);
+            if (!ls[i]->gamma || !ls[i]->beta) { g.err = sd.err; return -1; }
+            ls[i]->stats_buf = g.alloc_ln_stats(C, H, W);
+        }
+        g.ops.back().ln_out_buf = l1.stats_buf;           // proj_in
+    }
+    MtTensor n1, h1 = g.alloc(C, H, W);
+    if (fold) {
+        if (build_attention(g, sd, b + ".attn1", h0, h0, C, C, 8, false, h0, h1, nullptr, -1, &l1, l2.stats_buf)) return -1;
+    } else {
+        n1 = g.alloc(C, H, W);
+        if (g.add_ln(b + ".norm1", sd, b + ".norm1", h0, n1, 1e-5f)) return -1;
+        if (build_attention(g, sd, b + ".attn1", n1, n1, C, C, 8, false, h0, h1)) return -1;
+    }
+    MtTensor n2, h2 = g.alloc(C, H, W);
+    if (fold) {
+        auto kv = g.kv_pre.find(b + ".attn2");
+        const MtTensor pre[2] = {kv->second.k, kv->second.v};
+        if (build_attention(g, sd, b + ".attn2", h1, ctx, C, 384, 8, false, h1, h2, pre, kv->second.vt_buf, &l2, l3.stats_buf)) return -1;
+    } else {
+        n2 = g.alloc(C, H, W);
+        if (g.add_ln(b + ".norm2", sd, b + ".norm2", h1, n2, 1e-5f)) return -1;
         auto kv = g.kv_pre.find(b + ".attn2");
         if (kv != g.kv_pre.end()) {
             const MtTensor pre[2] = {kv->second.k, kv->second.v};
             if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2, pre, kv->second.vt_buf)) return -1;
         } else if (build_attention(g, sd, b + ".attn2", n2, ctx, C, 384, 8, false, h1, h2)) return -1;
     }
-    MtTensor n3 = g.alloc(C, H, W), f1, gg = g.alloc(4 * C, H, W), h3 = g.alloc(C, H, W);
+    MtTensor n3, f1, gg = g.alloc(4 * C, H, W), h3 = g.alloc(C, H, W);
     if (!(knob(K_MT_FUSE) & 1)) f1 = g.alloc(8 * C, H, W);
-    if (g.add_ln(b + ".norm3", sd, b + ".norm3", h2, n3, 1e-5f)) return -1;
+    if (!fold) {
+        n3 = g.alloc(C, H, W);
+        if (g.add_ln(b + ".norm3", sd, b + ".norm3", h2, n3, 1e-5f)) return -1;
+    }
     const float* w1 = sd.get(b + ".ff.net.0.proj.weight", (size_t)8 * C * C);
     const float* b1 = sd.get(b + ".ff.net.0.proj.bias", 8 * C);
     const float* w2 = sd.get(b + ".ff.net.2.weight", (size_t)C * 4 * C);
     const float* b2 = sd.get(b + ".ff.net.2.bias", C);
     if (!w1 || !b1 || !w2 || !b2) { g.err = sd.err; return -1; }
+    // the projection as the device runs it: LayerNorm folded in (fold), rows permuted for the GEGLU epilogue (bit 0)
+    std::vector<float> wff, scf, sff;
+    const float *wp1 = w1, *bp1 = b1, *sp1 = nullptr;
+    if (fold) { ln_fold(w1, b1, 8 * C, l3, &wff, &scf, &sff); wp1 = wff.data(); bp1 = sff.data(); sp1 = scf.data(); }
+    const MtTensor& ffin = fold ? h2 : n3;
     if (knob(K_MT_FUSE) & 1) {
         // GEGLU in the projection's epilogue: rows permuted so that every 32-row tile is [16 value rows | their 16 gate rows]
         // (value = rows [0, 4C), gate = rows [4C, 8C) of ff.net.0.proj: diffusers GEGLU chunks the projection in that order)
         const int F = 4 * C;
-        std::vector<float> wp((size_t)8 * C * C), bp((size_t)8 * C);
-        for (int t = 0; t < F / 16; ++t)
+        std::vector<float> wp((size_t)8 * C * C), bp((size_t)8 * C), sp((size_t)8 * C, 1.f);
+        for (int tl = 0; tl < F / 16; ++tl)
             for (int r = 0; r < 32; ++r) {
-                const int src = (r < 16) ? t * 16 + r : F + t * 16 + (r - 16);
-                memcpy(&wp[(size_t)(t * 32 + r) * C], &w1[(size_t)src * C], (size_t)C * sizeof(float));
-                bp[t * 32 + r] = b1[src];
+                const int src = (r < 16) ? tl * 16 + r : F + tl * 16 + (r - 16);
+                memcpy(&wp[(size_t)(tl * 32 + r) * C], &wp1[(size_t)src * C], (size_t)C * sizeof(float));
+                bp[tl * 32 + r] = bp1[src];
+                if (sp1) sp[tl * 32 + r] = sp1[src];
             }
-        if (g.add_conv(b + ".ff.net.0.proj", wp.data(), bp.data(), C, 8 * C, 1, 1, 0, n3, gg, nullptr, 4, 0)) return -1;
+        if (g.add_conv(b + ".ff.net.0.proj", wp.data(), bp.data(), C, 8 * C, 1, 1, 0, ffin, gg, nullptr, 4, 0, sp1 ? sp.data() : nullptr)) return -1;
         g.named.erase(b + ".ff.net.0.proj");          // the projection itself is never materialised
         g.named[b + ".ff.geglu"] = gg;
     } else {
-        if (g.add_conv(b + ".ff.net.0.proj", w1, b1, C, 8 * C, 1, 1, 0, n3, f1, nullptr, 0, 0)) return -1;
-        g.add_geglu(b + ".ff.geglu", f1, gg);
+        if (g.add_conv(b + ".ff.net.0.proj", wp1, bp1, C, 8 * C, 1, 1, 0, ffin, f1, nullptr, 0, 0, sp1)) return -1;
     }
+    if (fold) { MtOp& op = g.ops[g.ops.size() - 1]; op.ln_in_buf = l3.stats_buf; op.ln_in_tiles = C / 32; op.ln_eps = l3.eps; }
+    if (!(knob(K_MT_FUSE) & 1)) g.add_geglu(b + ".ff.geglu", f1, gg);
     if (g.add_conv(b + ".ff.net.2", w2, b2, 4 * C, C, 1, 1, 0, gg, h3, &h2, 0, 0)) return -1;
     const float* wo = sd.get(p + ".proj_out.weight", (size_t)C * C);
     const float* bo = sd.get(p + ".proj_out.bias", C);
@@ -877,6 +967,8 @@ static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, si
             io.res = op.r.buf >= 0 ? g.bufs[op.r.buf] : nullptr; io.res_ld = op.r.ld; io.res_coff = op.r.coff;
             io.relu = 0; io.act = op.act; io.ups = op.ups;
             io.partial = partial; io.partial_cap = partial_cap;
+            if (op.ln_out_buf >= 0) { io.ln_out = reinterpret_cast<float*>(g.bufs[op.ln_out_buf]); io.ln_out_tiles = op.y.C / 32; }
+            if (op.ln_in_buf >= 0) { io.ln_in = reinterpret_cast<const float*>(g.bufs[op.ln_in_buf]); io.ln_in_tiles = op.ln_in_tiles; io.ln_eps = op.ln_eps; }
             // U-Net resnet convs of a <= 16-frame pass: conv3's items-per-CU rule settles on tiles that re-read weights (8x8, 32x32 levels) or
             // under-fill the chip (16x16 level); measured per level with the tile forced for every 3x3 launch (profiles/r02_mt_tile_force_ab.txt:
             // 8x8 1280..2560 ch 116 -> 89 us at 256-px tiles, 16x16 640 ch 67 -> 49 us at 128-px tiles, 32x32 320 ch 55 -> 44 us at 256-px tiles).
@@ -891,6 +983,7 @@ static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, si
                 rio.y = io.y; rio.y_ld = op.y.ld; rio.y_coff = op.y.coff; rio.Ho = op.y.H; rio.Wo = op.y.W;
                 rio.res = io.res; rio.res_ld = io.res_ld; rio.res_coff = io.res_coff;
                 rio.N = nf; rio.KW = op.ksz; rio.stride = 1; rio.pad = op.ksz / 2; rio.relu = 0;
+                rio.ln_out = io.ln_out; rio.ln_out_tiles = io.ln_out_tiles; rio.ln_in = io.ln_in; rio.ln_in_tiles = io.ln_in_tiles; rio.ln_eps = io.ln_eps;
                 rc = rowconv_launch(g.rplans[op.rplan], rio, s, &e);
             } else {
                 rc = conv_launch(g.plans[op.plan], io, s, &e);

@@ -132,6 +132,11 @@ struct RowConvArgs {
     int nph;
     int Wout, HWout;                      // output map row pitch and plane size used for addressing (= Wo, Ho * Wo when nph == 1)
     struct Phase { const f16* w; const float* scale; const float* shift; int KT, KW, oy_add, ox_add; } ph[4];
+    // LayerNorm fold (1x1 plans; conv3_mfma.hip K3Args has the algebra): ln_out = [rows][ln_out_tiles] float2 partial sums of the stored
+    // output (this block's 32 channels = tile jb), ln_in = the same of the input rows
+    float* ln_out; const float* ln_in;
+    int ln_out_tiles, ln_in_tiles;
+    float ln_eps;
 };
 
 // FT: 16-row tiles per block; UB: k-steps in flight per trip.  Measured (profiles/r03_rowconv_ab.txt): deeper trips (9 / 6 steps), 32-row
@@ -221,6 +226,19 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
     for (; kt + 2 <= k1; kt += 2) trip(kt, std::integral_constant<int, 2>{});
     for (; kt < k1; ++kt) trip(kt, std::integral_constant<int, 1>{});
 
+    // LayerNorm fold: the finishing lane's row statistics (consumer) / running sums of what it stores (producer); row index = token index
+    float lmean = 0.f, lrstd = 1.f, lsum = 0.f, lsq = 0.f;
+    if (a.ln_in && wave < FT) {
+        const int r = (rg * FT + wave) * 16 + i16;
+        const float2* pp = reinterpret_cast<const float2*>(a.ln_in) + (size_t)(r < a.M ? r : 0) * a.ln_in_tiles;
+        float su = 0.f, sq = 0.f;
+        for (int t = g; t < a.ln_in_tiles; t += 4) { const float2 v = pp[t]; su += v.x; sq += v.y; }
+        su += __shfl_xor(su, 16); sq += __shfl_xor(sq, 16);
+        su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+        const float invC = 1.f / (float)(a.ln_in_tiles * 32);
+        lmean = su * invC;
+        lrstd = rsqrtf(fmaxf(sq * invC - lmean * lmean, 0.f) + a.ln_eps);
+    }
     // ---- the 8 partial tiles meet in LDS, one 16-channel slab at a time; wave ft finishes row tile ft in wave order (deterministic)
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
@@ -246,8 +264,13 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
                 const int j0 = cb * 16 + 4 * g;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + j0), sf = *reinterpret_cast<const f32x4*>(shift + j0);
                 float v[4];
+                if (a.ln_in) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = s[q] * sc[q] + sf[q];
+                    for (int q = 0; q < 4; ++q) v[q] = lrstd * (s[q] - lmean * sc[q]) + sf[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = s[q] * sc[q] + sf[q];
+                }
                 if (a.res) {
                     const f16x4 rv = *reinterpret_cast<const f16x4*>(a.res + (((size_t)n * a.res_cbt + a.res_cb0 + cb) * a.HWout + pix) * 16 + 4 * g);
 #pragma unroll
@@ -258,8 +281,18 @@ __global__ __launch_bounds__(512) void rowconv_kernel(const RowConvArgs a) {
                 for (int q = 0; q < 4; ++q)
                     o[q] = (f16)(a.relu ? __builtin_amdgcn_fmed3f(v[q], 0.f, 65504.f) : __builtin_amdgcn_fmed3f(v[q], -65504.f, 65504.f));
                 *reinterpret_cast<f16x4*>(a.y + (((size_t)n * a.y_cbt + a.y_cb0 + cb) * a.HWout + pix) * 16 + 4 * g) = o;
+                if (a.ln_out) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float f = (float)o[q]; lsum += f; lsq += f * f; }
+                }
             }
         }
+    }
+    if (a.ln_out && wave < FT) {          // this block's 32 channels of the row: the four channel-group lanes of a row meet, lane group 0 writes
+        lsum += __shfl_xor(lsum, 16); lsq += __shfl_xor(lsq, 16);
+        lsum += __shfl_xor(lsum, 32); lsq += __shfl_xor(lsq, 32);
+        const int r = (rg * FT + wave) * 16 + i16;
+        if (g == 0 && r < a.M) reinterpret_cast<float2*>(a.ln_out)[(size_t)r * a.ln_out_tiles + jb] = make_float2(lsum, lsq);
     }
 }
 
@@ -327,6 +360,10 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.Ho; a.Wo = io.Wo; a.S = io.stride; a.Sx = io.stride_w > 0 ? io.stride_w : io.stride; a.pad = io.pad; a.KW = io.KW;
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = p.K / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 1; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo; a.JB = p.J / 32;
+    a.ln_out = io.ln_out; a.ln_in = io.ln_in; a.ln_out_tiles = io.ln_out_tiles; a.ln_in_tiles = io.ln_in_tiles; a.ln_eps = io.ln_eps;
+    if ((io.ln_out || io.ln_in) && (taps != 1 || io.stride != 1 || (io.ln_out && io.ln_out_tiles != p.J / 32))) {
+        if (err) *err = "rowconv: the LayerNorm fold is a 1x1-layer feature"; return -1;
+    }
     const int tiles = (int)((M + 15) / 16);
     const int FT = tiles * (p.J / 32) <= 512 ? 2 : 4;          // ~2 blocks per CU's worth of row groups before the tiles grow
     a.NR = (tiles + FT - 1) / FT;
@@ -358,6 +395,7 @@ int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t strea
     a.N = io.N; a.H = io.H; a.W = io.W; a.Ho = io.H; a.Wo = io.W; a.S = 1; a.Sx = 1; a.pad = 0; a.KW = 1;      // the ROW map is the source map
     a.cpt = C / 32; a.cmagic = (unsigned)((0x100000000ull + (unsigned)a.cpt - 1) / (unsigned)a.cpt); a.KT = C / 32; a.M = (int)M; a.relu = io.relu;
     a.nph = 4; a.Wout = io.Wo; a.HWout = io.Ho * io.Wo; a.JB = J / 32;
+    a.ln_out = nullptr; a.ln_in = nullptr; a.ln_out_tiles = 0; a.ln_in_tiles = 0; a.ln_eps = 0.f;
     for (int g = 0; g < 4; ++g) {
         const int py = g >> 1, px = g & 1;
         if (!p[g].d_w || p[g].J != J || p[g].K != (1 + py) * (1 + px) * C) { if (err) *err = "rowconvT: phase plan mismatch"; return -1; }

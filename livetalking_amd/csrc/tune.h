@@ -65,6 +65,7 @@ enum Knob {
     K_MT_FUSE,            // LTK_MT_FUSE        MuseTalk program, read when the program is BUILT (weights are packed for it): bit 0 = GEGLU in the epilogue of
                           //                    ff.net.0.proj (no 8C-wide intermediate, no geglu launch); bit 1 = the k | v projections of the 16 cross-attentions
                           //                    (they read the audio context only) as ONE stacked projection + ONE value-transpose launch at the head of the pass;
+                          //                    bit 2 = the transformer blocks' LayerNorms folded into the linear layers around them (needs bit 1);
                           //                    0 = the launch list of rounds 2-5
     K_MT_GN1,             // LTK_MT_GN1         1 (default): GroupNorm of the maps whose (image, group) fits one block's registers (U-Net levels, the VAE's 32^2
                           //                    maps) as ONE launch (nn_kernels.hip gn_group_kernel) instead of gn_stats + gn_apply

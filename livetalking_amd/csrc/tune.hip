@@ -38,7 +38,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_FACE_CACHE", 0},
     {"LTK_PREFETCH", 1},
     {"LTK_AUDIO_ROWCONV", 54},
-    {"LTK_MT_FUSE", 3},
+    {"LTK_MT_FUSE", 7},
     {"LTK_MT_GN1", 1},
     {"LTK_ATTN_PF", 1},
     {"LTK_SAT_CHECK", 0},

@@ -37,10 +37,10 @@ def rel_l2(a, b):
 
 
 # Intermediates the default program no longer writes to memory (knob MT_FUSE, csrc/tune.h): the GEGLU projection lives in the
-# accumulators of its own epilogue (bit 0).  `test_unfused_program_every_tap_vs_oracle` builds the program with the fusions off
-# and checks these taps too.
-FUSED_AWAY = (".ff.net.0.proj",)
-MT_FUSE_DEFAULT = 3          # csrc/tune.hip
+# accumulators of its own epilogue (bit 0), the LayerNorm outputs in the epilogues of the projections that consume them (bit 2).
+# `test_unfused_program_every_tap_vs_oracle` builds the program with the fusions off and checks these taps too.
+FUSED_AWAY = (".ff.net.0.proj", "transformer_blocks.0.norm1", "transformer_blocks.0.norm2", "transformer_blocks.0.norm3")
+MT_FUSE_DEFAULT = 7          # csrc/tune.hip
 
 
 def _check_unet_taps(eng, usd, fused):
@@ -70,7 +70,7 @@ def _check_unet_taps(eng, usd, fused):
         if not (r <= 1e-2):
             report.append(f"{name}: rel L2 {r:.3e}")
     r = rel_l2(got_lat, ref_lat.numpy())
-    print(f"[mt] {'fused' if fused else 'unfused'} program: {seen} taps, U-Net output rel_l2={r:.3e}")
+    print(f"[mt] {'fused' if fused else 'unfused'} program: {seen} taps, {len(eng.musetalk_ops())} ops, U-Net output rel_l2={r:.3e}")
     assert r <= 1e-2 and not report, "\n".join(report)
     return got_lat
 
