@@ -615,7 +615,11 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     if (p->v3) {
         // 1x1: 64-channel chunks; wide outputs take 32-channel chunks so that a 128-cout block (conv3_launch) still fits two
         // resident blocks per CU
-        if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && knob(K_GEMM_NC8) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
+        // (knob GEMM_NC8 = 48: 32-channel chunks only on maps of >= 1024 pixels / tokens per image, where the 128-cout blocks are used;
+        // the smaller maps' launches settle on 32- / 64-cout blocks, whose 32-channel chunks carry 4-8 MFMAs per wave behind a DMA round trip)
+        const bool wide = Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 &&
+                          (knob(K_GEMM_NC8) == 4 || (knob(K_GEMM_NC8) == 48 && (hint_hw >= 1024 || hint_hw == 0)));
+        if (p->v3_T == 1) NC8 = wide ? 4 : (Cin % 64 == 0) ? 8 : 2;
         else if (p->ups4) NC8 = 2;          // 16 weight matrices per chunk: 16-channel chunks keep two blocks per CU
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
         else {

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth_inputs as synth  # noqa: E402
 from livetalking_amd.engine import Engine  # noqa: E402
 
-BUILD_KNOBS = ("MT_FUSE", "MT_ROWCONV")
+BUILD_KNOBS = ("MT_FUSE", "MT_ROWCONV", "GEMM_NC8")
 DEFAULTS = {"MT_GN1": 1, "GRAPH": 1, "MT_TILE_TABLE": 1}
 
 
