@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 namespace ltk {
@@ -615,11 +616,7 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
     if (p->v3) {
         // 1x1: 64-channel chunks; wide outputs take 32-channel chunks so that a 128-cout block (conv3_launch) still fits two
         // resident blocks per CU
-        // (knob GEMM_NC8 = 48: 32-channel chunks only on maps of >= 1024 pixels / tokens per image, where the 128-cout blocks are used;
-        // the smaller maps' launches settle on 32- / 64-cout blocks, whose 32-channel chunks carry 4-8 MFMAs per wave behind a DMA round trip)
-        const bool wide = Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 &&
-                          (knob(K_GEMM_NC8) == 4 || (knob(K_GEMM_NC8) == 48 && (hint_hw >= 1024 || hint_hw == 0)));
-        if (p->v3_T == 1) NC8 = wide ? 4 : (Cin % 64 == 0) ? 8 : 2;
+        if (p->v3_T == 1) NC8 = (Cin % 32 == 0 && lCout >= 128 && lCout % 128 == 0 && knob(K_GEMM_NC8) == 4) ? 4 : (Cin % 64 == 0) ? 8 : 2;
         else if (p->ups4) NC8 = 2;          // 16 weight matrices per chunk: 16-channel chunks keep two blocks per CU
         else if (p->v3_G == 4) NC8 = (Cin % 32 == 0) ? 4 : 2;
         else {
@@ -689,7 +686,10 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
         for (int t = 0; t < m.T; ++t) { m.dy[t] = (signed char)phases[pi][t].dy; m.dx[t] = (signed char)phases[pi][t].dx; }
         p->phase[pi].T = m.T; p->phase[pi].ooy = m.ooy; p->phase[pi].oox = m.oox; p->phase[pi].w_off16 = m.w_off16;
         f16* base = packed.data() + pi * phase_halfs;
-        for (int nt = 0; nt < n_sub; ++nt)
+        // the 32-cout sub-slabs are written to disjoint ranges: packed by a few host threads when the layer is large (a MuseTalk load
+        // packs 0.9 G weights: 16 s on one thread)
+        auto pack_range = [&](int nt0, int nt1) {
+        for (int nt = nt0; nt < nt1; ++nt)
             for (int c = 0; c < nchunks; ++c)
                 for (int t = 0; t < m.T; ++t)
                     for (int pl = 0; pl < NC8; ++pl) {
@@ -709,6 +709,15 @@ int conv_plan_create(ConvPlan* p, const float* weight, int CinArg, int Cout, int
                             for (int j = 0; j < 8; ++j) { const uint16_t u = wbits(co, c8 * 8 + j, ky, kx); memcpy(&dst[j], &u, 2); }
                         }
                     }
+        };
+        const size_t work = (size_t)n_sub * nchunks * m.T * NC8 * 256;
+        const int nthr = work < (size_t)4 << 20 ? 1 : std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n_sub}));
+        if (nthr <= 1) pack_range(0, n_sub);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nthr; ++k) th.emplace_back(pack_range, (int)((long long)n_sub * k / nthr), (int)((long long)n_sub * (k + 1) / nthr));
+            for (std::thread& t : th) t.join();
+        }
     }
 
     // folded BN parameters (padded to CoutPad; replicated per position for the 1x1-expand case)
