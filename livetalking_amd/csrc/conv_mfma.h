@@ -191,11 +191,6 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
 // W_eff[j][(dy * (1 + px) + dx) * C + c] = w[c][j][py + 1 - 2 dy][px + 1 - 2 dx], one launch; io.H x io.W source, io.Ho x io.Wo = 2H x 2W output
 int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t stream, std::string* err);
 
-// fused_tail.hip: face_decoder_blocks.7.2 -> output_block.0 -> 1x1 head + sigmoid in one launch (7.2's output stays in LDS); the plans
-// are the two layers' own conv3 plans (16-channel chunks), `x` 7.2's input, `skip` the 16 skip channels inside the concat buffer
-int fused_tail_launch(const ConvPlan& p72, const ConvPlan& pout, const f16* x, int x_ld, int x_coff, const f16* skip, int sk_ld, int sk_coff,
-                      const float* head_w, const void* head_outs, int N, int H, int W, hipStream_t stream, std::string* err);
-
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;
 struct FacePtrs;

@@ -801,22 +801,8 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
             if ((part == 1) == L->face_enc) kept.push_back(L);
         order.swap(kept);
     }
-    // knob FUSE_TAIL: face_decoder_blocks.7.2 + output_block.0 + head as ONE launch (fused_tail.hip) in the product configuration
-    const bool fuse_tail = head_outs && knob(K_FUSE_TAIL) && !e->capture && !evs && !knob(K_SAT_CHECK) && e->layers.size() >= 2 &&
-                           e->layers[e->layers.size() - 2].name == "face_decoder_blocks.7.2" && e->layers[e->layers.size() - 2].res_folded &&
-                           e->layers[e->layers.size() - 2].plan.v3 && e->layers.back().plan.v3;
     // one layer on frames [f0, f0 + n) of the arena
     auto launch_layer = [&](Layer& L, int f0, int n, bool on_aux) -> int {
-        if (fuse_tail && &L == &e->layers.back()) return 0;                 // ran inside the fused tail
-        if (fuse_tail && &L == &e->layers[e->layers.size() - 2]) {
-            const Layer& O = e->layers.back();
-            std::string ferr;
-            const int frc = fused_tail_launch(L.plan, O.plan, B(L.in_buf) + (size_t)f0 * L.in_ld * L.H * L.W, L.in_ld, L.in_coff,
-                                              B(O.in_buf) + (size_t)f0 * O.in_ld * O.H * O.W, O.in_ld, 64, e->d_head,
-                                              reinterpret_cast<const uint8_t* const*>(head_outs) + f0, n, L.H, L.W, s, &ferr);
-            if (frc) return fail(frc == -2 ? LTK_E_HIP : LTK_E_INVALID, "fused tail: " + ferr);
-            return 0;
-        }
         const int bucket = frame_bucket(n);
         ConvIO io;
         io.x = B(L.in_buf) + (size_t)f0 * L.in_ld * L.H * L.W; io.N = n; io.H = L.H; io.W = L.W; io.x_ld = L.in_ld; io.x_coff = L.in_coff;

@@ -76,7 +76,6 @@ enum Knob {
                           //                    The fused Wav2Lip head (which writes bytes) runs unfused under it.
     K_CONV_S2SPLIT,       // LTK_CONV_S2SPLIT   1 (default): the first-generation kernel's stride-2 3x3 layers (face_encoder_blocks.1.0 / 2.0) stage their patch rows
                           //                    split by column parity, so that a ds_read_b128 lane group reads 256 contiguous bytes (conv_mfma.hip KArgs::s2half)
-    K_FUSE_TAIL,          // LTK_FUSE_TAIL      1: face_decoder_blocks.7.2 + output_block.0 + head in one launch, 7.2's output kept in LDS (fused_tail.hip)
     K_COUNT
 };
 

@@ -43,7 +43,6 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_ATTN_PF", 1},
     {"LTK_SAT_CHECK", 0},
     {"LTK_CONV_S2SPLIT", 1},
-    {"LTK_FUSE_TAIL", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

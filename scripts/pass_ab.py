@@ -48,7 +48,7 @@ def main():
     eng.close()
 
 
-DEFAULTS = {"AUDIO_ROWCONV": 54, "PREFETCH": 1, "FACE_CACHE": 0, "DF_FRAMES": 0, "DF_MIN": 32, "DF_BLOCK": 6, "ROWCONV": 1024, "GRAPH": 1, "ROWGEMM": 1, "ROWCONVT": 512, "LDS_SWZ": 1, "CONV_S2SPLIT": 1, "FUSE_TAIL": 1}
+DEFAULTS = {"AUDIO_ROWCONV": 54, "PREFETCH": 1, "FACE_CACHE": 0, "DF_FRAMES": 0, "DF_MIN": 32, "DF_BLOCK": 6, "ROWCONV": 1024, "GRAPH": 1, "ROWGEMM": 1, "ROWCONVT": 512, "LDS_SWZ": 1, "CONV_S2SPLIT": 1}
 
 if __name__ == "__main__":
     main()
