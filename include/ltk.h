@@ -293,7 +293,9 @@ int ltk_wav2lip_graph_count(ltk_engine* e);
  * 4.15 MB of fp16 per bank frame, resident in HBM - and a pass copies them into the decoder's concat buffers instead of running
  * conv7 + 20 encoder layers.  Frames are byte-identical to the mode off for 16-frame calls (the cache is built by 16-frame
  * launches), within 1 LSB for other call sizes, byte-identical for every size under LTK_SPLITK=0.  bench.py never times this
- * mode on its headline line (cached outputs are skipped work there); it reports it on its own also[] entry.
+ * mode on its headline line (cached outputs are skipped work there); it reports it on its own also[] entry.  One avatar's cache
+ * is limited to LTK_FACE_CACHE_MAX_MB (default 16384; a call for a longer avatar fails with LTK_E_NOMEM, nothing allocated); the
+ * first call of an avatar after the mode was switched off frees its records.  The getter may be polled from any thread.
  * Returns the bytes of skip cache the avatar currently holds (0 = none built). */
 int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes);
 

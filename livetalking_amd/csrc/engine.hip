@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -225,9 +226,12 @@ struct Avatar {
     int device = 0;
     // knob FACE_CACHE: the face encoder's skip tensors of every bank frame (records of feat_rec_bytes, misc_kernels.h FeatGeom),
     // built on first use under the engine's enqueue lock; feat_epoch = knob_epoch() it was built under
+    // (d_feat / feat_rec_bytes / feat_epoch are touched under the engine's enqueue lock only; feat_bytes is what the statistics
+    // getter reads from other threads)
     uint8_t* d_feat = nullptr;
     size_t feat_rec_bytes = 0;
     unsigned feat_epoch = 0;
+    std::atomic<size_t> feat_bytes{0};
     Avatar() = default;
     Avatar(const Avatar&) = delete;
     Avatar& operator=(const Avatar&) = delete;
@@ -1320,8 +1324,15 @@ static int build_face_cache(ltk_engine* e, Avatar& a) {
     const FeatGeom g = feat_geom(e);
     const size_t rec = (size_t)g.off[8] * 16;
     if (!a.d_feat) {
+        // 4.15 MB per bank frame: a long avatar is gigabytes; the budget (knob FACE_CACHE_MAX_MB, per avatar) refuses instead of
+        // taking the HBM from under the arenas of later loads
+        const size_t budget = (size_t)std::max(0, knob(K_FACE_CACHE_MAX_MB)) << 20;
+        if (rec * a.n > budget)
+            return fail(LTK_E_NOMEM, "face cache of this avatar needs " + std::to_string((rec * a.n) >> 20) + " MB, over LTK_FACE_CACHE_MAX_MB = " +
+                                         std::to_string(knob(K_FACE_CACHE_MAX_MB)));
         if (hipMalloc((void**)&a.d_feat, rec * a.n) != hipSuccess) { (void)hipGetLastError(); return fail(LTK_E_NOMEM, "face-cache allocation failed"); }
         a.feat_rec_bytes = rec;
+        a.feat_bytes.store(rec * a.n, std::memory_order_release);
     }
     const int chunk = std::min(std::min(16, a.n), std::min(e->micro_batch, kPackMaxFrames));
     const bool pack_fused = e->c7 && knob(K_CONV7);
@@ -1347,7 +1358,7 @@ int ltk_avatar_face_cache_bytes(ltk_engine* e, int avatar_id, size_t* bytes) {
     std::lock_guard<std::mutex> g(e->pool_mu);
     auto it = e->avatars.find(avatar_id);
     if (it == e->avatars.end()) return fail(LTK_E_STATE, "unknown avatar id");
-    *bytes = it->second->d_feat ? it->second->feat_rec_bytes * (size_t)it->second->n : 0;
+    *bytes = it->second->feat_bytes.load(std::memory_order_acquire);
     return LTK_OK;
 }
 
@@ -1408,6 +1419,15 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
                 if (!rc && (!ap->d_feat || ap->feat_epoch != knob_epoch())) rc = build_face_cache(e, *ap);
             if (!rc)
                 for (int i = 0; i < total; ++i) fptr[i] = hold[fidx[2 * i]]->d_feat + (size_t)fidx[2 * i + 1] * hold[fidx[2 * i]]->feat_rec_bytes;
+        } else if (!want_cache) {
+            // the mode was switched off: give the records back (earlier cached calls may still read them on the compute stream)
+            for (auto& ap : hold)
+                if (ap->d_feat) {
+                    CHK(hipStreamSynchronize(e->compute));
+                    (void)hipFree(ap->d_feat);
+                    ap->d_feat = nullptr;
+                    ap->feat_bytes.store(0, std::memory_order_release);
+                }
         }
         // knob PREFETCH: a single-request call of <= 32 frames finds the face-encoder outputs of its frames in the slot a previous call of
         // its session prefetched them into (key: avatar, first bank index, frame count), and - when it continues a session's sequence

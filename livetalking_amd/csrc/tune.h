@@ -76,6 +76,8 @@ enum Knob {
                           //                    The fused Wav2Lip head (which writes bytes) runs unfused under it.
     K_CONV_S2SPLIT,       // LTK_CONV_S2SPLIT   1 (default): the first-generation kernel's stride-2 3x3 layers (face_encoder_blocks.1.0 / 2.0) stage their patch rows
                           //                    split by column parity, so that a ds_read_b128 lane group reads 256 contiguous bytes (conv_mfma.hip KArgs::s2half)
+    K_FACE_CACHE_MAX_MB,  // LTK_FACE_CACHE_MAX_MB  largest face cache ONE avatar may take under knob FACE_CACHE (default 16384 MB = a 3 900-frame bank); a
+                          //                    call for a longer avatar fails with LTK_E_NOMEM instead of allocating
     K_COUNT
 };
 

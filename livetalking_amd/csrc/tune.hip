@@ -43,6 +43,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_ATTN_PF", 1},
     {"LTK_SAT_CHECK", 0},
     {"LTK_CONV_S2SPLIT", 1},
+    {"LTK_FACE_CACHE_MAX_MB", 16384},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -543,11 +543,19 @@ def test_face_cache_mode_equals_mode_off(golden_dir):
             Engine.set_knob("SPLITK", 0)
             Engine.set_knob("FACE_CACHE", 0)
             off64_s = run64()
+            assert eng.face_cache_bytes(aid) == 0, "a call with the mode switched off gives the avatar's records back"
             Engine.set_knob("FACE_CACHE", 1)
+            Engine.set_knob("FACE_CACHE_MAX_MB", 8)          # 20 frames need 79 MB: refused, loudly, nothing allocated
+            with pytest.raises(RuntimeError, match="LTK_FACE_CACHE_MAX_MB"):
+                run64()
+            assert eng.face_cache_bytes(aid) == 0
+            Engine.set_knob("FACE_CACHE_MAX_MB", 16384)
             on64_s = run64()
+            assert eng.face_cache_bytes(aid) == 20 * per_frame
             assert np.array_equal(on64_s, off64_s), "LTK_SPLITK=0: the cache must be exact at every call size"
         finally:
             Engine.set_knob("FACE_CACHE", 0)
+            Engine.set_knob("FACE_CACHE_MAX_MB", 16384)
             Engine.set_knob("SPLITK", 1)
     finally:
         eng.close()
