@@ -857,6 +857,233 @@ __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restri
     *reinterpret_cast<f16x8*>(y + (((size_t)n * y_cbt + y_cb0 + cb) * HWo + opx) * 16 + half * 8) = o;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// lin_fk_kernel: the short-K linear / 1x1 layers of MuseTalk's transformer blocks (K = 320 / 640 on the 32^2 / 16^2 levels; round 6).
+// As conv3 1x1 launches these layers are latency chains: a 256-pixel x 64-cout item walks its 5-10 channel chunks one LDS-DMA
+// round trip at a time (16 MFMAs per wave behind each), pays a zero fill, a first round trip and an epilogue per item, and a
+// 3.4-GFLOP projection takes 22-28 us whatever the level.  Here the roles are turned round for a K that fits the register file:
+//   * a wave keeps the WHOLE K of its 32 pixels in registers as MFMA B-operand fragments (KB x 16 B per lane, straight from
+//     global memory: one contiguous KiB per channel block and wave, no LDS image, no zero fill);
+//   * the block streams the weights through LDS in FULL-K slabs of 32 output channels (KB KiB, contiguous in the packed
+//     weights: [cout/32][K/8][32][8]), two stages, one barrier per slab; the four waves read the same slab (one ds_read_b128
+//     per MFMA);
+//   * every slab ends in the epilogue of its 32 x 128 outputs (conv3's 1x1 epilogue: bias / folded LayerNorm consumer and
+//     producer sides / residual / activation / GEGLU), whose global loads and stores overlap the next slab's DMA.
+// A block = 128 consecutive pixels (tokens) x a group of `cpg` slabs; blocks of one pixel tile are adjacent (its A rows come from L2).
+// Summation order per output = conv3's unsplit order (channel blocks ascending): the two kernels agree bit for bit.
+template <int KB, int PXW>
+__global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const int cpg, const int ngroups, const int nslabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int grp = blockIdx.x % ngroups, mt = blockIdx.x / ngroups;
+    const int s_begin = grp * cpg, s_end = min(nslabs, s_begin + cpg);
+    const int P = a.HoA * a.WoA;
+    constexpr int SLAB = KB * 1024;                      // bytes of one 32-cout slab
+    constexpr int KPB = 20, KP = KB / KPB;               // a slab goes through LDS in KP parts of 20 channel blocks (20 KiB): K = 640 with 80-KiB
+    constexpr int PART = KPB * 1024;                     // stage pairs left ONE block per CU (and nothing for the scale / shift image)
+    constexpr int SS_OFF = 2 * PART;                     // [2][scale 32 | shift 32] fp32 behind the two weight stages
+    static_assert(KB % KPB == 0, "K = 320 / 640");
+    bool ok[PXW];
+    int n[PXW], pix[PXW];
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) {
+        const long long m = (long long)mt * (128 * PXW) + (wave * PXW + j) * 32 + l31;
+        ok[j] = m < a.Mtot;
+        const int mm = (int)(ok[j] ? m : a.Mtot - 1);
+        n[j] = mm / P; pix[j] = mm - n[j] * P;
+    }
+
+    // ---- weights: slab s -> stage buf (KB pieces of 1 KiB, piece k*4 + wave by this wave), its scale / shift behind them
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(a.w);
+    auto stage = [&](int s, int h, int buf) {
+        const unsigned char* src = wbase + (size_t)s * SLAB + h * PART + lane * 16;
+        unsigned char* dst = smem + buf * PART;
+#pragma unroll
+        for (int k = 0; k < KPB / 4; ++k) GLDS16(src + (k * 4 + wave) * 1024, dst + (k * 4 + wave) * 1024);
+        if (h == 0 && wave == 0 && lane < 16)
+            GLDS16((lane < 8 ? a.scale : a.shift - 32) + s * 32 + lane * 4, smem + SS_OFF + ((s - s_begin) & 1) * 256);
+    };
+    stage(s_begin, 0, 0);
+    int parts_done = 0;
+
+    // ---- this lane's pixels: 8 channels (half hh) of every channel block
+    f16x8 af[PXW][KB];
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) {
+        const f16* xb = a.x + ((size_t)(n[j] * a.x_cbt + a.x_cb0) * P + pix[j]) * 16 + hh * 8;
+#pragma unroll
+        for (int q = 0; q < KB; ++q) af[j][q] = *reinterpret_cast<const f16x8*>(xb + (size_t)q * P * 16);
+    }
+
+    // LayerNorm fold, consumer side: mean / rstd of this lane's tokens (once per block)
+    int tok[PXW];
+    float lmean[PXW], lrstd[PXW];
+    const bool ln_cons = a.ln_in != nullptr, ln_prod = a.ln_out != nullptr;
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) {
+        tok[j] = n[j] * P + pix[j];
+        lmean[j] = 0.f; lrstd[j] = 1.f;
+        if (ln_cons) {
+            const float2* pp = reinterpret_cast<const float2*>(a.ln_in) + (size_t)tok[j] * a.ln_in_tiles;
+            float su = 0.f, sq = 0.f;
+            for (int t = hh; t < a.ln_in_tiles; t += 2) { const float2 v = pp[t]; su += v.x; sq += v.y; }
+            su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+            const float invC = 1.f / (float)(a.ln_in_tiles * 32);
+            lmean[j] = su * invC;
+            lrstd[j] = rsqrtf(fmaxf(sq * invC - lmean[j] * lmean[j], 0.f) + a.ln_eps);
+        }
+    }
+    const bool has_res = a.res != nullptr;
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cout0 = s * 32;
+        const int ncb_valid = min(2, (a.Cout - cout0) >> 4);
+        // residual values of this slab's outputs: requested in front of the MFMAs, used behind them
+        // (32 pixels per wave only: the 64-pixel variant has no registers to spare and serves the wide projections, which have no residual)
+        constexpr bool RES_AHEAD = PXW == 1;
+        f16x4 rr[PXW][2][2];
+        if (RES_AHEAD && has_res) {
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int eo = 0; eo < 2; ++eo)
+                        if (pr < ncb_valid)
+                            rr[j][pr][eo] = *reinterpret_cast<const f16x4*>(a.res + ((size_t)(n[j] * a.res_cbt + a.res_cb0 + (cout0 >> 4) + pr) * P + pix[j]) * 16 + hh * 4 + eo * 8);
+        }
+        f32x16 acc[PXW];
+#pragma unroll
+        for (int j = 0; j < PXW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int h = 0; h < KP; ++h) {
+            const int cur = parts_done & 1;
+            __syncthreads();               // vmcnt(0): this part landed; every wave left stage cur^1
+            if (h + 1 < KP) stage(s, h + 1, cur ^ 1);
+            else if (s + 1 < s_end) stage(s + 1, 0, cur ^ 1);
+            ++parts_done;
+            const unsigned char* Bs = smem + cur * PART + (hh * 32 + l31) * 16;
+            // weight fragments WD channel blocks ahead of their MFMAs
+            constexpr int WD = PXW == 1 ? 4 : 2;
+            f16x8 wf[WD];
+#pragma unroll
+            for (int q = 0; q < WD; ++q) wf[q] = *reinterpret_cast<const f16x8*>(Bs + q * 1024);
+#pragma unroll
+            for (int q = 0; q < KPB; ++q) {
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[q % WD], af[j][h * KPB + q], acc[j], 0, 0, 0);
+                if (q + WD < KPB) wf[q % WD] = *reinterpret_cast<const f16x8*>(Bs + (q + WD) * 1024);
+            }
+        }
+
+        // ---- epilogue of the 32 output channels of slab s (conv3_item's 1x1 epilogue with NBT = 1)
+        const float* const ssb = reinterpret_cast<const float*>(smem + SS_OFF + ((s - s_begin) & 1) * 256);      // [scale 32 | shift 32]
+        if (a.relu == 4) {                 // GEGLU: the slab is [16 value | 16 gate] channels -> one 16-channel block of the output
+            if (ncb_valid <= 0) continue;
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int eo = 0; eo < 2; ++eo) {
+                    // (scale / shift re-read from LDS per use: four ds_read_b128 instead of 32 registers held across the pixel subtiles)
+                    const int cl = 8 * eo + 4 * hh;
+                    const f32x4 scv = *reinterpret_cast<const f32x4*>(ssb + cl), sfv = *reinterpret_cast<const f32x4*>(ssb + 32 + cl);
+                    const f32x4 scg = *reinterpret_cast<const f32x4*>(ssb + cl + 16), sfg = *reinterpret_cast<const f32x4*>(ssb + 32 + cl + 16);
+                    f16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v, gt;
+                        if (ln_cons) {
+                            v = lrstd[j] * (acc[j][4 * eo + r] - lmean[j] * scv[r]) + sfv[r];
+                            gt = lrstd[j] * (acc[j][4 * (2 + eo) + r] - lmean[j] * scg[r]) + sfg[r];
+                        } else {
+                            v = acc[j][4 * eo + r] * scv[r] + sfv[r];
+                            gt = acc[j][4 * (2 + eo) + r] * scg[r] + sfg[r];
+                        }
+                        const float t = v * gelu_as(gt);
+                        o[r] = (f16)__builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+                    }
+                    const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                    pk[eo][0] = u.x; pk[eo][1] = u.y;
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                if (ok[j]) *reinterpret_cast<uint4*>(a.y + ((size_t)(n[j] * a.y_cbt + a.y_cb0 + (cout0 >> 5)) * P + pix[j]) * 16 + hh * 8) = out;
+            }
+            continue;
+        }
+        auto epilogue = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            const int cbo = cout0 >> 4;
+            float ls[PXW], lq[PXW];
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) { ls[j] = 0.f; lq[j] = 0.f; }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                if (pr >= ncb_valid) continue;           // wave-uniform
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int eo = 0; eo < 2; ++eo) {
+                        const int q4 = 2 * pr + eo;
+                        const int cl = 8 * q4 + 4 * hh;
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssb + cl), sf = *reinterpret_cast<const f32x4*>(ssb + 32 + cl);
+                        float v[4];
+                        if (ln_cons) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = lrstd[j] * (acc[j][4 * q4 + r] - lmean[j] * sc[r]) + sf[r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[j][4 * q4 + r] * sc[r] + sf[r];
+                        }
+                        if (has_res) {
+                            if constexpr (!RES_AHEAD)
+                                rr[j][pr][eo] = *reinterpret_cast<const f16x4*>(a.res + ((size_t)(n[j] * a.res_cbt + a.res_cb0 + cbo + pr) * P + pix[j]) * 16 + hh * 4 + eo * 8);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[j][pr][eo][r];
+                        }
+                        f16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = v[r];
+                            if constexpr (ACT == 1) t = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
+                            else t = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+                            o[r] = (f16)t;
+                        }
+                        if (ln_prod) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; ls[j] += f; lq[j] += f * f; }
+                        }
+                        const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                        pk[eo][0] = u.x; pk[eo][1] = u.y;
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (ok[j]) *reinterpret_cast<uint4*>(a.y + ((size_t)(n[j] * a.y_cbt + a.y_cb0 + cbo + pr) * P + pix[j]) * 16 + hh * 8) = out;
+                }
+            }
+            if (ln_prod && ncb_valid > 0) {
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) {
+                    const float su = ls[j] + __shfl_xor(ls[j], 32), sq = lq[j] + __shfl_xor(lq[j], 32);
+                    if (ok[j] && hh == 0) reinterpret_cast<float2*>(a.ln_out)[(size_t)tok[j] * a.ln_out_tiles + s] = make_float2(su, sq);
+                }
+            }
+        };
+        if (a.relu == 1) epilogue(std::integral_constant<int, 1>{});       // (GELU / SiLU epilogues stay on conv3: no linear layer of the path has one)
+        else epilogue(std::integral_constant<int, 0>{});
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1077,6 +1304,27 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
     if (a.relu == 4) {                                                    // GEGLU epilogue: value and gate meet in the accumulators
         if (!(G == 1 && T == 1 && !p.q8 && p.lCout % 32 == 0 && !io.res)) { if (err) *err = "conv3: the GEGLU epilogue is a 1x1-layer feature"; return -1; }
         ksplit = 1;
+    }
+    // short-K linear layers on many tokens: lin_fk_kernel (A rows in registers, full-K weight slabs through LDS)
+    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && (p.Cin == 320 || p.Cin == 640) &&
+        a.nchunks * NC8 * 8 == p.Cin && a.Mtot >= knob(K_LIN_FK_MIN_ROWS) && a.ablate == 0 && p.lCout % 16 == 0 &&
+        (a.relu == 0 || a.relu == 1 || a.relu == 4)) {
+        const int nslabs = (p.lCout + 31) / 32;
+        const long long mtiles = (a.Mtot + 127) / 128;
+        int ngroups = (int)std::max(1ll, std::min((long long)nslabs, (knob(K_LIN_FK_BLOCKS) + mtiles - 1) / mtiles));
+        const int cpg = (nslabs + ngroups - 1) / ngroups;
+        ngroups = (nslabs + cpg - 1) / cpg;
+        const long long grid = mtiles * ngroups;
+        if (grid > 0 && grid <= 0x7fffffffll) {
+            typedef void (*lin_t)(const K3Args, int, int, int);
+            const lin_t lk = p.Cin == 320 ? (lin_t)lin_fk_kernel<20, 1> : (lin_t)lin_fk_kernel<40, 1>;
+            const size_t lbytes = (size_t)2 * 20 * 1024 + 512;
+            HIPCHK3((hipError_t)ensure_dyn_lds((const void*)lk, (int)lbytes));
+            a.ksplit = 1; a.partial = nullptr;
+            hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(256), lbytes, stream, a, cpg, ngroups, nslabs);
+            HIPCHK3(hipGetLastError());
+            return 0;
+        }
     }
     if (ksplit > 1) {   // fall back to fewer splits when the caller's scratch is smaller
         while (ksplit > 1 && (!io.partial || io.partial_cap < (size_t)ksplit * a.Mtot * p.CoutPad * sizeof(float))) ksplit /= 2;

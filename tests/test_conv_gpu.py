@@ -146,3 +146,63 @@ def test_conv_first_generation_kernel(engine):
         from livetalking_amd.engine import Engine
         Engine.set_knob("CONV_V3", 1)
     assert not report, "\n".join(report)
+
+
+# lin_fk_kernel (conv3_mfma.hip): 1x1 / linear layers with K = 320 / 640 on >= 2048 rows (MuseTalk's 32^2 / 16^2 transformer levels):
+# whole and ragged pixel tiles, tiles that straddle images (8x8 maps), partial cout slabs (48 = 1.5 slabs), with / without residual
+CASES_LIN_FK = [
+    (16, 32, 32, 320, 320, 1, 1, 0, False, 0, True),
+    (16, 32, 32, 320, 960, 1, 1, 0, False, 0, False),
+    (16, 16, 16, 640, 640, 1, 1, 0, False, 0, True),
+    (3, 32, 32, 640, 320, 1, 1, 0, False, 0, False),
+    (5, 21, 37, 320, 48, 1, 1, 0, False, 0, False),
+    (40, 8, 8, 640, 640, 1, 1, 0, False, 0, True),
+    (33, 8, 8, 320, 336, 1, 1, 0, False, 0, False),
+]
+
+
+@pytest.mark.gpu
+def test_lin_fk_kernel_vs_torch_and_conv3(engine):
+    """The short-K linear kernel against the fp32 torch reference, and bit for bit against conv3's 1x1 path with the split-K
+    rule off (both sum the channel blocks in ascending order)."""
+    from livetalking_amd.engine import Engine
+
+    def run(case, seed):
+        N, H, W, Cin, Cout, k, stride, pad, transposed, out_pad, residual = case
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        x = torch.randn(N, Cin, H, W, generator=g).half().float()
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).half().float()
+        scale = torch.rand(Cout, generator=g) + 0.5
+        shift = torch.randn(Cout, generator=g) * 0.1
+        x_dev = to_cb16(x.cuda())
+        y = empty_cb16(N, Cout, H, W, fill=float("nan"))
+        engine.conv2d_f16(x_dev.data_ptr(), N, H, W, Cin, w.numpy(), Cout, 1, 1, 0, False, 0, scale.numpy(), shift.numpy(),
+                          x_dev.data_ptr() if residual else 0, True, y.data_ptr())
+        torch.cuda.synchronize()
+        ref = F.conv2d(x.cuda(), w.cuda()) * scale.cuda()[None, :, None, None] + shift.cuda()[None, :, None, None]
+        if residual:
+            ref = ref + x.cuda()
+        return y.clone(), torch.relu(ref)
+
+    report = []
+    try:
+        Engine.set_knob("SPLITK", 0)
+        for i, case in enumerate(CASES_LIN_FK):
+            Engine.set_knob("LIN_FK", 1)
+            y1, ref = run(case, 300 + i)
+            Engine.set_knob("LIN_FK", 0)
+            y0, _ = run(case, 300 + i)
+            Cout = case[4]
+            got = from_cb16(y1, Cout)
+            err = (got - ref).abs()
+            bad = (~(err <= 2e-3 * ref.abs().clamp(min=1.0) + 2e-3)).sum().item()
+            same = torch.equal(from_cb16(y1, Cout), from_cb16(y0, Cout))
+            dd = (from_cb16(y1, Cout) - from_cb16(y0, Cout)).abs()
+            print(f"[lin_fk] case {i} {case}: bad={bad} maxerr={float(torch.nan_to_num(err, nan=1e9).max()):.4g} equal_to_conv3={same} "
+                  f"(differing {int((dd != 0).sum())} of {dd.numel()}, max {float(dd.max()):.3g})")
+            if bad or not same:
+                report.append(f"case {i} {case}: bad={bad} equal_to_conv3={same}")
+    finally:
+        Engine.set_knob("LIN_FK", 1)
+        Engine.set_knob("SPLITK", 1)
+    assert not report, "\n".join(report)
