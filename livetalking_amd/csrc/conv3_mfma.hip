@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restri
 //     producer sides / residual / activation / GEGLU), whose global loads and stores overlap the next slab's DMA.
 // A block = 128 consecutive pixels (tokens) x a group of `cpg` slabs; blocks of one pixel tile are adjacent (its A rows come from L2).
 // Summation order per output = conv3's unsplit order (channel blocks ascending): the two kernels agree bit for bit.
-template <int KB, int PXW>
+template <int KB, int KPB>
 __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const int cpg, const int ngroups, const int nslabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -883,10 +883,11 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
     const int s_begin = grp * cpg, s_end = min(nslabs, s_begin + cpg);
     const int P = a.HoA * a.WoA;
     constexpr int SLAB = KB * 1024;                      // bytes of one 32-cout slab
-    constexpr int KPB = 20, KP = KB / KPB;               // a slab goes through LDS in KP parts of 20 channel blocks (20 KiB): K = 640 with 80-KiB
-    constexpr int PART = KPB * 1024;                     // stage pairs left ONE block per CU (and nothing for the scale / shift image)
+    constexpr int PXW = 1;                               // 32-pixel subtiles per wave (2 was built: 116-164 bytes of scratch per lane, slower)
+    constexpr int KP = KB / KPB;                         // a slab goes through LDS in KP parts of KPB channel blocks (K = 640: two 20-KiB parts;
+    constexpr int PART = KPB * 1024;                     // its 80-KiB stage pairs left ONE block per CU and nothing for the scale / shift image)
     constexpr int SS_OFF = 2 * PART;                     // [2][scale 32 | shift 32] fp32 behind the two weight stages
-    static_assert(KB % KPB == 0, "K = 320 / 640");
+    static_assert(KB % KPB == 0 && KPB % 4 == 0, "whole parts, whole KiB pieces per wave");
     bool ok[PXW];
     int n[PXW], pix[PXW];
 #pragma unroll
@@ -1306,7 +1307,7 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         ksplit = 1;
     }
     // short-K linear layers on many tokens: lin_fk_kernel (A rows in registers, full-K weight slabs through LDS)
-    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && (p.Cin == 320 || p.Cin == 640) &&
+    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && (p.Cin == 320 || p.Cin == 640 || p.Cin == 512 || p.Cin == 384) &&
         a.nchunks * NC8 * 8 == p.Cin && a.Mtot >= knob(K_LIN_FK_MIN_ROWS) && a.ablate == 0 && p.lCout % 16 == 0 &&
         (a.relu == 0 || a.relu == 1 || a.relu == 4)) {
         const int nslabs = (p.lCout + 31) / 32;
@@ -1317,8 +1318,10 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         const long long grid = mtiles * ngroups;
         if (grid > 0 && grid <= 0x7fffffffll) {
             typedef void (*lin_t)(const K3Args, int, int, int);
-            const lin_t lk = p.Cin == 320 ? (lin_t)lin_fk_kernel<20, 1> : (lin_t)lin_fk_kernel<40, 1>;
-            const size_t lbytes = (size_t)2 * 20 * 1024 + 512;
+            // K = 320 / 640: MuseTalk's 32^2 / 16^2 transformer levels; 512: the VAE mid-block attention; 384: the stacked k | v projection of the audio context
+            const lin_t lk = p.Cin == 320 ? (lin_t)lin_fk_kernel<20, 20> : p.Cin == 640 ? (lin_t)lin_fk_kernel<40, 20> : p.Cin == 512 ? (lin_t)lin_fk_kernel<32, 16>
+                                                                                                                          : (lin_t)lin_fk_kernel<24, 24>;
+            const size_t lbytes = (size_t)2 * (p.Cin == 512 ? 16 : p.Cin == 384 ? 24 : 20) * 1024 + 512;
             HIPCHK3((hipError_t)ensure_dyn_lds((const void*)lk, (int)lbytes));
             a.ksplit = 1; a.partial = nullptr;
             hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(256), lbytes, stream, a, cpg, ngroups, nslabs);

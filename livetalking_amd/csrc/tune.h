@@ -78,10 +78,10 @@ enum Knob {
                           //                    split by column parity, so that a ds_read_b128 lane group reads 256 contiguous bytes (conv_mfma.hip KArgs::s2half)
     K_FACE_CACHE_MAX_MB,  // LTK_FACE_CACHE_MAX_MB  largest face cache ONE avatar may take under knob FACE_CACHE (default 16384 MB = a 3 900-frame bank); a
                           //                    call for a longer avatar fails with LTK_E_NOMEM instead of allocating
-    K_LIN_FK,             // LTK_LIN_FK         1 (default): 1x1 / linear layers with K = 320 / 640 input channels on >= LIN_FK_MIN_ROWS pixels or tokens run on
+    K_LIN_FK,             // LTK_LIN_FK         1 (default): 1x1 / linear layers with K = 320 / 384 / 512 / 640 input channels on >= LIN_FK_MIN_ROWS pixels or tokens run on
                           //                    lin_fk_kernel (conv3_mfma.hip: a wave's A rows in registers, full-K 32-cout weight slabs through LDS); 0: conv3 1x1
     K_LIN_FK_BLOCKS,      // LTK_LIN_FK_BLOCKS  blocks a lin_fk launch aims at (the output channels are split into groups of slabs until the grid has this many)
-    K_LIN_FK_MIN_ROWS,    // LTK_LIN_FK_MIN_ROWS
+    K_LIN_FK_MIN_ROWS,    // LTK_LIN_FK_MIN_ROWS  (default 512)
     K_COUNT
 };
 

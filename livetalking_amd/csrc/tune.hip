@@ -46,7 +46,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_FACE_CACHE_MAX_MB", 16384},
     {"LTK_LIN_FK", 1},
     {"LTK_LIN_FK_BLOCKS", 512},
-    {"LTK_LIN_FK_MIN_ROWS", 2048},
+    {"LTK_LIN_FK_MIN_ROWS", 512},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -19,6 +19,9 @@ SHAPES = [  # (N, H, Cin, Cout, residual, name)
     (16, 16, 640, 640, True, "16^2 to_out / to_q / proj"), (16, 16, 640, 1920, False, "16^2 to_qkv"), (16, 16, 640, 5120, False, "16^2 ff.net.0.proj"),
     (64, 32, 320, 320, True, "64 frames 32^2 to_out"), (64, 16, 640, 640, True, "64 frames 16^2 to_out"),
     (4, 32, 320, 320, True, "4 frames 32^2 to_out"), (4, 16, 640, 640, True, "4 frames 16^2 to_out"),
+    (1, 32, 320, 320, True, "1 frame 32^2 to_out"), (1, 32, 320, 2560, False, "1 frame 32^2 ff.net.0.proj"), (2, 16, 640, 640, True, "2 frames 16^2 to_out"),
+    (16, 32, 512, 1536, False, "VAE mid attention to_qkv"), (16, 32, 512, 512, True, "VAE mid attention to_out"),
+    (25, 8, 384, 25600, False, "audio context k | v, 1600 rows"),
 ]
 
 

@@ -148,7 +148,7 @@ def test_conv_first_generation_kernel(engine):
     assert not report, "\n".join(report)
 
 
-# lin_fk_kernel (conv3_mfma.hip): 1x1 / linear layers with K = 320 / 640 on >= 2048 rows (MuseTalk's 32^2 / 16^2 transformer levels):
+# lin_fk_kernel (conv3_mfma.hip): 1x1 / linear layers with K = 320 / 384 / 512 / 640 on >= 512 rows (MuseTalk's 32^2 / 16^2 transformer levels):
 # whole and ragged pixel tiles, tiles that straddle images (8x8 maps), partial cout slabs (48 = 1.5 slabs), with / without residual
 CASES_LIN_FK = [
     (16, 32, 32, 320, 320, 1, 1, 0, False, 0, True),
@@ -158,6 +158,9 @@ CASES_LIN_FK = [
     (5, 21, 37, 320, 48, 1, 1, 0, False, 0, False),
     (40, 8, 8, 640, 640, 1, 1, 0, False, 0, True),
     (33, 8, 8, 320, 336, 1, 1, 0, False, 0, False),
+    (2, 32, 32, 512, 512, 1, 1, 0, False, 0, True),
+    (13, 10, 5, 384, 160, 1, 1, 0, False, 0, False),
+    (1, 32, 32, 320, 320, 1, 1, 0, False, 0, True),
 ]
 
 
