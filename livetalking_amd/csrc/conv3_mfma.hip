@@ -872,22 +872,30 @@ __global__ __launch_bounds__(256) void conv3_finish_kernel(const float* __restri
 //     producer sides / residual / activation / GEGLU), whose global loads and stores overlap the next slab's DMA.
 // A block = 128 consecutive pixels (tokens) x a group of `cpg` slabs; blocks of one pixel tile are adjacent (its A rows come from L2).
 // Summation order per output = conv3's unsplit order (channel blocks ascending): the two kernels agree bit for bit.
-template <int KB, int KPB>
-__global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const int cpg, const int ngroups, const int nslabs) {
+// KS = 2 (K = 1280: the 8^2 level's projections, ff.net.2 of the 32^2 level): 1280 channels are 320 registers per lane, so TWO waves share a
+// pixel subtile - wave w takes the subtile w & 3 and the K half w >> 2 (KB = 40 channel blocks each), a stage holds one 20-KiB part of the
+// slab for either half, the upper half's 16 accumulators meet the lower half's in LDS behind the slab's last part (one more barrier per slab;
+// exchange area double-buffered by slab parity) and the lower-half waves run the epilogue.  acc = (half 0) + (half 1): fixed order,
+// deterministic, not conv3's sequential order (fp32 rounding only).
+template <int KB, int KPB, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void lin_fk_kernel(const K3Args a, const int cpg, const int ngroups, const int nslabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, kh = wave8 >> 2;         // pixel subtile, K half (KS = 1: kh = 0)
     const int l31 = lane & 31, hh = lane >> 5;
     const int grp = blockIdx.x % ngroups, mt = blockIdx.x / ngroups;
     const int s_begin = grp * cpg, s_end = min(nslabs, s_begin + cpg);
     const int P = a.HoA * a.WoA;
-    constexpr int SLAB = KB * 1024;                      // bytes of one 32-cout slab
+    constexpr int SLAB = KB * KS * 1024;                 // bytes of one 32-cout slab
     constexpr int PXW = 1;                               // 32-pixel subtiles per wave (2 was built: 116-164 bytes of scratch per lane, slower)
     constexpr int KP = KB / KPB;                         // a slab goes through LDS in KP parts of KPB channel blocks (K = 640: two 20-KiB parts;
     constexpr int PART = KPB * 1024;                     // its 80-KiB stage pairs left ONE block per CU and nothing for the scale / shift image)
-    constexpr int SS_OFF = 2 * PART;                     // [2][scale 32 | shift 32] fp32 behind the two weight stages
-    static_assert(KB % KPB == 0 && KPB % 4 == 0, "whole parts, whole KiB pieces per wave");
+    constexpr int STAGE = KS * PART;                     // a stage: part h of the slab for every K half
+    constexpr int SS_OFF = 2 * STAGE;                    // [2][scale 32 | shift 32] fp32 behind the two weight stages
+    constexpr int XCH_OFF = SS_OFF + 512;                // KS = 2: [2 slab parities][4 subtiles][4][64 lanes][16 B] accumulators of the upper K half
+    static_assert(KB % KPB == 0 && KPB % 4 == 0 && (KS == 1 || KS == 2), "whole parts, whole KiB pieces per wave");
     bool ok[PXW];
     int n[PXW], pix[PXW];
 #pragma unroll
@@ -901,11 +909,12 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
     // ---- weights: slab s -> stage buf (KB pieces of 1 KiB, piece k*4 + wave by this wave), its scale / shift behind them
     const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(a.w);
     auto stage = [&](int s, int h, int buf) {
-        const unsigned char* src = wbase + (size_t)s * SLAB + h * PART + lane * 16;
-        unsigned char* dst = smem + buf * PART;
+        // (K half kh's part h sits (kh * KP + h) parts into the slab; every wave copies KPB / 4 KiB pieces of its own half's part)
+        const unsigned char* src = wbase + (size_t)s * SLAB + (kh * KP + h) * PART + lane * 16;
+        unsigned char* dst = smem + buf * STAGE + kh * PART;
 #pragma unroll
         for (int k = 0; k < KPB / 4; ++k) GLDS16(src + (k * 4 + wave) * 1024, dst + (k * 4 + wave) * 1024);
-        if (h == 0 && wave == 0 && lane < 16)
+        if (h == 0 && wave8 == 0 && lane < 16)
             GLDS16((lane < 8 ? a.scale : a.shift - 32) + s * 32 + lane * 4, smem + SS_OFF + ((s - s_begin) & 1) * 256);
     };
     stage(s_begin, 0, 0);
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
     f16x8 af[PXW][KB];
 #pragma unroll
     for (int j = 0; j < PXW; ++j) {
-        const f16* xb = a.x + ((size_t)(n[j] * a.x_cbt + a.x_cb0) * P + pix[j]) * 16 + hh * 8;
+        const f16* xb = a.x + ((size_t)(n[j] * a.x_cbt + a.x_cb0 + kh * KB) * P + pix[j]) * 16 + hh * 8;
 #pragma unroll
         for (int q = 0; q < KB; ++q) af[j][q] = *reinterpret_cast<const f16x8*>(xb + (size_t)q * P * 16);
     }
@@ -928,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
     for (int j = 0; j < PXW; ++j) {
         tok[j] = n[j] * P + pix[j];
         lmean[j] = 0.f; lrstd[j] = 1.f;
-        if (ln_cons) {
+        if (ln_cons && kh == 0) {
             const float2* pp = reinterpret_cast<const float2*>(a.ln_in) + (size_t)tok[j] * a.ln_in_tiles;
             float su = 0.f, sq = 0.f;
             for (int t = hh; t < a.ln_in_tiles; t += 2) { const float2 v = pp[t]; su += v.x; sq += v.y; }
@@ -947,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
         // (32 pixels per wave only: the 64-pixel variant has no registers to spare and serves the wide projections, which have no residual)
         constexpr bool RES_AHEAD = PXW == 1;
         f16x4 rr[PXW][2][2];
-        if (RES_AHEAD && has_res) {
+        if (RES_AHEAD && has_res && kh == 0) {
 #pragma unroll
             for (int j = 0; j < PXW; ++j)
 #pragma unroll
@@ -969,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
             if (h + 1 < KP) stage(s, h + 1, cur ^ 1);
             else if (s + 1 < s_end) stage(s + 1, 0, cur ^ 1);
             ++parts_done;
-            const unsigned char* Bs = smem + cur * PART + (hh * 32 + l31) * 16;
+            const unsigned char* Bs = smem + cur * STAGE + kh * PART + (hh * 32 + l31) * 16;
             // weight fragments WD channel blocks ahead of their MFMAs
             constexpr int WD = PXW == 1 ? 4 : 2;
             f16x8 wf[WD];
@@ -983,6 +992,21 @@ __global__ __launch_bounds__(256, 2) void lin_fk_kernel(const K3Args a, const in
             }
         }
 
+        if constexpr (KS == 2) {           // the two K halves of a subtile meet in LDS; the lower half's wave goes on to the epilogue
+            f32x4* const xw = reinterpret_cast<f32x4*>(smem + XCH_OFF + (((s - s_begin) & 1) * 4 + wave) * 4096) + lane;
+            if (kh == 1) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) xw[g4 * 64] = (f32x4){acc[0][4 * g4], acc[0][4 * g4 + 1], acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]};
+            }
+            __syncthreads();
+            if (kh == 1) continue;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 o = xw[g4 * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][4 * g4 + r] += o[r];
+            }
+        }
         // ---- epilogue of the 32 output channels of slab s (conv3_item's 1x1 epilogue with NBT = 1)
         const float* const ssb = reinterpret_cast<const float*>(smem + SS_OFF + ((s - s_begin) & 1) * 256);      // [scale 32 | shift 32]
         if (a.relu == 4) {                 // GEGLU: the slab is [16 value | 16 gate] channels -> one 16-channel block of the output
@@ -1136,6 +1160,8 @@ static unsigned magic_u16_(int d) { return (unsigned)((0x100000000ull + (unsigne
     } while (0)
 
 constexpr int kMaxKSplit = 32;
+
+bool conv3_lin_fk_k(int Cin) { return Cin == 320 || Cin == 640 || Cin == 512 || Cin == 384 || Cin == 1280; }
 
 // Split-K factor of a launch with `base` items and `nchunks` channel chunks: only under-filled grids are split, every
 // split keeps >= 2 chunks.  Depends on the batch size through `base`: outputs of launches with different splits
@@ -1307,24 +1333,28 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         ksplit = 1;
     }
     // short-K linear layers on many tokens: lin_fk_kernel (A rows in registers, full-K weight slabs through LDS)
-    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && (p.Cin == 320 || p.Cin == 640 || p.Cin == 512 || p.Cin == 384) &&
+    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && conv3_lin_fk_k(p.Cin) &&
         a.nchunks * NC8 * 8 == p.Cin && a.Mtot >= knob(K_LIN_FK_MIN_ROWS) && a.ablate == 0 && p.lCout % 16 == 0 &&
         (a.relu == 0 || a.relu == 1 || a.relu == 4)) {
         const int nslabs = (p.lCout + 31) / 32;
         const long long mtiles = (a.Mtot + 127) / 128;
-        int ngroups = (int)std::max(1ll, std::min((long long)nslabs, (knob(K_LIN_FK_BLOCKS) + mtiles - 1) / mtiles));
+        // (K = 1280: one 8-wave block per CU)
+        const int want = p.Cin == 1280 ? knob(K_LIN_FK_BLOCKS) / 2 : knob(K_LIN_FK_BLOCKS);
+        int ngroups = (int)std::max(1ll, std::min((long long)nslabs, (want + mtiles - 1) / mtiles));
         const int cpg = (nslabs + ngroups - 1) / ngroups;
         ngroups = (nslabs + cpg - 1) / cpg;
         const long long grid = mtiles * ngroups;
         if (grid > 0 && grid <= 0x7fffffffll) {
             typedef void (*lin_t)(const K3Args, int, int, int);
             // K = 320 / 640: MuseTalk's 32^2 / 16^2 transformer levels; 512: the VAE mid-block attention; 384: the stacked k | v projection of the audio context
-            const lin_t lk = p.Cin == 320 ? (lin_t)lin_fk_kernel<20, 20> : p.Cin == 640 ? (lin_t)lin_fk_kernel<40, 20> : p.Cin == 512 ? (lin_t)lin_fk_kernel<32, 16>
-                                                                                                                          : (lin_t)lin_fk_kernel<24, 24>;
-            const size_t lbytes = (size_t)2 * (p.Cin == 512 ? 16 : p.Cin == 384 ? 24 : 20) * 1024 + 512;
+            // 1280: the 8^2 level's projections and ff.net.2 of the 32^2 level (two waves per pixel subtile, K halves)
+            const lin_t lk = p.Cin == 320 ? (lin_t)lin_fk_kernel<20, 20, 1> : p.Cin == 640 ? (lin_t)lin_fk_kernel<40, 20, 1> : p.Cin == 512 ? (lin_t)lin_fk_kernel<32, 16, 1>
+                           : p.Cin == 384 ? (lin_t)lin_fk_kernel<24, 24, 1> : (lin_t)lin_fk_kernel<40, 20, 2>;
+            const int ks = p.Cin == 1280 ? 2 : 1;
+            const size_t lbytes = (size_t)2 * ks * (p.Cin == 512 ? 16 : p.Cin == 384 ? 24 : 20) * 1024 + 512 + (ks == 2 ? 2 * 4 * 4096 : 0);
             HIPCHK3((hipError_t)ensure_dyn_lds((const void*)lk, (int)lbytes));
             a.ksplit = 1; a.partial = nullptr;
-            hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(256), lbytes, stream, a, cpg, ngroups, nslabs);
+            hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(256 * ks), lbytes, stream, a, cpg, ngroups, nslabs);
             HIPCHK3(hipGetLastError());
             return 0;
         }

@@ -191,6 +191,9 @@ int rowconv_launch(const RowGemmPlan& p, const RowConvIO& io, hipStream_t stream
 // W_eff[j][(dy * (1 + px) + dx) * C + c] = w[c][j][py + 1 - 2 dy][px + 1 - 2 dx], one launch; io.H x io.W source, io.Ho x io.Wo = 2H x 2W output
 int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t stream, std::string* err);
 
+// conv3_mfma.hip: input-channel counts of 1x1 / linear layers that lin_fk_kernel serves (knob LIN_FK; >= LIN_FK_MIN_ROWS pixels or tokens)
+bool conv3_lin_fk_k(int Cin);
+
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;
 struct FacePtrs;

@@ -977,7 +977,9 @@ static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, si
             if (op.unet3x3 && nf <= 16 && knob(K_MT_TILE_TABLE) && op.x.P() >= 64) io.force_pxw = op.x.P() == 256 ? 1 : 2;
             std::string e;
             int rc;
-            if (op.rplan >= 0 && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
+            // (K = 1280 linear layers from LIN_FK_MIN_ROWS rows on - the 8^2 level of a 16-frame pass - take conv3_launch's lin_fk route)
+            const bool lin_fk = knob(K_LIN_FK) && op.ksz == 1 && conv3_lin_fk_k(g.plans[op.plan].Cin) && (long long)nf * op.y.P() >= knob(K_LIN_FK_MIN_ROWS);
+            if (op.rplan >= 0 && !lin_fk && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
                 RowConvIO rio;
                 rio.x = io.x; rio.x_ld = op.x.ld; rio.x_coff = op.x.coff; rio.H = op.x.H; rio.W = op.x.W;
                 rio.y = io.y; rio.y_ld = op.y.ld; rio.y_coff = op.y.coff; rio.Ho = op.y.H; rio.Wo = op.y.W;

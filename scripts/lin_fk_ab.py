@@ -22,6 +22,9 @@ SHAPES = [  # (N, H, Cin, Cout, residual, name)
     (1, 32, 320, 320, True, "1 frame 32^2 to_out"), (1, 32, 320, 2560, False, "1 frame 32^2 ff.net.0.proj"), (2, 16, 640, 640, True, "2 frames 16^2 to_out"),
     (16, 32, 512, 1536, False, "VAE mid attention to_qkv"), (16, 32, 512, 512, True, "VAE mid attention to_out"),
     (25, 8, 384, 25600, False, "audio context k | v, 1600 rows"),
+    (16, 8, 1280, 1280, True, "8^2 to_out / to_q / proj"), (16, 8, 1280, 3840, False, "8^2 to_qkv"), (16, 8, 1280, 10240, False, "8^2 ff.net.0.proj"),
+    (16, 32, 1280, 320, True, "32^2 ff.net.2"), (16, 16, 1280, 640, False, "16^2 shortcut 1280 -> 640"), (64, 8, 1280, 1280, True, "64 frames 8^2 to_out"),
+    (8, 8, 1280, 1280, True, "8 frames 8^2 to_out"),
 ]
 
 

@@ -148,7 +148,7 @@ def test_conv_first_generation_kernel(engine):
     assert not report, "\n".join(report)
 
 
-# lin_fk_kernel (conv3_mfma.hip): 1x1 / linear layers with K = 320 / 384 / 512 / 640 on >= 512 rows (MuseTalk's 32^2 / 16^2 transformer levels):
+# lin_fk_kernel (conv3_mfma.hip): 1x1 / linear layers with K = 320 / 384 / 512 / 640 / 1280 on >= 512 rows (MuseTalk's 32^2 / 16^2 transformer levels):
 # whole and ragged pixel tiles, tiles that straddle images (8x8 maps), partial cout slabs (48 = 1.5 slabs), with / without residual
 CASES_LIN_FK = [
     (16, 32, 32, 320, 320, 1, 1, 0, False, 0, True),
@@ -161,6 +161,11 @@ CASES_LIN_FK = [
     (2, 32, 32, 512, 512, 1, 1, 0, False, 0, True),
     (13, 10, 5, 384, 160, 1, 1, 0, False, 0, False),
     (1, 32, 32, 320, 320, 1, 1, 0, False, 0, True),
+    # K = 1280: two waves per pixel subtile (K halves summed through LDS: fixed order, not conv3's)
+    (16, 8, 8, 1280, 1280, 1, 1, 0, False, 0, True),
+    (3, 32, 32, 1280, 320, 1, 1, 0, False, 0, False),
+    (9, 8, 8, 1280, 3840, 1, 1, 0, False, 0, False),
+    (11, 7, 9, 1280, 48, 1, 1, 0, False, 0, False),
 ]
 
 
@@ -203,7 +208,7 @@ def test_lin_fk_kernel_vs_torch_and_conv3(engine):
             dd = (from_cb16(y1, Cout) - from_cb16(y0, Cout)).abs()
             print(f"[lin_fk] case {i} {case}: bad={bad} maxerr={float(torch.nan_to_num(err, nan=1e9).max()):.4g} equal_to_conv3={same} "
                   f"(differing {int((dd != 0).sum())} of {dd.numel()}, max {float(dd.max()):.3g})")
-            if bad or not same:
+            if bad or (not same and case[3] != 1280) or float(dd.max()) > 4e-3 * float(ref.abs().max()):
                 report.append(f"case {i} {case}: bad={bad} equal_to_conv3={same}")
     finally:
         Engine.set_knob("LIN_FK", 1)
