@@ -974,7 +974,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void lin_fk_kernel(const
 #pragma unroll
         for (int h = 0; h < KP; ++h) {
             const int cur = parts_done & 1;
-            __syncthreads();               // vmcnt(0): this part landed; every wave left stage cur^1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's copies of the part landed (explicit: not left to hipcc's barrier lowering)
+            __syncthreads();               // ... every wave's did; every wave left stage cur^1
             if (h + 1 < KP) stage(s, h + 1, cur ^ 1);
             else if (s + 1 < s_end) stage(s + 1, 0, cur ^ 1);
             ++parts_done;

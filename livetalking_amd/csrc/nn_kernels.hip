@@ -563,6 +563,152 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     }
 }
 
+// Round 6: self-attention with the key / value tiles staged in LDS (the 32^2 and 16^2 levels of the U-Net: 1024 / 256 tokens, head
+// dims 40 / 80).  attn_kernel's waves each pull all of K and V^T through their own registers from L2 (4096 waves x 160 KB per 32^2
+// attention; 190 registers with the two-tile prefetch: two waves per SIMD); here the four waves of a block - four query tiles of one
+// (image, head) - share 64-key tiles that the block copies with global_load_lds into a three-stage ring (K: [channel block][key][2 x 16 B]
+// with the halves swapped where bit 3 of the key is set; V^T: [channel row][8 x 16 B] with the chunk index xor (row >> 1) & 7: both
+// fragment reads are conflict-free ds_read_b128), one barrier per tile.  Arithmetic and order are attn_kernel's: same values.
+#define NN_GLDS16(gptr, lptr)                                                                                \
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                  \
+                                     (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
+template <int DT, int DVT>
+__global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_at[];
+    constexpr int KBY = DT * 2048, VBY = DVT * 32 * 128, STG = KBY + VBY;      // bytes per stage: K tile, V^T tile
+    constexpr int NP = 2 * DT + 4 * DVT;                                       // 1-KiB DMA pieces per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int Tq = a.Tq, Tk = a.Tk, Tkp = a.Tkp;
+    const f16* qb = a.q + ((size_t)(n * a.q_cbt + a.q_cb0 + h * DT) * Tq) * 16 + hh * 8;
+    const f16* kb = a.k + ((size_t)(n * a.k_cbt + a.k_cb0 + h * DT) * Tk) * 16;
+    const f16* vtb = a.vt + ((size_t)(n * a.heads + h) * a.dv32) * Tkp;
+    const int qrow = min(q0 + l31, Tq - 1);
+
+    // every wave issues PPW copies per tile (the last ones wrap round and repeat a piece: same bytes to the same place), so that ONE
+    // counted wait - all but the newest tile's copies - holds for the whole block
+    constexpr int PPW = (NP + 3) / 4;
+    auto stage = [&](int t, int buf) {
+        unsigned char* const base = smem_at + buf * STG;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            int pi = wave + 4 * k;                               // wave-uniform
+            if (pi >= NP) pi -= 4;
+            if (pi < 2 * DT) {
+                const int j = pi >> 1, key_l = (pi & 1) * 32 + (lane >> 1);
+                const int half = (lane & 1) ^ ((key_l >> 3) & 1);
+                NN_GLDS16(kb + ((size_t)j * Tk + t * 64 + key_l) * 16 + half * 8, base + pi * 1024);
+            } else {
+                const int pv = pi - 2 * DT, row = pv * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                NN_GLDS16(vtb + (size_t)row * Tkp + t * 64 + c * 8, base + KBY + pv * 1024);
+            }
+        }
+    };
+    const int ntiles = Tk >> 6;
+    stage(0, 0);
+    if (ntiles > 1) stage(1, 1);
+
+    f16x8 qf[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const f16x8*>(qb + ((size_t)j * Tq + qrow) * 16);
+    f32x16 acc[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    int buf = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t landed (this wave's copies - all but the PPW of tile t+1 -; the barrier then covers the other waves'), and every wave left
+        // the stage of tile t-1, which tile t+2 now overwrites.  The waits are explicit: hipcc's own s_waitcnt in front of this barrier
+        // covered lgkmcnt only (it had hoisted the vmcnt(0) out of the loop), and a second call with the same inputs gave other frames.
+        // (No other vector-memory operation is outstanding inside the loop: the counter counts tile copies only.)
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < ntiles) stage(t + 2, buf == 0 ? 2 : buf - 1);
+        const unsigned char* const Kb = smem_at + buf * STG;
+        const unsigned char* const Vb = Kb + KBY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key_l = u * 32 + l31;
+            const unsigned char* kp = Kb + key_l * 32 + ((hh ^ ((key_l >> 3) & 1)) << 4);
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(kp + j * 2048), qf[j], st, 0, 0, 0);
+            // the value fragments of this sub-tile: requested in front of the softmax arithmetic
+            f16x8 vf[2][DVT];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int tt = 0; tt < DVT; ++tt) {
+                    const int row = tt * 32 + l31;
+                    vf[s2][tt] = *reinterpret_cast<const f16x8*>(Vb + row * 128 + (((u * 4 + s2 * 2 + hh) ^ ((row >> 1) & 7)) << 4));
+                }
+            float mx = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m, mx);
+            float ls = 0.f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+            if (__any(m_new > m)) {
+                const float alpha = __expf(m - m_new);
+                l = l * alpha;
+#pragma unroll
+                for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] *= alpha;
+            }
+            l += ls;
+            m = m_new;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pf[r] = (f16)p[8 * s2 + r]; pf[4 + r] = (f16)p[8 * s2 + 4 + r]; }
+#pragma unroll
+                for (int tt = 0; tt < DVT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][tt], pf, acc[tt], 0, 0, 0);
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    const float inv = 1.f / (l + __shfl_xor(l, 32));
+    const bool qok = (q0 + l31) < Tq;
+    f16* ob = a.o + ((size_t)(n * a.o_cbt + a.o_cb0 + h * DT) * Tq + min(q0 + l31, Tq - 1)) * 16 + hh * 8;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int cbl = t * 2 + pr;
+            unsigned pk[2][2];
+#pragma unroll
+            for (int eo = 0; eo < 2; ++eo) {
+                const int g = 2 * pr + eo;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[t][4 * g + r] * inv);
+                const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                pk[eo][0] = u.x; pk[eo][1] = u.y;
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (qok && cbl < DT) *reinterpret_cast<uint4*>(ob + (size_t)cbl * Tq * 16) = out;
+        }
+    }
+}
+
 // Wide single head (VAE mid-block attention: 1 head of 512 channels, 1024 tokens; vae.py:96-108 -> AutoencoderKL mid block).
 // The 4 waves of a block take the SAME 32 queries and split BOTH contractions:
 //   S^T = K Q^T over the channel dimension: wave w contracts channel blocks [8w, 8w+8) (8 MFMAs per 32-key tile instead of
@@ -696,6 +842,16 @@ int launch_attention(const f16* q, int q_cbt, int q_cb0, int Tq, const f16* k, i
     a.Tq = Tq; a.Tk = Tk; a.Tkp = attn_tkp(Tk); a.heads = heads; a.dv32 = attn_dv32(d16);
     const int qtiles = (Tq + 31) / 32;
     const dim3 grid4((qtiles + 3) / 4, heads, N), grid1(qtiles, heads, N);
+    // self-attention over whole 64-key tiles: K / V^T tiles shared by a block's four query tiles through LDS (knob ATTN_LDS)
+    if (knob(K_ATTN_LDS) && Tk % 64 == 0 && Tk >= 128 && (d16 == 48 || d16 == 80)) {
+        if (d16 == 48) hipLaunchKernelGGL((attn_lds_kernel<3, 2>), grid4, dim3(256), (size_t)3 * (3 * 2048 + 2 * 32 * 128), s, a);
+        else {
+            constexpr int lds53 = 3 * (5 * 2048 + 3 * 32 * 128);          // 66 KiB: above the 64-KiB default
+            if (ensure_dyn_lds((const void*)attn_lds_kernel<5, 3>, lds53)) return -2;
+            hipLaunchKernelGGL((attn_lds_kernel<5, 3>), grid4, dim3(256), (size_t)lds53, s, a);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     switch (d16) {
         case 48:
             if (knob(K_ATTN_PF)) hipLaunchKernelGGL((attn_kernel<3, 2, false, true>), grid4, dim3(256), 0, s, a);

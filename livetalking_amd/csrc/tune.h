@@ -82,6 +82,8 @@ enum Knob {
                           //                    lin_fk_kernel (conv3_mfma.hip: a wave's A rows in registers, full-K 32-cout weight slabs through LDS); 0: conv3 1x1
     K_LIN_FK_BLOCKS,      // LTK_LIN_FK_BLOCKS  blocks a lin_fk launch aims at (the output channels are split into groups of slabs until the grid has this many)
     K_LIN_FK_MIN_ROWS,    // LTK_LIN_FK_MIN_ROWS  (default 512)
+    K_ATTN_LDS,           // LTK_ATTN_LDS       1 (default): self-attention with head dims 40 / 80 over >= 128 keys (whole 64-key tiles) shares its K / V^T tiles between a
+                          //                    block's four query tiles through LDS (nn_kernels.hip attn_lds_kernel); 0: attn_kernel (every wave reads them from L2)
     K_COUNT
 };
 

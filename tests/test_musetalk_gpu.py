@@ -400,3 +400,33 @@ def test_musetalk_graph_replay_equals_eager_launches(mt):
         assert not torch.equal(eager[0], eager[1])
     finally:
         Engine.set_knob("GRAPH", 1)
+
+
+@pytest.mark.gpu
+def test_lds_staged_self_attention_equals_per_wave_attention(mt):
+    """Knob ATTN_LDS (round 6, nn_kernels.hip attn_lds_kernel): the self-attentions of the 32^2 / 16^2 levels share their key /
+    value tiles between a block's four query tiles through LDS.  Same arithmetic in the same order as attn_kernel: the frames of
+    a call must be byte for byte the frames of the knob off."""
+    from livetalking_amd.engine import Engine
+    eng, usd, vsd = mt
+    n = 4
+    lats = synth.musetalk_latents(n)
+    frames, masks, face_boxes, crop_boxes, _ = synth.musetalk_blend_avatar()
+    aid = eng.register_musetalk_avatar(lats, frames, face_boxes, masks, crop_boxes)
+    feats = torch.from_numpy(synth.musetalk_whisper_feats(B, seed=77)).cuda()
+
+    def run():
+        pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            eng.musetalk_infer([(aid, 1, B, feats.data_ptr(), pred.data_ptr())])
+        return pred
+
+    try:
+        Engine.set_knob("ATTN_LDS", 0)
+        off = run()
+        Engine.set_knob("ATTN_LDS", 1)
+        on = run()
+        assert torch.equal(on, off), f"differing bytes: {int((on != off).sum())}"
+        assert int(on.max()) > 0
+    finally:
+        Engine.set_knob("ATTN_LDS", 1)
