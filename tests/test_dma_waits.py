@@ -1,0 +1,59 @@
+"""Regression guard for the LDS-DMA pipelines (global_load_lds): a wave must wait for its own tile copies (`s_waitcnt vmcnt`) before
+the workgroup barrier that publishes the tile.  hipcc derives that wait from __syncthreads() for conv3's chunk loop, but hoisted it
+OUT of attn_lds_kernel's tile loop (round 6: a second call with equal inputs gave other frames; profiles/r06_attn_lds_ab.txt).  The
+kernels that stage through a DMA ring now carry the wait as inline asm; this test compiles the two sources to gfx950 ISA (no GPU
+needed) and checks every barrier of those kernels - and the chunk-loop barrier of every conv3 instantiation - for it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "livetalking_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _functions(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", CSRC, os.path.join(CSRC, src), "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    funcs, cur = {}, None
+    for line in out.read_text().split("\n"):
+        m = re.match(r"^(_ZN3ltk\w+):", line)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        if cur is not None:
+            funcs[cur].append(line)
+        if "s_endpgm" in line:
+            cur = None
+    return funcs
+
+
+def _barrier_waits(lines):
+    """per s_barrier: True when an s_waitcnt with a vmcnt field sits within the six instructions in front of it"""
+    res = []
+    for i, l in enumerate(lines):
+        if "s_barrier" in l:
+            res.append(any("s_waitcnt" in x and "vmcnt" in x for x in lines[max(0, i - 8):i]))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_dma_ring_kernels_wait_for_their_copies_before_the_barrier(tmp_path):
+    conv3 = _functions("conv3_mfma.hip", tmp_path)
+    nn = _functions("nn_kernels.hip", tmp_path)
+    checked = 0
+    for name, lines in list(conv3.items()) + list(nn.items()):
+        if not any("global_load_lds" in l for l in lines):
+            continue
+        waits = _barrier_waits(lines)
+        assert waits, f"{name}: a DMA kernel without a barrier"
+        if "lin_fk_kernel" in name or "attn_lds_kernel" in name:
+            assert all(waits), f"{name}: a barrier of the DMA ring has no vmcnt wait in front of it: {waits}"
+        else:
+            # conv3: the item barrier and the zero-fill barrier publish no copies; the chunk-loop barrier (the last one) does
+            assert waits[-1], f"{name}: the chunk-loop barrier has no vmcnt wait in front of it: {waits}"
+        checked += 1
+    assert checked >= 40, f"only {checked} DMA kernels found: the scan no longer sees the instantiations"
