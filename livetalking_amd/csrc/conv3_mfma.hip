@@ -1110,6 +1110,197 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void lin_fk_kernel(const
     }
 }
 
+
+// One slab's epilogue for one wave's 32 pixels (lin_fk_kernel's, as a function for lin_mp_kernel): 32 x 32 accumulators -> y
+__device__ __forceinline__ void lin_slab_epilogue(const K3Args& a, const f32x16& acc, const int s, const float* const ssb, const int n, const int pix,
+                                                   const bool ok, const int tok, const float lmean, const float lrstd, const int hh, const int P) {
+    const int cout0 = s * 32;
+    const int ncb_valid = min(2, (a.Cout - cout0) >> 4);
+    const bool ln_cons = a.ln_in != nullptr, ln_prod = a.ln_out != nullptr, has_res = a.res != nullptr;
+    if (ncb_valid <= 0) return;
+    if (a.relu == 4) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int eo = 0; eo < 2; ++eo) {
+            const int cl = 8 * eo + 4 * hh;
+            const f32x4 scv = *reinterpret_cast<const f32x4*>(ssb + cl), sfv = *reinterpret_cast<const f32x4*>(ssb + 32 + cl);
+            const f32x4 scg = *reinterpret_cast<const f32x4*>(ssb + cl + 16), sfg = *reinterpret_cast<const f32x4*>(ssb + 32 + cl + 16);
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v, gt;
+                if (ln_cons) {
+                    v = lrstd * (acc[4 * eo + r] - lmean * scv[r]) + sfv[r];
+                    gt = lrstd * (acc[4 * (2 + eo) + r] - lmean * scg[r]) + sfg[r];
+                } else {
+                    v = acc[4 * eo + r] * scv[r] + sfv[r];
+                    gt = acc[4 * (2 + eo) + r] * scg[r] + sfg[r];
+                }
+                const float t = v * gelu_as(gt);
+                o[r] = (f16)__builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+            }
+            const uint2 u = *reinterpret_cast<const uint2*>(&o);
+            pk[eo][0] = u.x; pk[eo][1] = u.y;
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if (ok) *reinterpret_cast<uint4*>(a.y + ((size_t)(n * a.y_cbt + a.y_cb0 + (cout0 >> 5)) * P + pix) * 16 + hh * 8) = out;
+        return;
+    }
+    const int cbo = cout0 >> 4;
+    const float lo = a.relu == 1 ? 0.f : -65504.f;
+    float ls = 0.f, lq = 0.f;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        if (pr >= ncb_valid) continue;           // wave-uniform
+        unsigned pk[2][2];
+#pragma unroll
+        for (int eo = 0; eo < 2; ++eo) {
+            const int q4 = 2 * pr + eo;
+            const int cl = 8 * q4 + 4 * hh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ssb + cl), sf = *reinterpret_cast<const f32x4*>(ssb + 32 + cl);
+            float v[4];
+            if (ln_cons) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = lrstd * (acc[4 * q4 + r] - lmean * sc[r]) + sf[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[4 * q4 + r] * sc[r] + sf[r];
+            }
+            if (has_res) {
+                const f16x4 rr = *reinterpret_cast<const f16x4*>(a.res + ((size_t)(n * a.res_cbt + a.res_cb0 + cbo + pr) * P + pix) * 16 + hh * 4 + eo * 8);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)__builtin_amdgcn_fmed3f(v[r], lo, 65504.f);
+            if (ln_prod) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; ls += f; lq += f * f; }
+            }
+            const uint2 u = *reinterpret_cast<const uint2*>(&o);
+            pk[eo][0] = u.x; pk[eo][1] = u.y;
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if (ok) *reinterpret_cast<uint4*>(a.y + ((size_t)(n * a.y_cbt + a.y_cb0 + cbo + pr) * P + pix) * 16 + hh * 8) = out;
+    }
+    if (ln_prod) {
+        const float su = ls + __shfl_xor(ls, 32), sq = lq + __shfl_xor(lq, 32);
+        if (ok && hh == 0) reinterpret_cast<float2*>(a.ln_out)[(size_t)tok * a.ln_out_tiles + s] = make_float2(su, sq);
+    }
+}
+
+// lin_mp_kernel<NSL>: lin_fk's K = 1280 arrangement (8 waves: pixel subtile w & 3, K half w >> 2, 640 channels = 160 registers per wave) for
+// K = 2560 / 5120 (ff.net.2 of the 16^2 / 8^2 levels, the 2560-channel shortcuts): the K loop runs in `npass` passes of 1280 channels - a
+// wave reloads its A fragments per pass - and the accumulators of the block's NSL slabs stay in registers across the passes (NSL x 16), so
+// a block is 128 pixels x NSL x 32 output channels over the whole K.  Weight stream: (pass, slab, part) in that order, 20-KiB parts per K
+// half, two stages; after the last pass the upper half's accumulators meet the lower half's in LDS and the lower-half waves run the NSL
+// epilogues.  A group's missing slabs (nslabs not a multiple of NSL) are clamped to the last slab: computed, not stored.
+template <int NSL>
+__global__ __launch_bounds__(512, 1) void lin_mp_kernel(const K3Args a, const int ngroups, const int nslabs, const int npass) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KB = 40, KPB = 20, KP = 2, PART = KPB * 1024, STAGE = 2 * PART;
+    constexpr int SS_OFF = 2 * STAGE, XCH_OFF = SS_OFF + 1024;        // [NSL][scale 32 | shift 32] (NSL <= 4); [NSL][4 subtiles][4][64 lanes][16 B]
+    static_assert(NSL >= 1 && NSL <= 3, "accumulator budget (4 slabs spill)");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, kh = wave8 >> 2;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int grp = blockIdx.x % ngroups, mt = blockIdx.x / ngroups;
+    const int s0 = grp * NSL;
+    const int P = a.HoA * a.WoA;
+    const long long m = (long long)mt * 128 + wave * 32 + l31;
+    const bool ok = m < a.Mtot;
+    const int mm = (int)(ok ? m : a.Mtot - 1);
+    const int n = mm / P, pix = mm - n * P;
+    const size_t slab_bytes = (size_t)npass * 2 * KB * 1024;
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(a.w);
+    auto slab_of = [&](int sl) { return min(s0 + sl, nslabs - 1); };
+    auto stage = [&](int p, int sl, int h, int buf) {
+        const unsigned char* src = wbase + (size_t)slab_of(sl) * slab_bytes + (size_t)((p * 2 + kh) * KP + h) * PART + lane * 16;
+        unsigned char* dst = smem + buf * STAGE + kh * PART;
+#pragma unroll
+        for (int k = 0; k < KPB / 4; ++k) GLDS16(src + (k * 4 + wave) * 1024, dst + (k * 4 + wave) * 1024);
+    };
+    stage(0, 0, 0, 0);
+    if (wave8 < NSL && lane < 16) GLDS16((lane < 8 ? a.scale : a.shift - 32) + slab_of(wave8) * 32 + lane * 4, smem + SS_OFF + wave8 * 256);
+
+    const int tok = n * P + pix;
+    float lmean = 0.f, lrstd = 1.f;
+    if (a.ln_in != nullptr && kh == 0) {
+        const float2* pp = reinterpret_cast<const float2*>(a.ln_in) + (size_t)tok * a.ln_in_tiles;
+        float su = 0.f, sq = 0.f;
+        for (int t = hh; t < a.ln_in_tiles; t += 2) { const float2 v = pp[t]; su += v.x; sq += v.y; }
+        su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+        const float invC = 1.f / (float)(a.ln_in_tiles * 32);
+        lmean = su * invC;
+        lrstd = rsqrtf(fmaxf(sq * invC - lmean * lmean, 0.f) + a.ln_eps);
+    }
+    f32x16 acc[NSL];
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sl][r] = 0.f;
+
+    int parts_done = 0;
+    for (int p = 0; p < npass; ++p) {
+        // this wave's 640 channels of the pass
+        const f16* xb = a.x + ((size_t)(n * a.x_cbt + a.x_cb0 + (p * 2 + kh) * KB) * P + pix) * 16 + hh * 8;
+        f16x8 af[KB];
+#pragma unroll
+        for (int q = 0; q < KB; ++q) af[q] = *reinterpret_cast<const f16x8*>(xb + (size_t)q * P * 16);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int h = 0; h < KP; ++h) {
+                const int cur = parts_done & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's copies of the part (and, at a pass's first part, its A rows) landed
+                __syncthreads();
+                if (h + 1 < KP) stage(p, sl, h + 1, cur ^ 1);
+                else if (sl + 1 < NSL) stage(p, sl + 1, 0, cur ^ 1);
+                else if (p + 1 < npass) stage(p + 1, 0, 0, cur ^ 1);
+                ++parts_done;
+                const unsigned char* Bs = smem + cur * STAGE + kh * PART + (hh * 32 + l31) * 16;
+                f16x8 wf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wf[q] = *reinterpret_cast<const f16x8*>(Bs + q * 1024);
+#pragma unroll
+                for (int q = 0; q < KPB; ++q) {
+                    acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[q & 3], af[h * KPB + q], acc[sl], 0, 0, 0);
+                    if (q + 4 < KPB) wf[q & 3] = *reinterpret_cast<const f16x8*>(Bs + (q + 4) * 1024);
+                }
+            }
+    }
+    // the K halves of a subtile meet in LDS; the lower half's wave runs the epilogues
+    if (kh == 1) {
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            f32x4* const xw = reinterpret_cast<f32x4*>(smem + XCH_OFF + (sl * 4 + wave) * 4096) + lane;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) xw[g4 * 64] = (f32x4){acc[sl][4 * g4], acc[sl][4 * g4 + 1], acc[sl][4 * g4 + 2], acc[sl][4 * g4 + 3]};
+        }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+        if (s0 + sl >= nslabs) break;              // block-uniform
+        const f32x4* const xw = reinterpret_cast<const f32x4*>(smem + XCH_OFF + (sl * 4 + wave) * 4096) + lane;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 o = xw[g4 * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[sl][4 * g4 + r] += o[r];
+        }
+        lin_slab_epilogue(a, acc[sl], s0 + sl, reinterpret_cast<const float*>(smem + SS_OFF + sl * 256), n, pix, ok, tok, lmean, lrstd, hh, P);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1163,6 +1354,21 @@ static unsigned magic_u16_(int d) { return (unsigned)((0x100000000ull + (unsigne
 constexpr int kMaxKSplit = 32;
 
 bool conv3_lin_fk_k(int Cin) { return Cin == 320 || Cin == 640 || Cin == 512 || Cin == 384 || Cin == 1280; }
+
+// lin_mp_kernel's slabs per block for a K = 2560 / 5120 linear layer on `rows` tokens, 0: not its case.  Knob LIN_MP = 1: the kernel is used where its
+// grid is ONE round of blocks on the 256 CUs (measured, profiles/r06_lin_mp_ab.txt: 16^2 ff.net.2 of a 16-frame pass 43 -> 36 us as 224 blocks of 3
+// slabs, 8^2 52 -> 32 us as 160 blocks of 2; in several rounds - 64 frames - it loses to conv3: 113 -> 131 us), with the fewest slabs per block that fit
+// one round; 2 / 3: forced.
+int conv3_lin_mp_nsl(int Cin, long long rows, int Cout) {
+    const int kn = knob(K_LIN_MP);
+    if (!kn || !knob(K_LIN_FK) || !(Cin == 2560 || Cin == 5120) || rows < knob(K_LIN_FK_MIN_ROWS) || Cout % 16) return 0;
+    if (kn == 2 || kn == 3) return kn;
+    const long long mt = (rows + 127) / 128;
+    const int nslabs = (Cout + 31) / 32;
+    for (int nsl = 2; nsl <= 3; ++nsl)
+        if (mt * ((nslabs + nsl - 1) / nsl) <= 256) return nsl;
+    return 0;
+}
 
 // Split-K factor of a launch with `base` items and `nchunks` channel chunks: only under-filled grids are split, every
 // split keeps >= 2 chunks.  Depends on the batch size through `base`: outputs of launches with different splits
@@ -1334,10 +1540,24 @@ int conv3_launch(const ConvPlan& p, const ConvIO& io_in, hipStream_t stream, std
         ksplit = 1;
     }
     // short-K linear layers on many tokens: lin_fk_kernel (A rows in registers, full-K weight slabs through LDS)
-    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && conv3_lin_fk_k(p.Cin) &&
+    const int mp_nsl = (G == 1 && T == 1 && S == 1) ? conv3_lin_mp_nsl(p.Cin, a.Mtot, p.lCout) : 0;
+    if (G == 1 && T == 1 && S == 1 && !p.q8 && !p.mx && !a.ups && !p.gemm_1x1_expand && knob(K_LIN_FK) && (conv3_lin_fk_k(p.Cin) || mp_nsl) &&
         a.nchunks * NC8 * 8 == p.Cin && a.Mtot >= knob(K_LIN_FK_MIN_ROWS) && a.ablate == 0 && p.lCout % 16 == 0 &&
         (a.relu == 0 || a.relu == 1 || a.relu == 4)) {
         const int nslabs = (p.lCout + 31) / 32;
+        if (mp_nsl) {          // lin_mp_kernel: passes of 1280 channels, NSL slabs' accumulators per block
+            const int NSL = mp_nsl;
+            const long long mt = (a.Mtot + 127) / 128;
+            const int ng = (nslabs + NSL - 1) / NSL;
+            typedef void (*mp_t)(const K3Args, int, int, int);
+            const mp_t mk = NSL == 2 ? (mp_t)lin_mp_kernel<2> : (mp_t)lin_mp_kernel<3>;
+            const size_t mb = (size_t)2 * 2 * 20 * 1024 + 1024 + (size_t)NSL * 4 * 4096;
+            HIPCHK3((hipError_t)ensure_dyn_lds((const void*)mk, (int)mb));
+            a.ksplit = 1; a.partial = nullptr;
+            hipLaunchKernelGGL(mk, dim3((unsigned)(mt * ng)), dim3(512), mb, stream, a, ng, nslabs, p.Cin / 1280);
+            HIPCHK3(hipGetLastError());
+            return 0;
+        }
         const long long mtiles = (a.Mtot + 127) / 128;
         // (K = 1280: one 8-wave block per CU)
         const int want = p.Cin == 1280 ? knob(K_LIN_FK_BLOCKS) / 2 : knob(K_LIN_FK_BLOCKS);

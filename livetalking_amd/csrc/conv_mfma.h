@@ -193,6 +193,7 @@ int rowconvT_launch(const RowGemmPlan* p, const RowConvIO& io, hipStream_t strea
 
 // conv3_mfma.hip: input-channel counts of 1x1 / linear layers that lin_fk_kernel serves (knob LIN_FK; >= LIN_FK_MIN_ROWS pixels or tokens)
 bool conv3_lin_fk_k(int Cin);
+int conv3_lin_mp_nsl(int Cin, long long rows, int Cout);     // lin_mp_kernel's slabs per block for this layer on `rows` tokens, 0: not its case
 
 // conv7_mfma.hip: the generator's first layer (Conv2d(6,16,7,1,3) + BN + ReLU on 256x256) fused with the input pack
 struct Conv7Plan;

@@ -978,7 +978,8 @@ static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, si
             std::string e;
             int rc;
             // (K = 1280 linear layers from LIN_FK_MIN_ROWS rows on - the 8^2 level of a 16-frame pass - take conv3_launch's lin_fk route)
-            const bool lin_fk = knob(K_LIN_FK) && op.ksz == 1 && conv3_lin_fk_k(g.plans[op.plan].Cin) && (long long)nf * op.y.P() >= knob(K_LIN_FK_MIN_ROWS);
+            const bool lin_fk = knob(K_LIN_FK) && op.ksz == 1 && (long long)nf * op.y.P() >= knob(K_LIN_FK_MIN_ROWS) &&
+                                (conv3_lin_fk_k(g.plans[op.plan].Cin) || conv3_lin_mp_nsl(g.plans[op.plan].Cin, (long long)nf * op.y.P(), g.plans[op.plan].lCout) > 0);
             if (op.rplan >= 0 && !lin_fk && (long long)nf * op.y.P() <= std::min(knob(K_MT_ROWCONV), kRowConvMaxRows)) {
                 RowConvIO rio;
                 rio.x = io.x; rio.x_ld = op.x.ld; rio.x_coff = op.x.coff; rio.H = op.x.H; rio.W = op.x.W;

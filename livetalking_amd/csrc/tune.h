@@ -84,6 +84,9 @@ enum Knob {
     K_LIN_FK_MIN_ROWS,    // LTK_LIN_FK_MIN_ROWS  (default 512)
     K_ATTN_LDS,           // LTK_ATTN_LDS       1 (default): self-attention with head dims 40 / 80 over >= 128 keys (whole 64-key tiles) shares its K / V^T tiles between a
                           //                    block's four query tiles through LDS (nn_kernels.hip attn_lds_kernel); 0: attn_kernel (every wave reads them from L2)
+    K_LIN_MP,             // LTK_LIN_MP         1 (default): 1x1 / linear layers with K = 2560 / 5120 run on lin_mp_kernel (conv3_mfma.hip: passes of 1280 channels, the
+                          //                    accumulators of 2 or 3 weight slabs per block in registers) where its grid is one round of blocks
+                          //                    (conv3_lin_mp_nsl); 2 / 3: always, with that many slabs per block; 0: conv3 / rowconv
     K_COUNT
 };
 

@@ -25,6 +25,8 @@ SHAPES = [  # (N, H, Cin, Cout, residual, name)
     (16, 8, 1280, 1280, True, "8^2 to_out / to_q / proj"), (16, 8, 1280, 3840, False, "8^2 to_qkv"), (16, 8, 1280, 10240, False, "8^2 ff.net.0.proj"),
     (16, 32, 1280, 320, True, "32^2 ff.net.2"), (16, 16, 1280, 640, False, "16^2 shortcut 1280 -> 640"), (64, 8, 1280, 1280, True, "64 frames 8^2 to_out"),
     (8, 8, 1280, 1280, True, "8 frames 8^2 to_out"),
+    (16, 16, 2560, 640, False, "16^2 ff.net.2 (lin_mp)"), (16, 8, 5120, 1280, False, "8^2 ff.net.2 (lin_mp)"), (16, 8, 2560, 1280, False, "8^2 shortcut 2560 -> 1280 (lin_mp)"),
+    (64, 16, 2560, 640, False, "64 frames 16^2 ff.net.2 (lin_mp)"), (64, 8, 5120, 1280, False, "64 frames 8^2 ff.net.2 (lin_mp)"),
 ]
 
 
@@ -32,6 +34,8 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     blocks = [v for v in sys.argv[2:]] or ["512"]          # LIN_FK_BLOCKS values
     eng = Engine(0)
+    if os.environ.get("LIN_MP"):
+        Engine.set_knob("LIN_MP", int(os.environ["LIN_MP"]))
     g = torch.Generator(device="cpu").manual_seed(1)
     settings = [("conv3", 0, "0")] + [(f"lin_fk/{b}", 1, b) for b in blocks]
     print("us per launch: " + " | ".join(n for n, _, _ in settings))

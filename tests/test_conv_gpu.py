@@ -166,6 +166,13 @@ CASES_LIN_FK = [
     (3, 32, 32, 1280, 320, 1, 1, 0, False, 0, False),
     (9, 8, 8, 1280, 3840, 1, 1, 0, False, 0, False),
     (11, 7, 9, 1280, 48, 1, 1, 0, False, 0, False),
+    # K = 2560 / 5120: lin_mp_kernel (passes of 1280 channels, the accumulators of LIN_MP weight slabs per block)
+    (16, 16, 16, 2560, 640, 1, 1, 0, False, 0, False),
+    (16, 8, 8, 5120, 1280, 1, 1, 0, False, 0, False),
+    (9, 8, 8, 2560, 1280, 1, 1, 0, False, 0, False),
+    (11, 7, 9, 2560, 48, 1, 1, 0, False, 0, False),
+    (5, 11, 13, 5120, 336, 1, 1, 0, False, 0, False),
+    (2, 16, 16, 2560, 2560, 1, 1, 0, False, 0, True),
 ]
 
 
@@ -195,8 +202,10 @@ def test_lin_fk_kernel_vs_torch_and_conv3(engine):
     report = []
     try:
         Engine.set_knob("SPLITK", 0)
-        for i, case in enumerate(CASES_LIN_FK):
+        runs = [(i, case, mp) for i, case in enumerate(CASES_LIN_FK) for mp in ((2, 3) if case[3] >= 2560 else (1,))]   # lin_mp: both slab counts, forced
+        for i, case, mp in runs:
             Engine.set_knob("LIN_FK", 1)
+            Engine.set_knob("LIN_MP", mp)
             y1, ref = run(case, 300 + i)
             Engine.set_knob("LIN_FK", 0)
             y0, _ = run(case, 300 + i)
@@ -206,11 +215,12 @@ def test_lin_fk_kernel_vs_torch_and_conv3(engine):
             bad = (~(err <= 2e-3 * ref.abs().clamp(min=1.0) + 2e-3)).sum().item()
             same = torch.equal(from_cb16(y1, Cout), from_cb16(y0, Cout))
             dd = (from_cb16(y1, Cout) - from_cb16(y0, Cout)).abs()
-            print(f"[lin_fk] case {i} {case}: bad={bad} maxerr={float(torch.nan_to_num(err, nan=1e9).max()):.4g} equal_to_conv3={same} "
+            print(f"[lin_fk] case {i} {case} LIN_MP={mp}: bad={bad} maxerr={float(torch.nan_to_num(err, nan=1e9).max()):.4g} equal_to_conv3={same} "
                   f"(differing {int((dd != 0).sum())} of {dd.numel()}, max {float(dd.max()):.3g})")
-            if bad or (not same and case[3] != 1280) or float(dd.max()) > 4e-3 * float(ref.abs().max()):
+            if bad or (not same and case[3] < 1280) or float(dd.max()) > 4e-3 * float(ref.abs().max()):
                 report.append(f"case {i} {case}: bad={bad} equal_to_conv3={same}")
     finally:
         Engine.set_knob("LIN_FK", 1)
+        Engine.set_knob("LIN_MP", 1)
         Engine.set_knob("SPLITK", 1)
     assert not report, "\n".join(report)

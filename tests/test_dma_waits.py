@@ -50,7 +50,7 @@ def test_dma_ring_kernels_wait_for_their_copies_before_the_barrier(tmp_path):
             continue
         waits = _barrier_waits(lines)
         assert waits, f"{name}: a DMA kernel without a barrier"
-        if "lin_fk_kernel" in name or "attn_lds_kernel" in name:
+        if "lin_fk_kernel" in name or "lin_mp_kernel" in name or "attn_lds_kernel" in name:
             assert all(waits), f"{name}: a barrier of the DMA ring has no vmcnt wait in front of it: {waits}"
         else:
             # conv3: the item barrier and the zero-fill barrier publish no copies; the chunk-loop barrier (the last one) does
