@@ -2131,6 +2131,7 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
     if (!rc) {
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+        if (!rc && mt_gn_error(e->mt)) rc = fail(LTK_E_HIP, std::string("musetalk: ") + mt_graph_error(e->mt));
     }
     return rc;
 }
@@ -2455,6 +2456,7 @@ int ltk_musetalk_time_ops(ltk_engine* e, int frames, int iters, float* ms_per_op
     }
     for (auto& ev : evs) (void)hipEventDestroy(ev);
     if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
+    if (mt_gn_error(e->mt)) return fail(LTK_E_HIP, std::string("musetalk: ") + mt_graph_error(e->mt));
     for (int i = 0; i < n_ops; ++i) ms_per_op[i] = (float)(acc[i] / iters);
     return LTK_OK;
 }
@@ -2477,6 +2479,7 @@ int ltk_musetalk_time(ltk_engine* e, int frames, int iters, float* ms_per_pass, 
     if (rc) return fail(LTK_E_INVALID, std::string("musetalk: ") + mt_graph_error(e->mt));
     CHK(hipEventRecord(t1, e->compute));
     CHK(hipEventSynchronize(t1));
+    if (mt_gn_error(e->mt)) return fail(LTK_E_HIP, std::string("musetalk: ") + mt_graph_error(e->mt));
     float ms = 0.f;
     CHK(hipEventElapsedTime(&ms, t0, t1));
     *ms_per_pass = ms / iters;
@@ -2603,6 +2606,7 @@ int ltk_vae_encode_faces(ltk_engine* e, const uint8_t* faces_bgr, int nfaces, co
         launch_vae_latents(mt_unet_out(e->vae_enc, &cbt), nf, noise ? d_noise : nullptr, 0.18215f, d_out, s);
         CHK(hipMemcpyAsync(latents_out + (size_t)f0 * 8 * 1024, d_out, (size_t)nf * 8 * 1024 * sizeof(float), hipMemcpyDeviceToHost, s));
         CHK(hipStreamSynchronize(s));
+        if (mt_gn_error(e->vae_enc)) { rc = fail(LTK_E_HIP, std::string("vae encoder: ") + mt_graph_error(e->vae_enc)); break; }
     }
     (void)hipFree(d_faces); (void)hipFree(d_out);
     if (d_noise) (void)hipFree(d_noise);

@@ -16,6 +16,8 @@ struct MtTensor;
 MtGraph* mt_graph_new();
 void mt_graph_delete(MtGraph* g);
 const char* mt_graph_error(const MtGraph* g);
+// after the pass's stream has been synchronised: 1 (and mt_graph_error says so) if a cooperative GroupNorm block's wait ran out during it
+int mt_gn_error(MtGraph* g);
 // before mt_build: run the ResnetBlock2D 3x3 convs on fp8 (e4m3) operands; act_scale = what GroupNorm+SiLU outputs are
 // multiplied by before the saturating conversion (<= 0 keeps the default 8)
 void mt_set_fp8(MtGraph* g, int on, float act_scale);

@@ -90,6 +90,7 @@ struct MtOp {
     int ln_out_buf = -1, ln_in_buf = -1, ln_in_tiles = 0;
     float ln_eps = 1e-5f;
     int vt_buf = -1;            // OP_ATTN: the values are already transposed in this buffer (written by the pass's OP_VT), else the shared scratch
+    long long gn_slot_off = -1; // OP_GN on a map gn_coop_kernel serves: first word of this op's exchange slots in MtGraph::gn_slots
 };
 
 // one cross-attention's share of the hoisted k | v projection (MtGraph::kv_all): its value view and where the transposed values go
@@ -105,6 +106,10 @@ struct MtGraph {
     std::map<std::string, MtTensor> named;
     float* gn_partial = nullptr;
     size_t gn_partial_floats = 0;
+    unsigned* gn_slots = nullptr;            // gn_coop_kernel's exchange slots of every GroupNorm op it serves (reset to the sentinel at the head of a pass)
+    size_t gn_slot_words = 0;
+    unsigned* gn_err_host = nullptr;         // host-mapped word a block sets when its wait for its set ran out; gn_err_dev = the device's view of it
+    unsigned* gn_err_dev = nullptr;
     f16* vt = nullptr;                        // transposed values scratch
     size_t vt_halfs = 0;                      // per frame
     struct KvPre { MtTensor k, v; int vt_buf; };
@@ -938,6 +943,22 @@ int mt_graph_alloc(MtGraph& g, int frames) {
         if (op.type == OP_GN) need = std::max(need, (size_t)frames * (op.x.C / 16) * 256 * 32);
     g.gn_partial_floats = need;
     if (hipMalloc((void**)&g.gn_partial, need * sizeof(float)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+    // gn_coop_kernel: 8 words per block, a region per op (a launch of nf <= frames images uses the head of its region)
+    g.gn_slot_words = 0;
+    for (MtOp& op : g.ops) {
+        op.gn_slot_off = -1;
+        if (op.type != OP_GN || gn_group_fits(op.x.C, op.x.P(), op.groups)) continue;
+        const int M = gn_coop_members(op.x.C, op.x.P(), op.groups);
+        if (!M) continue;
+        op.gn_slot_off = (long long)g.gn_slot_words;
+        g.gn_slot_words += (size_t)frames * (op.x.C / 16) * (op.x.P() / 2048) * 8;      // sized for 2048-pixel slices, the smallest the kernel uses
+    }
+    if (g.gn_slot_words) {
+        if (hipMalloc((void**)&g.gn_slots, g.gn_slot_words * sizeof(unsigned)) != hipSuccess) { g.err = "allocation failed"; return -4; }
+        if (hipHostMalloc((void**)&g.gn_err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) { g.err = "allocation failed"; return -4; }
+        *g.gn_err_host = 0u;
+        if (hipHostGetDevicePointer((void**)&g.gn_err_dev, g.gn_err_host, 0) != hipSuccess) { g.err = "allocation failed"; return -4; }
+    }
     if (g.vt_halfs) {
         if (hipMalloc((void**)&g.vt, g.vt_halfs * frames * sizeof(f16)) != hipSuccess) { g.err = "allocation failed"; return -4; }
     }
@@ -950,6 +971,9 @@ void mt_graph_free(MtGraph& g) {
     for (RowGemmPlan& p : g.rplans) rowgemm_plan_destroy(&p);
     for (float* v : g.vecs) if (v) (void)hipFree(v);
     if (g.gn_partial) (void)hipFree(g.gn_partial);
+    if (g.gn_slots) (void)hipFree(g.gn_slots);
+    if (g.gn_err_host) (void)hipHostFree(g.gn_err_host);
+    g.gn_slots = nullptr; g.gn_err_host = nullptr; g.gn_err_dev = nullptr;
     if (g.vt) (void)hipFree(g.vt);
     g.bufs.clear(); g.plans.clear(); g.rplans.clear(); g.vecs.clear();
 }
@@ -1000,6 +1024,12 @@ static int mt_run_op_body(MtGraph& g, const MtOp& op, int nf, float* partial, si
                 launch_gn_group(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.vecs[op.gamma],
                                 g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.q8 ? op.y.ld / 32 : op.y.ld / 16,
                                 op.y.q8 ? op.y.coff / 32 : op.y.coff / 16, op.y.q8 ? 1 : 0, g.fp8_ascale, s);
+                break;
+            }
+            if (knob(K_GN_COOP) && op.gn_slot_off >= 0 && g.gn_slots) {           // one tensor pass: slices in registers, partial sums exchanged between blocks
+                launch_gn_coop(g.bufs[op.x.buf], nf, op.x.ld / 16, op.x.coff / 16, op.x.C, P, op.groups, op.eps, g.gn_slots + op.gn_slot_off, g.gn_err_dev,
+                               g.vecs[op.gamma], g.vecs[op.beta], op.silu, g.bufs[op.y.buf], op.y.q8 ? op.y.ld / 32 : op.y.ld / 16,
+                               op.y.q8 ? op.y.coff / 32 : op.y.coff / 16, op.y.q8 ? 1 : 0, g.fp8_ascale, s);
                 break;
             }
             const int segs = gn_segments(nf, op.x.C, P);
@@ -1063,6 +1093,17 @@ int mt_graph_run(MtGraph& g, int nf, float* partial, size_t partial_cap, hipStre
                  std::vector<hipEvent_t>* evs = nullptr) {
     if (nf > g.frames) { g.err = "more frames than the graph was sized for"; return -1; }
     if (op_end < 0) op_end = (int)g.ops.size();
+    if (g.gn_slots && knob(K_GN_COOP)) {                 // the exchange slots of this range's cooperative GroupNorms back to the sentinel (one fill per pass)
+        long long lo = -1, hi = -1;
+        for (int oi = op_begin; oi < op_end; ++oi) {
+            const MtOp& op = g.ops[oi];
+            if (op.type != OP_GN || op.gn_slot_off < 0) continue;
+            const long long words = (long long)g.frames * (op.x.C / 16) * (op.x.P() / 2048) * 8;
+            if (lo < 0) lo = op.gn_slot_off;
+            hi = op.gn_slot_off + words;
+        }
+        if (lo >= 0) launch_gn_coop_reset(g.gn_slots + lo, (size_t)(hi - lo), s);
+    }
     for (int oi = op_begin; oi < op_end; ++oi) {
         if (evs) (void)hipEventRecord((*evs)[oi - op_begin], s);
         const int rc = mt_run_op(g, g.ops[oi], nf, partial, partial_cap, s);
@@ -1092,6 +1133,12 @@ void mt_graph_delete(MtGraph* g) {
     delete g;
 }
 const char* mt_graph_error(const MtGraph* g) { return g->err.c_str(); }
+int mt_gn_error(MtGraph* g) {
+    if (!g || !g->gn_err_host || !*reinterpret_cast<volatile unsigned*>(g->gn_err_host)) return 0;
+    *g->gn_err_host = 0u;
+    g->err = "a cooperative GroupNorm block gave up waiting for its set (gn_coop_kernel): the pass's frames are invalid; LTK_GN_COOP=0 selects the two-pass kernels";
+    return 1;
+}
 
 void mt_set_sat_counter(MtGraph* g, unsigned long long* d_ctr) { g->sat_ctr = d_ctr; }
 void mt_set_fp8(MtGraph* g, int on, float act_scale) { g->fp8 = on != 0; if (act_scale > 0.f) g->fp8_ascale = act_scale; }

@@ -30,6 +30,16 @@ bool gn_group_fits(int C, int P, int groups);
 void launch_gn_group(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, const float* gamma, const float* beta,
                      int silu, f16* y, int y_cbt, int y_cb0, int fp8, float out_scale, hipStream_t s);
 
+// GroupNorm of the large maps in ONE tensor pass (gn_coop_kernel): a block keeps a 2048-pixel slice of an (image, 16-channel block) in registers,
+// the gn_coop_members() = P / 2048 blocks of that (image, channel block) exchange partial sums through `slots` (8 words per block, this launch's
+// N * C/16 * members * 8 words; filled with 0xFFFFFFFF by launch_gn_coop_reset BEFORE the launch, once per pass for all its GroupNorms).  0: not its
+// case (channels per group other than 4 / 8 / 16, P not a multiple of 2048, fewer than 2 or more than 32 slices).  *err (host-visible) is set to 1
+// if a block's wait for its set ran out.
+int gn_coop_members(int C, int P, int groups);
+void launch_gn_coop_reset(unsigned* slots, size_t words, hipStream_t s);
+void launch_gn_coop(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, unsigned* slots, unsigned* err,
+                    const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, int fp8, float out_scale, hipStream_t s);
+
 // ---- LayerNorm over channels per token (BasicTransformerBlock.norm1/2/3, Whisper layer norms)
 void launch_layernorm(const f16* x, int N, int cbt, int cb0, int C, int P, float eps, const float* gamma, const float* beta,
                       f16* y, int y_cbt, int y_cb0, hipStream_t s);

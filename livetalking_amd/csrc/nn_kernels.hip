@@ -298,6 +298,164 @@ void launch_gn_group(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, in
 #undef GNG
 }
 
+// ---- GroupNorm of the large maps in ONE tensor pass (round 6): gn_coop_kernel
+// The (image, group)s of the VAE's 64^2 .. 256^2 maps (128 KB .. 2 MB per 16-channel block) fit no single block, so gn_stats + gn_apply read the
+// tensor twice.  Here a block owns a 2048-pixel slice of one (image, 16-channel block) - 64 KB, kept in REGISTERS from its single read -, the M
+// blocks of a (image, channel block) exchange their partial sums through global memory and every block normalises, activates and stores its own
+// registers: one read + one write instead of two reads + one write.
+//   * exchange without fences: a block publishes its 8 partial sums (sum / sum of squares of the channel quarters 0-3, 4-7, 8-11, 12-15) as 8
+//     self-validating words - relaxed agent-scope atomic stores into slots that the pass's prologue filled with the sentinel 0xFFFFFFFF (no fp32
+//     sum has that bit pattern) - and polls the 8 M words of its set with relaxed agent-scope atomic loads until none is the sentinel.  No
+//     release / acquire fence anywhere (an agent-scope fence writes back / invalidates the XCD's whole L2: what sank the in-kernel split-K
+//     reduction of round 3).
+//   * forward progress: the members of a set have consecutive block ids; workgroups are dispatched in id order (per XCD), so the members of
+//     the lowest unfinished set are resident or done whatever the later blocks wait for.  A poll that does not complete in ~2^16 tries sets
+//     *err (host-mapped) and goes on with what it has: loud on the host, never a hang.
+//   * fixed summation order (thread, wave tree, waves, members in id order): deterministic, every member derives the same statistics.
+// Channels per group 4 / 8 / 16 (whole groups inside a 16-channel block), P a multiple of 2048 with <= 32 slices.
+// Measured (profiles/r06_gn_coop_ab.txt, 16 frames): 128 ch @ 256^2 155 -> 132 us (117 us with the exchange switched off: the wait is exposed once per
+// round of resident blocks; 512-thread blocks with 16 members per set: 134 us), 256 ch @ 128^2 80 -> 67 us, 512 ch @ 64^2 50 -> 33 us.
+int gn_coop_members(int C, int P, int groups) {
+    if (groups <= 0 || C % groups) return 0;
+    const int cpg = C / groups;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16) || C % 16 || P % 2048) return 0;
+    const int M = P / 2048;
+    return (M >= 2 && M <= 32) ? M : 0;
+}
+
+__global__ __launch_bounds__(256) void gn_fill_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+void launch_gn_coop_reset(unsigned* slots, size_t words, hipStream_t s) {
+    if (!words) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 1024);
+    hipLaunchKernelGGL(gn_fill_kernel, dim3(blocks), dim3(256), 0, s, slots, words, 0xFFFFFFFFu);
+}
+
+template <bool FP8>
+__global__ __launch_bounds__(256) void gn_coop_kernel(const f16* __restrict__ x, int x_cbt, int x_cb0, int CB, int P, int cpg, int M, float eps,
+                                                       unsigned* __restrict__ slots, unsigned* __restrict__ err,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                       f16* __restrict__ y, int y_cbt, int y_cb0, float out_scale) {
+    constexpr int NT = 256, NW = NT / 64, SL = NT * 8;  // threads, waves, pixels of a block's slice
+    __shared__ float red[NW][8];
+    __shared__ float part[32][8];
+    __shared__ float ab[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int set = blockIdx.x / M, mem = blockIdx.x - set * M;
+    const int n = set / CB, cb = set - n * CB;
+    const int p0 = mem * SL + tid;                         // this thread's pixels: p0 + NT k, all 16 channels of each
+    const f16* xb = x + ((size_t)(n * x_cbt + x_cb0 + cb) * P + p0) * 16;
+    f16x8 v[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k][0] = *reinterpret_cast<const f16x8*>(xb + (size_t)k * NT * 16);
+        v[k][1] = *reinterpret_cast<const f16x8*>(xb + (size_t)k * NT * 16 + 8);
+    }
+    float sq[8];                                           // [0..3] sums of the channel quarters, [4..7] sums of squares
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float f = (float)v[k][h][c];
+                sq[2 * h + (c >> 2)] += f;
+                sq[4 + 2 * h + (c >> 2)] += f * f;
+            }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sq[i] += __shfl_xor(sq[i], m);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[wave][i] = sq[i];
+    }
+    __syncthreads();
+    unsigned* const set_slots = slots + (size_t)set * M * 8;
+    if (tid < 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][tid];
+        __hip_atomic_store(set_slots + mem * 8 + tid, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 8 * M) {
+        unsigned w = __hip_atomic_load(set_slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int tries = 0;
+        while (w == 0xFFFFFFFFu && ++tries < (1 << 16)) {
+            __builtin_amdgcn_s_sleep(2);
+            w = __hip_atomic_load(set_slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (w == 0xFFFFFFFFu) { *err = 1u; w = 0u; }
+        part[tid >> 3][tid & 7] = __uint_as_float(w);
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int q0 = (tid / cpg) * cpg / 4, nq = cpg / 4;       // this channel's group = quarters [q0, q0 + nq)
+        float S = 0.f, Q = 0.f;
+        for (int m = 0; m < M; ++m)
+            for (int i = 0; i < nq; ++i) { S += part[m][q0 + i]; Q += part[m][4 + q0 + i]; }
+        const float cnt = (float)cpg * (float)P;
+        const float mean = S / cnt;
+        const float rstd = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + eps);
+        const float a = gamma[cb * 16 + tid] * rstd;
+        ab[0][tid] = a;
+        ab[1][tid] = beta[cb * 16 + tid] - mean * a;
+    }
+    __syncthreads();
+    // (the slice stays PACKED across the exchange: without this the compiler keeps the fp32 copies of the statistics loop alive - 168 registers)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { asm volatile("" : "+v"(v[k][0])); asm volatile("" : "+v"(v[k][1])); }
+    float a16[16], b16[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { a16[c] = ab[0][c]; b16[c] = ab[1][c]; }
+    if constexpr (FP8) {
+        unsigned char* yq = reinterpret_cast<unsigned char*>(y) + ((size_t)(n * y_cbt + y_cb0 + (cb >> 1)) * P + p0) * 32 + (cb & 1) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float t = (float)v[k][c >> 3][c & 7] * a16[c] + b16[c];
+                if (silu) t = silu_f(t);
+                f[c] = fminf(fmaxf(t * out_scale, -448.f), 448.f);
+            }
+            int w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[j] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * j], f[4 * j + 1], w[j], false);
+                w[j] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * j + 2], f[4 * j + 3], w[j], true);
+            }
+            *reinterpret_cast<int4*>(yq + (size_t)k * NT * 32) = make_int4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        f16* yb = y + ((size_t)(n * y_cbt + y_cb0 + cb) * P + p0) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 o;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float t = (float)v[k][h][c] * a16[8 * h + c] + b16[8 * h + c];
+                    if (silu) t = silu_f(t);
+                    o[c] = (f16)t;
+                }
+                *reinterpret_cast<f16x8*>(yb + (size_t)k * NT * 16 + 8 * h) = o;
+            }
+    }
+}
+
+void launch_gn_coop(const f16* x, int N, int x_cbt, int x_cb0, int C, int P, int groups, float eps, unsigned* slots, unsigned* err,
+                    const float* gamma, const float* beta, int silu, f16* y, int y_cbt, int y_cb0, int fp8, float out_scale, hipStream_t s) {
+    const int CB = C / 16, M = gn_coop_members(C, P, groups);
+    const dim3 grid((unsigned)((size_t)N * CB * M));
+    if (fp8) hipLaunchKernelGGL(gn_coop_kernel<true>, grid, dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, M, eps, slots, err, gamma, beta, silu, y, y_cbt, y_cb0, out_scale);
+    else hipLaunchKernelGGL(gn_coop_kernel<false>, grid, dim3(256), 0, s, x, x_cbt, x_cb0, CB, P, C / groups, M, eps, slots, err, gamma, beta, silu, y, y_cbt, y_cb0, 1.f);
+}
+
 // =============================================================================================== LayerNorm
 // 16 tokens x 16 channel slices per block: the transformer maps are small (1024 / 256 / 64 tokens per image), so the grid
 // needs short blocks to cover 256 CUs (64-token blocks left the 32^2 level at one block per CU, 1 TB/s)

@@ -87,6 +87,8 @@ enum Knob {
     K_LIN_MP,             // LTK_LIN_MP         1 (default): 1x1 / linear layers with K = 2560 / 5120 run on lin_mp_kernel (conv3_mfma.hip: passes of 1280 channels, the
                           //                    accumulators of 2 or 3 weight slabs per block in registers) where its grid is one round of blocks
                           //                    (conv3_lin_mp_nsl); 2 / 3: always, with that many slabs per block; 0: conv3 / rowconv
+    K_GN_COOP,            // LTK_GN_COOP        1 (default): GroupNorm of the maps too large for MT_GN1 (the VAE's 64^2 .. 256^2 maps) in ONE tensor pass: blocks keep their
+                          //                    slice in registers and exchange partial sums through global memory (nn_kernels.hip gn_coop_kernel); 0: gn_stats + gn_apply
     K_COUNT
 };
 

@@ -49,6 +49,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_LIN_FK_MIN_ROWS", 512},
     {"LTK_ATTN_LDS", 1},
     {"LTK_LIN_MP", 1},
+    {"LTK_GN_COOP", 1},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -17,7 +17,7 @@ import synth_inputs as synth  # noqa: E402
 from livetalking_amd.engine import Engine  # noqa: E402
 
 BUILD_KNOBS = ("MT_FUSE", "MT_ROWCONV", "GEMM_NC8")
-DEFAULTS = {"MT_GN1": 1, "GRAPH": 1, "MT_TILE_TABLE": 1, "LIN_FK": 1, "LIN_FK_BLOCKS": 512, "LIN_FK_MIN_ROWS": 512, "ATTN_LDS": 1, "LIN_MP": 1}
+DEFAULTS = {"MT_GN1": 1, "GRAPH": 1, "MT_TILE_TABLE": 1, "LIN_FK": 1, "LIN_FK_BLOCKS": 512, "LIN_FK_MIN_ROWS": 512, "ATTN_LDS": 1, "LIN_MP": 1, "GN_COOP": 1}
 
 
 def parse(spec):

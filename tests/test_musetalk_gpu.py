@@ -430,3 +430,40 @@ def test_lds_staged_self_attention_equals_per_wave_attention(mt):
         assert int(on.max()) > 0
     finally:
         Engine.set_knob("ATTN_LDS", 1)
+
+
+@pytest.mark.gpu
+def test_one_pass_groupnorm_of_the_large_maps(mt):
+    """Knob GN_COOP (round 6, nn_kernels.hip gn_coop_kernel): the GroupNorms of the VAE's 64^2 .. 256^2 maps read their tensor once - a block
+    keeps its slice in registers, the blocks of an (image, channel block) exchange partial sums through global memory (slots reset at the head
+    of every pass, also inside the replayed graph).  Another fp32 summation order than gn_stats + gn_apply: frames within 1 LSB of the knob off;
+    deterministic: eight calls (eager, capture, replays) give the same bytes."""
+    from livetalking_amd.engine import Engine
+    eng, usd, vsd = mt
+    n = 4
+    lats = synth.musetalk_latents(n)
+    frames, masks, face_boxes, crop_boxes, _ = synth.musetalk_blend_avatar()
+    aid = eng.register_musetalk_avatar(lats, frames, face_boxes, masks, crop_boxes)
+    feats = torch.from_numpy(synth.musetalk_whisper_feats(B, seed=78)).cuda()
+
+    def run(times):
+        outs = []
+        for _ in range(times):
+            pred = torch.zeros(B, 256, 256, 3, dtype=torch.uint8, device="cuda")
+            eng.musetalk_infer([(aid, 1, B, feats.data_ptr(), pred.data_ptr())])
+            outs.append(pred)
+        return outs
+
+    try:
+        Engine.set_knob("GN_COOP", 0)
+        off = run(2)[-1]
+        Engine.set_knob("GN_COOP", 1)
+        on = run(8)
+        for k in range(1, 8):
+            assert torch.equal(on[k], on[0]), f"call {k} differs from call 0: {int((on[k] != on[0]).sum())} bytes"
+        d = (on[0].int() - off.int()).abs()
+        print(f"[mt] one-pass GroupNorm vs two-pass: max diff {int(d.max())} LSB, differing bytes {float((d != 0).float().mean()):.2e}")
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.1
+        assert int(on[0].max()) > 0
+    finally:
+        Engine.set_knob("GN_COOP", 1)
