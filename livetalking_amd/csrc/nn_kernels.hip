@@ -84,7 +84,9 @@ void launch_gn_stats(const f16* x, int N, int cbt, int cb0, int C, int P, int se
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * CB, segs), dim3(256), 0, s, x, cbt, cb0, CB, P, segs, partial);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+// v * rcp(1 + exp(-v)): v_rcp_f32 (1 ulp) instead of the correctly rounded division (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup: 11 more
+// VALU instructions per element, 38 % of gn_coop_kernel's instruction stream; MuseTalk pass -1.1 .. -1.5 % in-job, profiles/r06_gn_coop_ab.txt)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
 template <bool FP8>
@@ -355,15 +357,19 @@ __global__ __launch_bounds__(256) void gn_coop_kernel(const f16* __restrict__ x,
     float sq[8];                                           // [0..3] sums of the channel quarters, [4..7] sums of squares
 #pragma unroll
     for (int i = 0; i < 8; ++i) sq[i] = 0.f;
+    // v_dot2c_f32_f16: sum and sum of squares of a channel PAIR in one instruction each (exact fp16 products, fp32 accumulation) - a third of the
+    // convert / add / fma sequence; the kernel's VALU time is of the order of its memory time (r06_gn_coop_ab.txt)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float f = (float)v[k][h][c];
-                sq[2 * h + (c >> 2)] += f;
-                sq[4 + 2 * h + (c >> 2)] += f * f;
+            for (int c2 = 0; c2 < 4; ++c2) {
+                const h2 pr = {v[k][h][2 * c2], v[k][h][2 * c2 + 1]};
+                sq[2 * h + (c2 >> 1)] = __builtin_amdgcn_fdot2(pr, ones, sq[2 * h + (c2 >> 1)], false);
+                sq[4 + 2 * h + (c2 >> 1)] = __builtin_amdgcn_fdot2(pr, pr, sq[4 + 2 * h + (c2 >> 1)], false);
             }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
