@@ -17,7 +17,7 @@ typedef _Float16 f16;
 // most of the GEGLU epilogue's time (21 M gates per 16-frame launch on the 32^2 level).
 __device__ __forceinline__ float gelu_as(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));      // v_rcp_f32 (1 ulp); __frcp_rn compiles to the 12-instruction correctly rounded division
     float p = fmaf(t, 1.061405429f, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
