@@ -20,6 +20,7 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kLog2e = 1.4426950408889634f;
 
 // =============================================================================================== GroupNorm
 int gn_segments(int N, int C, int P) {
@@ -660,8 +661,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         const float m_new = fmaxf(m, mx);
         float ls = 0.f;
         float p[16];
+        const float mneg = -m_new * kLog2e;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(st[r], kLog2e, mneg)); ls += p[r]; }      // exp(st - m_new): one fma in front of v_exp_f32 instead of sub + mul
         if (__any(m_new > m)) {
             const float alpha = __expf(m - m_new);
             l = l * alpha;
@@ -824,8 +826,9 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
             const float m_new = fmaxf(m, mx);
             float ls = 0.f;
             float p[16];
+            const float mneg = -m_new * kLog2e;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(st[r], kLog2e, mneg)); ls += p[r]; }      // exp(st - m_new): one fma in front of v_exp_f32 instead of sub + mul
             if (__any(m_new > m)) {
                 const float alpha = __expf(m - m_new);
                 l = l * alpha;
@@ -955,8 +958,9 @@ __global__ __launch_bounds__(256, 2) void attn_wide_kernel(const AttnArgs a) {
         const float alpha = __expf(m - m_new);
         float ls = 0.f;
         float p[16];
+        const float mneg = -m_new * kLog2e;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = __expf(st[r] - m_new); ls += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(st[r], kLog2e, mneg)); ls += p[r]; }      // exp(st - m_new): one fma in front of v_exp_f32 instead of sub + mul
         l = l * alpha + ls;
         m = m_new;
 #pragma unroll
