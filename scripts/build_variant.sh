@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
 for f in tune conv_mfma conv3_mfma conv7_mfma rowgemm misc_kernels egress_kernels nn_kernels musetalk engine; do
   extra=""
-  case $f in misc_kernels|egress_kernels) extra="-ffp-contract=off";; esac
+  case $f in misc_kernels|egress_kernels) extra="-ffp-contract=off";; nn_kernels) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ -n "$(find $SRC -name '*.h' -newer $OBJ/$f.o)" ] || [ -n "$FORCE" ]; then
     /opt/rocm/bin/hipcc $FLAGS $extra -c $SRC/$f.hip -o $OBJ/$f.o &
     pids+=($!)

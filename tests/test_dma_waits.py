@@ -16,7 +16,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 def _functions(src, tmp_path):
     out = tmp_path / (os.path.basename(src) + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", CSRC, os.path.join(CSRC, src), "-o", str(out)],
+    extra = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] if src == "nn_kernels.hip" else []        # as csrc/Makefile builds it
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, "-S", "--cuda-device-only", "-I", CSRC, os.path.join(CSRC, src), "-o", str(out)],
                    check=True, capture_output=True, timeout=900)
     funcs, cur = {}, None
     for line in out.read_text().split("\n"):
