@@ -334,6 +334,15 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
                    int transposed, int out_pad, const float* scale, const float* shift,
                    const void* d_res, int relu, void* d_y, int iters, float* ms_avg);
 
+/* Standalone GroupNorm (+ SiLU) over a channel-blocked fp16 tensor, for kernel unit tests and timing (diffusers GroupNorm as the MuseTalk U-Net / VAE
+ * use it; `avatars/musetalk/models/unet.py:36-46`, `vae.py:96-108` call sites).  x, y: device fp16 [N][C/16][P][16]; gamma / beta host fp32 [C];
+ * impl: 0 = what the MuseTalk program would pick for this shape, 1 = gn_stats + gn_apply (two launches, three tensor passes), 2 = gn_group_kernel
+ * (one block per (image, group)), 3 = gn_coop_kernel (one tensor pass, blocks exchange partial sums); an impl that does not serve the shape is refused.
+ * out_fp8 != 0: y is e4m3 [N][C/32][P][32] = min(max(result * out_scale, -448), 448) (the operand format of the fp8 conv path).
+ * iters > 0: additionally timed over `iters` back-to-back runs. */
+int ltk_groupnorm_f16(ltk_engine* e, const void* d_x, int N, int C, int P, int groups, float eps, const float* gamma, const float* beta,
+                      int silu, int impl, int out_fp8, float out_scale, void* d_y, int iters, float* ms_avg);
+
 /* host-side fp32 -> OCP e4m3fn conversion of the weight packer (round to nearest even, saturating at +-448); no GPU needed */
 int ltk_f32_to_e4m3(const float* in, size_t n, uint8_t* out);
 

@@ -95,6 +95,8 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.POINTER(C.c_float)]),
+    "ltk_groupnorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "ltk_f32_to_e4m3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ltk_conv2d_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -1868,6 +1868,71 @@ int ltk_conv2d_f16(ltk_engine* e, const void* d_x, int N, int H, int W, int Cin,
     return LTK_OK;
 }
 
+int ltk_groupnorm_f16(ltk_engine* e, const void* d_x, int N, int C, int P, int groups, float eps, const float* gamma, const float* beta,
+                      int silu, int impl, int out_fp8, float out_scale, void* d_y, int iters, float* ms_avg) {
+    if (!e || !d_x || !d_y || !gamma || !beta || N <= 0 || C <= 0 || P <= 0 || groups <= 0 || C % groups || C % 16 || (out_fp8 && C % 32))
+        return fail(LTK_E_INVALID, "bad arguments");
+    CHK(enter_device(e->device));
+    const bool fits_group = gn_group_fits(C, P, groups);
+    const int members = gn_coop_members(C, P, groups);
+    if (impl == 0) impl = (knob(K_MT_GN1) && fits_group) ? 2 : (knob(K_GN_COOP) && members) ? 3 : 1;
+    if ((impl == 2 && !fits_group) || (impl == 3 && !members) || impl < 1 || impl > 3) return fail(LTK_E_INVALID, "this GroupNorm kernel does not serve the shape");
+    float *d_gamma = nullptr, *d_beta = nullptr, *d_partial = nullptr;
+    unsigned *d_slots = nullptr, *err_host = nullptr, *err_dev = nullptr;
+    const int segs = gn_segments(N, C, P);
+    const size_t slot_words = (size_t)N * (C / 16) * std::max(members, 1) * 8;
+    hipStream_t s = e->compute;
+    std::lock_guard<std::mutex> g(e->mu);
+    int rc = LTK_OK;
+    auto cleanup = [&]() {
+        if (d_gamma) (void)hipFree(d_gamma);
+        if (d_beta) (void)hipFree(d_beta);
+        if (d_partial) (void)hipFree(d_partial);
+        if (d_slots) (void)hipFree(d_slots);
+        if (err_host) (void)hipHostFree(err_host);
+    };
+    if (hipMalloc((void**)&d_gamma, C * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_beta, C * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&d_partial, (size_t)N * (C / 16) * segs * 32 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&d_slots, slot_words * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void**)&err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&err_dev, err_host, 0) != hipSuccess) { cleanup(); return fail(LTK_E_HIP, "allocation failed"); }
+    *err_host = 0u;
+    (void)hipMemcpyAsync(d_gamma, gamma, C * sizeof(float), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(d_beta, beta, C * sizeof(float), hipMemcpyHostToDevice, s);
+    const f16* x = (const f16*)d_x;
+    const int ycb = out_fp8 ? C / 32 : C / 16;
+    auto run = [&]() {
+        if (impl == 3) {
+            launch_gn_coop_reset(d_slots, slot_words, s);
+            launch_gn_coop(x, N, C / 16, 0, C, P, groups, eps, d_slots, err_dev, d_gamma, d_beta, silu, (f16*)d_y, ycb, 0, out_fp8 ? 1 : 0, out_scale, s);
+        } else if (impl == 2) {
+            launch_gn_group(x, N, C / 16, 0, C, P, groups, eps, d_gamma, d_beta, silu, (f16*)d_y, ycb, 0, out_fp8 ? 1 : 0, out_scale, s);
+        } else {
+            launch_gn_stats(x, N, C / 16, 0, C, P, segs, d_partial, s);
+            if (out_fp8) launch_gn_apply_fp8(x, N, C / 16, 0, C, P, groups, eps, d_partial, segs, d_gamma, d_beta, silu, out_scale, (unsigned char*)d_y, ycb, 0, s);
+            else launch_gn_apply(x, N, C / 16, 0, C, P, groups, eps, d_partial, segs, d_gamma, d_beta, silu, (f16*)d_y, ycb, 0, s);
+        }
+    };
+    run();
+    if (iters > 0 && ms_avg) {
+        hipEvent_t t0, t1;
+        (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+        (void)hipEventRecord(t0, s);
+        for (int i = 0; i < iters; ++i) run();
+        (void)hipEventRecord(t1, s);
+        (void)hipEventSynchronize(t1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        *ms_avg = ms / iters;
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    }
+    const hipError_t he = hipStreamSynchronize(s);
+    if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(LTK_E_HIP, std::string("GroupNorm kernel: ") + hipGetErrorString(he));
+    else if (*reinterpret_cast<volatile unsigned*>(err_host)) rc = fail(LTK_E_HIP, "a cooperative GroupNorm block gave up waiting for its set (gn_coop_kernel)");
+    cleanup();
+    return rc;
+}
+
 int ltk_f32_to_e4m3(const float* in, size_t n, uint8_t* out) {
     if (!in || !out) return fail(LTK_E_INVALID, "bad arguments");
     for (size_t i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);

@@ -412,6 +412,17 @@ class Engine:
             C.c_void_p(d_y_ptr), iters, C.byref(ms)))
         return ms.value
 
+    def groupnorm_f16(self, d_x_ptr: int, N, C_, P, groups, eps, gamma: np.ndarray, beta: np.ndarray, silu: bool, d_y_ptr: int, impl: int = 0,
+                      out_fp8: bool = False, out_scale: float = 1.0, iters: int = 0) -> float:
+        """Standalone GroupNorm(+SiLU) on a CB16 tensor (include/ltk.h: ltk_groupnorm_f16); impl 0 = the program's choice, 1 = two-pass,
+        2 = one block per (image, group), 3 = one tensor pass with the exchange between blocks.  Returns ms per run when iters > 0."""
+        ga = np.ascontiguousarray(gamma, dtype=np.float32)
+        be = np.ascontiguousarray(beta, dtype=np.float32)
+        ms = C.c_float(0)
+        _lib.check(self._lib.ltk_groupnorm_f16(self._h, C.c_void_p(d_x_ptr), N, C_, P, groups, float(eps), ga.ctypes.data, be.ctypes.data,
+                                               1 if silu else 0, impl, 1 if out_fp8 else 0, float(out_scale), C.c_void_p(d_y_ptr), iters, C.byref(ms)))
+        return ms.value
+
     def conv2d_f16(self, d_x_ptr: int, N, H, W, Cin, weight: np.ndarray, Cout, k, stride, pad, transposed=False,
                    out_pad=0, scale: Optional[np.ndarray] = None, shift: Optional[np.ndarray] = None,
                    d_res_ptr: int = 0, relu=True, d_y_ptr: int = 0, iters: int = 0) -> float:
