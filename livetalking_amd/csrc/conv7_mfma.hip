@@ -185,4 +185,84 @@ int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ audio0
+// audio_encoder.0: Conv2d(1, 32, 3, stride 1, pad 1) + BN + ReLU on the 80 x 16 mel window (wav2lip_v2.py:42, conv.py:5-19), with the
+// mel pack of LipReal.inference_batch fused (avatars/wav2lip_avatar.py:131,134: the float32 windows go to the network as [B][1][80][16]).
+//
+// Why its own kernel (round 6): ONE input channel x 9 taps.  The generic path was pack_mel_kernel (float32 -> an 8-channel fp16 cell per
+// pixel, 7 of them zero) + the first-generation MFMA kernel on a K of 8 x 10 rows of which 9 carry anything: 4.8 + 12.0 us at the head of
+// a 16-frame call's dependent chain (the audio encoder heads the critical path under knob PREFETCH) and 10 + 243 us at 256 frames, for
+// 5.9 MFLOP per 16 frames.  As VALU work it is 288 fma per pixel: a thread owns one pixel and all 32 output channels, reads its 3 x 3
+// neighbourhood from the frame's float32 window (rounded to fp16 exactly as the pack did, so the operands are the MFMA path's operands),
+// takes the fp16-rounded weights, the BN scale and shift as wave-uniform scalar loads (constant indices after unrolling: no LDS, no
+// vector loads) and stores the two 32-byte CB16 cells of its pixel.  fp32 products of fp16 operands are exact; the nine-term fp32 sum
+// differs from the MFMA's in summation order only.
+__global__ __launch_bounds__(256) void audio0_kernel(const MelPtrs* __restrict__ mel, const float* __restrict__ wsf, f16* __restrict__ y,
+                                                     const int y_cbt, const int y_cb0) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;          // pixel of the 80 x 16 map (5 blocks x 256 threads = 1280)
+    const float* __restrict__ m = mel->p[f];
+    const int r = i >> 4, c = i & 15;
+    float v[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int rr = r + ky - 1, cc = c + kx - 1;
+            const bool in = rr >= 0 && rr < 80 && cc >= 0 && cc < 16;
+            v[ky * 3 + kx] = in ? (float)(f16)m[in ? rr * 16 + cc : 0] : 0.f;
+        }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        f16* const yp = y + (((size_t)f * y_cbt + y_cb0 + cb) * 1280 + i) * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int co = cb * 16 + h * 8 + q;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wsf[co * 9 + t], acc);
+                o[q] = (f16)__builtin_amdgcn_fmed3f(fmaf(acc, wsf[288 + co], wsf[320 + co]), 0.f, 65504.f);
+            }
+            *reinterpret_cast<f16x8*>(yp + h * 8) = o;
+        }
+    }
+}
+
+struct Audio0Plan {
+    float* d_wsf = nullptr;        // [32][9] fp16-rounded weights, [32] scale, [32] shift
+};
+
+int audio0_plan_create(Audio0Plan** out, const float* weight /*[32][1][3][3]*/, const float* scale, const float* shift, std::string* err) {
+    std::vector<float> wsf(352);
+    for (int k = 0; k < 288; ++k) wsf[k] = (float)(f16)weight[k];
+    for (int co = 0; co < 32; ++co) { wsf[288 + co] = scale[co]; wsf[320 + co] = shift[co]; }
+    Audio0Plan* p = new Audio0Plan();
+    if (hipMalloc((void**)&p->d_wsf, wsf.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->d_wsf, wsf.data(), wsf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (p->d_wsf) (void)hipFree(p->d_wsf);
+        delete p;
+        if (err) *err = "audio0: allocation / upload failed";
+        return -2;
+    }
+    *out = p;
+    return 0;
+}
+
+void audio0_plan_destroy(Audio0Plan* p) {
+    if (!p) return;
+    if (p->d_wsf) (void)hipFree(p->d_wsf);
+    delete p;
+}
+
+// `mels` is a DEVICE table (entries [0, N)); y = the layer's output buffer [N][y_ld / 16][80][16][16], written at channels [y_coff, y_coff + 32)
+int audio0_launch(const Audio0Plan* p, const MelPtrs* mels, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err) {
+    if (!p || !mels || !y || N <= 0 || N > kPackMaxFrames || ((y_ld | y_coff) & 15)) { if (err) *err = "audio0: bad arguments"; return -1; }
+    hipLaunchKernelGGL(audio0_kernel, dim3(5, N), dim3(256), 0, stream, mels, p->d_wsf, y, y_ld >> 4, y_coff >> 4);
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "audio0: launch failed"; return -2; }
+    return 0;
+}
+
 }  // namespace ltk

@@ -204,4 +204,14 @@ void conv7_plan_destroy(Conv7Plan* p);
 int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N, f16* y, int y_ld, int y_coff, hipStream_t stream,
                  std::string* err);
 
+
+// conv7_mfma.hip: the audio encoder's first layer (Conv2d(1,32,3,1,1) + BN + ReLU on the 80 x 16 mel window) as a VALU kernel with the
+// mel pack fused (knob AUDIO0)
+struct Audio0Plan;
+struct MelPtrs;
+int audio0_plan_create(Audio0Plan** out, const float* weight /*[32][1][3][3]*/, const float* scale, const float* shift, std::string* err);
+void audio0_plan_destroy(Audio0Plan* p);
+// `mels`: DEVICE table of per-frame float32 [80][16] windows
+int audio0_launch(const Audio0Plan* p, const MelPtrs* mels, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err);
+
 }  // namespace ltk

@@ -329,6 +329,7 @@ struct ltk_engine {
     size_t buf_halfs[B_COUNT] = {0};  // per frame
     float* d_head = nullptr;          // 96 weights + 3 bias
     Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
+    Audio0Plan* a0 = nullptr;         // audio_encoder.0 (3x3, 1 -> 32) with the mel pack fused (VALU): conv7_mfma.hip, knob AUDIO0
     double macs_per_frame = 0;
     DevTables* d_tab = nullptr;       // per-frame pointer tables of the pass being enqueued (misc_kernels.h), filled on the compute stream
     // captured passes (knob GRAPH): one executable graph per frame count of the product configuration (bank crops in, fused head out);
@@ -568,6 +569,10 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
         rc = conv7_plan_create(&e->c7, w, sc.data(), sf.data(), &err);
         if (rc) return fail(LTK_E_HIP, p + ": " + err);
     }
+    if (!d.transposed && d.k == 3 && d.cin == 1 && d.cout == 32 && d.sh == 1 && d.sw == 1 && d.pad == 1 && !d.residual && knob(K_AUDIO0) && !e->a0) {
+        rc = audio0_plan_create(&e->a0, w, sc.data(), sf.data(), &err);
+        if (rc) return fail(LTK_E_HIP, p + ": " + err);
+    }
     L->name = p;
     L->cin_real = d.cin;
     L->residual = d.residual;
@@ -629,6 +634,8 @@ void wav2lip_unload(ltk_engine* e) {
     if (e->d_head) { (void)hipFree(e->d_head); e->d_head = nullptr; }
     conv7_plan_destroy(e->c7);
     e->c7 = nullptr;
+    audio0_plan_destroy(e->a0);
+    e->a0 = nullptr;
     e->loaded = false;
 }
 
@@ -821,6 +828,8 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
             rc = conv7_launch(e->c7, faces ? reinterpret_cast<const FacePtrs*>(reinterpret_cast<const uint8_t* const*>(faces) + f0) : nullptr,
                               B(B_X0) + (size_t)f0 * 65536 * 8, n, io.y, L.out_ld, L.out_coff, s, &err);
+        else if (e->a0 && knob(K_AUDIO0) && L.in_buf == B_MEL)  // audio_encoder.0: reads the float32 mel windows of the pass's table itself
+            rc = audio0_launch(e->a0, reinterpret_cast<const MelPtrs*>(e->d_tab->mels.p + f0), n, io.y, L.out_ld, L.out_coff, on_aux ? e->aux : s, &err);
         // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
         // output element whatever the launch's frame count (larger launches run these layers on conv3)
         else if (L.rowconv && L.rg.d_w && (long long)n * L.Ho * L.Wo <= std::min(knob(K_ROWCONV), kRowConvMaxRows) && knob(K_SPLITK) &&
@@ -1178,7 +1187,7 @@ static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, c
     else if (have_feats) {}
     else if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
-    launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);
+    if (!(e->a0 && knob(K_AUDIO0))) launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);     // (audio0_kernel reads the windows itself)
     const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, (pack_fused && !cached && !have_feats) ? d_faces : nullptr,
                              (cached || have_feats) ? 2 : 0, par);
     if (rc) return rc;
