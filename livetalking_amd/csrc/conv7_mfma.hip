@@ -194,14 +194,18 @@ int conv7_launch(const Conv7Plan* p, const FacePtrs* faces, const f16* x0, int N
 // a 16-frame call's dependent chain (the audio encoder heads the critical path under knob PREFETCH) and 10 + 243 us at 256 frames, for
 // 5.9 MFLOP per 16 frames.  As VALU work it is 288 fma per pixel: a thread owns one pixel and all 32 output channels, reads its 3 x 3
 // neighbourhood from the frame's float32 window (rounded to fp16 exactly as the pack did, so the operands are the MFMA path's operands),
-// takes the fp16-rounded weights, the BN scale and shift as wave-uniform scalar loads (constant indices after unrolling: no LDS, no
-// vector loads) and stores the two 32-byte CB16 cells of its pixel.  fp32 products of fp16 operands are exact; the nine-term fp32 sum
+// takes the fp16-rounded weights, the BN scale and shift (352 floats: one coalesced load into LDS, then broadcast ds_read_b128; as
+// wave-uniform scalar loads they were a chain of 27 s_load round trips, 10.4 us for the launch in profiles' first timeline) and stores
+// the two 32-byte CB16 cells of its pixel.  fp32 products of fp16 operands are exact; the nine-term fp32 sum
 // differs from the MFMA's in summation order only.
 __global__ __launch_bounds__(256) void audio0_kernel(const MelPtrs* __restrict__ mel, const float* __restrict__ wsf, f16* __restrict__ y,
                                                      const int y_cbt, const int y_cb0) {
+    __shared__ __attribute__((aligned(16))) float sw[352];
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;          // pixel of the 80 x 16 map (5 blocks x 256 threads = 1280)
-    const float* __restrict__ m = mel->p[f];
+    const float4 wv = reinterpret_cast<const float4*>(wsf)[min((int)threadIdx.x, 87)];      // (written to LDS behind the mel loads' issue)
+    // (a global-address-space pointer and unconditional loads at clamped indices: nine loads in flight instead of nine flat-load round trips)
+    const float __attribute__((address_space(1)))* const m = (const float __attribute__((address_space(1)))*)mel->p[f];
     const int r = i >> 4, c = i & 15;
     float v[9];
 #pragma unroll
@@ -209,9 +213,18 @@ __global__ __launch_bounds__(256) void audio0_kernel(const MelPtrs* __restrict__
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int rr = r + ky - 1, cc = c + kx - 1;
-            const bool in = rr >= 0 && rr < 80 && cc >= 0 && cc < 16;
-            v[ky * 3 + kx] = in ? (float)(f16)m[in ? rr * 16 + cc : 0] : 0.f;
+            v[ky * 3 + kx] = m[min(max(rr, 0), 79) * 16 + min(max(cc, 0), 15)];
         }
+    if (threadIdx.x < 88) reinterpret_cast<float4*>(sw)[threadIdx.x] = wv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int rr = r + ky - 1, cc = c + kx - 1;
+            const bool in = rr >= 0 && rr < 80 && cc >= 0 && cc < 16;
+            v[ky * 3 + kx] = in ? (float)(f16)v[ky * 3 + kx] : 0.f;
+        }
+    __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         f16* const yp = y + (((size_t)f * y_cbt + y_cb0 + cb) * 1280 + i) * 16;
@@ -223,8 +236,8 @@ __global__ __launch_bounds__(256) void audio0_kernel(const MelPtrs* __restrict__
                 const int co = cb * 16 + h * 8 + q;
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wsf[co * 9 + t], acc);
-                o[q] = (f16)__builtin_amdgcn_fmed3f(fmaf(acc, wsf[288 + co], wsf[320 + co]), 0.f, 65504.f);
+                for (int t = 0; t < 9; ++t) acc = fmaf(v[t], sw[co * 9 + t], acc);
+                o[q] = (f16)__builtin_amdgcn_fmed3f(fmaf(acc, sw[288 + co], sw[320 + co]), 0.f, 65504.f);
             }
             *reinterpret_cast<f16x8*>(yp + h * 8) = o;
         }
