@@ -278,4 +278,119 @@ int audio0_launch(const Audio0Plan* p, const MelPtrs* mels, int N, f16* y, int y
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ audio3
+// audio_encoder.3: Conv2d(32, 64, 3, stride (3, 1), pad 1) + BN + ReLU, 80 x 16 -> 27 x 16 (wav2lip_v2.py:46, conv.py:5-19).
+//
+// The only stride-(3, 1) layer of the network ran on the first-generation kernel: 64 blocks, each staging a 48-row patch through its
+// registers in two chunks - 15.4 us of a 16-frame call's head for 0.25 GFLOP.  Its output rows read DISJOINT input row triples, so a
+// patch in LDS shares nothing but the three columns of a tap row.  Here a WAVE owns 32 consecutive output pixels (over all frames) and
+// all 64 output channels, and feeds v_mfma_f32_32x32x16_f16 straight from global memory: the pixel operand of tap (ky, kx) and channel
+// block cb is ONE 16-byte load per lane (lane & 31 = pixel, lane >> 5 = which 8 of the block's 16 channels; zero outside the map), the
+// weight operand one 16-byte load per lane from a host-packed [cout tile][tap][cb][lane] image (1 KB per wave and MFMA, L2 resident):
+// 18 + 36 independent loads and 36 MFMAs per wave, no LDS, no barrier; one-wave blocks, 216 of them at 16 frames.  Two variants
+// with v_dot2_f32_f16 on the VALU were slower than the MFMA launch they replaced (profiles/r06_audio0_ab.txt).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void audio3_kernel(const f16* __restrict__ x, const int x_cbt, const int x_cb0, const int npix_total,
+                                                    const f16x8* __restrict__ wq, const float* __restrict__ ss, f16* __restrict__ y,
+                                                    const int y_cbt, const int y_cb0) {
+    const int lane = threadIdx.x, l31 = lane & 31, kh = lane >> 5;
+    const int Pr = blockIdx.x * 32 + l31;                  // output pixel over all frames (432 per frame)
+    const bool live = Pr < npix_total;
+    const int P = live ? Pr : npix_total - 1;
+    const int f = P / 432, p = P - f * 432;
+    const int oy = p >> 4, ox = p & 15;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nt][v] = 0.f;
+    const f16x8 zero = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    // all 18 + 36 operand loads in flight before the first MFMA (216 VGPRs; left to itself the compiler pairs every few loads with their
+    // MFMAs: nine serial round trips, as slow as the launch this kernel replaces)
+    f16x8 bv[18], av[36];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 3 * oy - 1 + t / 3, ix = ox - 1 + t % 3;      // iy <= 79 always
+        const bool in = iy >= 0 && ix >= 0 && ix < 16;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + ((((size_t)f * x_cbt + x_cb0 + cb) * 80 + (in ? iy : 0)) * 16 + (in ? ix : 0)) * 16 + 8 * kh);
+            bv[t * 2 + cb] = in ? xv : zero;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) av[k] = wq[k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[(nt * 9 + t) * 2 + cb], bv[t * 2 + cb], acc[nt], 0, 0, 0);
+    // accumulator v of a lane: output channel 32 nt + 8 (v / 4) + 4 kh + (v % 4) of pixel l31
+    if (live) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = 32 * nt + 8 * q + 4 * kh;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + co), sf = *reinterpret_cast<const f32x4*>(ss + 64 + co);
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)__builtin_amdgcn_fmed3f(fmaf(acc[nt][4 * q + r], sc[r], sf[r]), 0.f, 65504.f);
+                *reinterpret_cast<f16x4*>(y + ((((size_t)f * y_cbt + y_cb0 + (co >> 4)) * 432 + p) * 16 + (co & 15))) = o;
+            }
+    }
+}
+
+struct Audio3Plan {
+    f16x8* d_wq = nullptr;         // [2 cout tiles][9 taps][2 channel blocks][64 lanes] x 8 halfs: the A operand of every MFMA
+    float* d_ss = nullptr;         // [64] scale, [64] shift
+};
+
+int audio3_plan_create(Audio3Plan** out, const float* weight /*[64][32][3][3]*/, const float* scale, const float* shift, std::string* err) {
+    std::vector<f16> wq((size_t)2 * 9 * 2 * 64 * 8);
+    for (int nt = 0; nt < 2; ++nt)
+        for (int t = 0; t < 9; ++t)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * nt + (lane & 31), ci = 16 * cb + 8 * (lane >> 5) + j;
+                        wq[((((size_t)nt * 9 + t) * 2 + cb) * 64 + lane) * 8 + j] = (f16)weight[((size_t)co * 32 + ci) * 9 + t];
+                    }
+    std::vector<float> ss(128);
+    for (int co = 0; co < 64; ++co) { ss[co] = scale[co]; ss[64 + co] = shift[co]; }
+    Audio3Plan* p = new Audio3Plan();
+    if (hipMalloc((void**)&p->d_wq, wq.size() * sizeof(f16)) != hipSuccess || hipMalloc((void**)&p->d_ss, ss.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->d_wq, wq.data(), wq.size() * sizeof(f16), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (p->d_wq) (void)hipFree(p->d_wq);
+        if (p->d_ss) (void)hipFree(p->d_ss);
+        delete p;
+        if (err) *err = "audio3: allocation / upload failed";
+        return -2;
+    }
+    *out = p;
+    return 0;
+}
+
+void audio3_plan_destroy(Audio3Plan* p) {
+    if (!p) return;
+    if (p->d_wq) (void)hipFree(p->d_wq);
+    if (p->d_ss) (void)hipFree(p->d_ss);
+    delete p;
+}
+
+// x: [N][x_ld / 16][80][16][16] (channels [x_coff, x_coff + 32)), y: [N][y_ld / 16][27][16][16] (channels [y_coff, y_coff + 64))
+int audio3_launch(const Audio3Plan* p, const f16* x, int x_ld, int x_coff, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err) {
+    if (!p || !x || !y || N <= 0 || N > kPackMaxFrames || ((x_ld | x_coff | y_ld | y_coff) & 15)) { if (err) *err = "audio3: bad arguments"; return -1; }
+    const int npix = N * 432;
+    hipLaunchKernelGGL(audio3_kernel, dim3((npix + 31) / 32), dim3(64), 0, stream, x, x_ld >> 4, x_coff >> 4, npix, p->d_wq, p->d_ss, y,
+                       y_ld >> 4, y_coff >> 4);
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "audio3: launch failed"; return -2; }
+    return 0;
+}
+
 }  // namespace ltk

@@ -213,5 +213,10 @@ int audio0_plan_create(Audio0Plan** out, const float* weight /*[32][1][3][3]*/, 
 void audio0_plan_destroy(Audio0Plan* p);
 // `mels`: DEVICE table of per-frame float32 [80][16] windows
 int audio0_launch(const Audio0Plan* p, const MelPtrs* mels, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err);
+// ... and its stride-(3, 1) layer audio_encoder.3 (Conv2d(32,64,3,(3,1),1) + BN + ReLU, 80 x 16 -> 27 x 16): one-wave blocks, MFMA operands loaded straight from global memory (knob AUDIO0 bit 1)
+struct Audio3Plan;
+int audio3_plan_create(Audio3Plan** out, const float* weight /*[64][32][3][3]*/, const float* scale, const float* shift, std::string* err);
+void audio3_plan_destroy(Audio3Plan* p);
+int audio3_launch(const Audio3Plan* p, const f16* x, int x_ld, int x_coff, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err);
 
 }  // namespace ltk

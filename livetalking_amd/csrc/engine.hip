@@ -143,6 +143,7 @@ struct Layer {
     bool residual = false;
     bool res_folded = false;   // the identity branch lives in the centre tap of the packed weights
     bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
+    int special = 0;      // 3: audio_encoder.3, which has a kernel of its own (audio3_kernel, knob AUDIO0 bit 1)
     bool face_enc = false;   // face-encoder layer: depends on the bank frame only (knob FACE_CACHE)
     double macs = 0;  // per frame
     // measured tile / split choice per frame-count bucket (<= 16, 32, 64, 128, 256+ frames per launch); 0 = conv3's rule
@@ -329,7 +330,8 @@ struct ltk_engine {
     size_t buf_halfs[B_COUNT] = {0};  // per frame
     float* d_head = nullptr;          // 96 weights + 3 bias
     Conv7Plan* c7 = nullptr;          // first layer (7x7, 6 -> 16) with the input pack fused: conv7_mfma.hip
-    Audio0Plan* a0 = nullptr;         // audio_encoder.0 (3x3, 1 -> 32) with the mel pack fused (VALU): conv7_mfma.hip, knob AUDIO0
+    Audio0Plan* a0 = nullptr;         // audio_encoder.0 (3x3, 1 -> 32) with the mel pack fused (VALU): conv7_mfma.hip, knob AUDIO0 bit 0
+    Audio3Plan* a3 = nullptr;         // audio_encoder.3 (3x3 stride (3,1), 32 -> 64), MFMA operands straight from global memory: conv7_mfma.hip, knob AUDIO0 bit 1
     double macs_per_frame = 0;
     DevTables* d_tab = nullptr;       // per-frame pointer tables of the pass being enqueued (misc_kernels.h), filled on the compute stream
     // captured passes (knob GRAPH): one executable graph per frame count of the product configuration (bank crops in, fused head out);
@@ -569,9 +571,14 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
         rc = conv7_plan_create(&e->c7, w, sc.data(), sf.data(), &err);
         if (rc) return fail(LTK_E_HIP, p + ": " + err);
     }
-    if (!d.transposed && d.k == 3 && d.cin == 1 && d.cout == 32 && d.sh == 1 && d.sw == 1 && d.pad == 1 && !d.residual && knob(K_AUDIO0) && !e->a0) {
+    if (!d.transposed && d.k == 3 && d.cin == 1 && d.cout == 32 && d.sh == 1 && d.sw == 1 && d.pad == 1 && !d.residual && (knob(K_AUDIO0) & 1) && !e->a0) {
         rc = audio0_plan_create(&e->a0, w, sc.data(), sf.data(), &err);
         if (rc) return fail(LTK_E_HIP, p + ": " + err);
+    }
+    if (!d.transposed && d.k == 3 && d.cin == 32 && d.cout == 64 && d.sh == 3 && d.sw == 1 && d.pad == 1 && !d.residual && (knob(K_AUDIO0) & 2) && !e->a3) {
+        rc = audio3_plan_create(&e->a3, w, sc.data(), sf.data(), &err);
+        if (rc) return fail(LTK_E_HIP, p + ": " + err);
+        L->special = 3;
     }
     L->name = p;
     L->cin_real = d.cin;
@@ -636,6 +643,8 @@ void wav2lip_unload(ltk_engine* e) {
     e->c7 = nullptr;
     audio0_plan_destroy(e->a0);
     e->a0 = nullptr;
+    audio3_plan_destroy(e->a3);
+    e->a3 = nullptr;
     e->loaded = false;
 }
 
@@ -828,7 +837,9 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
             rc = conv7_launch(e->c7, faces ? reinterpret_cast<const FacePtrs*>(reinterpret_cast<const uint8_t* const*>(faces) + f0) : nullptr,
                               B(B_X0) + (size_t)f0 * 65536 * 8, n, io.y, L.out_ld, L.out_coff, s, &err);
-        else if (e->a0 && knob(K_AUDIO0) && L.in_buf == B_MEL)  // audio_encoder.0: reads the float32 mel windows of the pass's table itself
+        else if (e->a3 && (knob(K_AUDIO0) & 2) && L.special == 3 && L.H == 80 && L.W == 16)      // audio_encoder.3
+            rc = audio3_launch(e->a3, io.x, L.in_ld, L.in_coff, n, io.y, L.out_ld, L.out_coff, on_aux ? e->aux : s, &err);
+        else if (e->a0 && (knob(K_AUDIO0) & 1) && L.in_buf == B_MEL)  // audio_encoder.0: reads the float32 mel windows of the pass's table itself
             rc = audio0_launch(e->a0, reinterpret_cast<const MelPtrs*>(e->d_tab->mels.p + f0), n, io.y, L.out_ld, L.out_coff, on_aux ? e->aux : s, &err);
         // one-pixel maps: a skinny GEMM, no split-K finish launch.  Not under LTK_SPLITK=0, whose promise is ONE summation order per
         // output element whatever the launch's frame count (larger launches run these layers on conv3)
@@ -1187,7 +1198,7 @@ static int enqueue_pass(ltk_engine* e, int nf, hipStream_t s, bool bank_faces, c
     else if (have_feats) {}
     else if (bank_faces) { if (!pack_fused) launch_pack_faces(d_faces, nf, e->buf[B_X0], s); }
     else launch_pack_face6_nchw(d_face6, nf, e->buf[B_X0], s);
-    if (!(e->a0 && knob(K_AUDIO0))) launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);     // (audio0_kernel reads the windows itself)
+    if (!(e->a0 && (knob(K_AUDIO0) & 1))) launch_pack_mel(&e->d_tab->mels, nf, e->buf[B_MEL], s);     // (audio0_kernel reads the windows itself)
     const int rc = run_convs(e, nf, s, fused ? d_outs : nullptr, nullptr, (pack_fused && !cached && !have_feats) ? d_faces : nullptr,
                              (cached || have_feats) ? 2 : 0, par);
     if (rc) return rc;

@@ -89,8 +89,9 @@ enum Knob {
                           //                    (conv3_lin_mp_nsl); 2 / 3: always, with that many slabs per block; 0: conv3 / rowconv
     K_GN_COOP,            // LTK_GN_COOP        1 (default): GroupNorm of the maps too large for MT_GN1 (the VAE's 64^2 .. 256^2 maps) in ONE tensor pass: blocks keep their
                           //                    slice in registers and exchange partial sums through global memory (nn_kernels.hip gn_coop_kernel); 0: gn_stats + gn_apply
-    K_AUDIO0,             // LTK_AUDIO0         1 (default): audio_encoder.0 (1 -> 32 channels on the 80 x 16 mel window) as a VALU kernel that reads the float32 mel
-                          //                    windows itself (conv7_mfma.hip audio0_kernel: no pack_mel launch, no 8-channel padded MFMA launch); 0: pack_mel + conv_mfma
+    K_AUDIO0,             // LTK_AUDIO0         bit 0: audio_encoder.0 (1 -> 32 channels on the 80 x 16 mel window) as a VALU kernel that reads the float32 mel
+                          //                    windows itself (conv7_mfma.hip audio0_kernel: no pack_mel launch, no 8-channel padded MFMA launch); bit 1: the
+                          //                    stride-(3, 1) layer audio_encoder.3 on MFMAs fed straight from global memory (audio3_kernel); default 3; 0: pack_mel + conv_mfma_kernel
     K_COUNT
 };
 

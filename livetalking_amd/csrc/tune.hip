@@ -50,7 +50,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_ATTN_LDS", 1},
     {"LTK_LIN_MP", 1},
     {"LTK_GN_COOP", 1},
-    {"LTK_AUDIO0", 1},
+    {"LTK_AUDIO0", 3},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table

@@ -141,11 +141,11 @@ def test_infer_batching_invariance(engine, golden_dir):
 
 
 @pytest.mark.gpu
-def test_audio0_kernel_vs_generic_first_layer(engine, golden_dir):
-    """audio_encoder.0 (Conv2d(1, 32, 3, 1, 1) + BN + ReLU, wav2lip_v2.py:42) as the VALU kernel that reads the float32 mel windows itself
-    (knob AUDIO0, the default: conv7_mfma.hip audio0_kernel) against pack_mel + the generic MFMA launch: same fp16 operands, fp32 sums in
-    another order - the layer's tap holds the oracle's to the per-layer tolerance either way, and the frames of a call differ by at most
-    1 LSB (1-, 7- and 16-frame calls: one block row per frame, whatever the count)."""
+def test_audio_first_layers_vs_generic_path(engine, golden_dir):
+    """Knob AUDIO0 (default 3, conv7_mfma.hip).  Bit 0: audio_encoder.0 (Conv2d(1, 32, 3, 1, 1) + BN + ReLU, wav2lip_v2.py:42) as the VALU kernel
+    that reads the float32 mel windows itself; bit 1: the stride-(3, 1) layer audio_encoder.3 (wav2lip_v2.py:46) as one-wave blocks whose MFMA operands come straight from global memory.  Against
+    pack_mel + the generic MFMA launches: same fp16 operands, fp32 sums in another order - each layer's tap holds the oracle's to the
+    per-layer tolerance either way, and the frames of a call differ by at most 1 LSB (1-, 7- and 16-frame calls)."""
     from livetalking_amd.engine import Engine
     g, frames, faces, coords, feats = _golden_inputs(golden_dir)
     B, index = int(g["batch"]), int(g["index"])
@@ -153,21 +153,23 @@ def test_audio0_kernel_vs_generic_first_layer(engine, golden_dir):
     mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, feats)
     taps = {}
     wav2lip_oracle.forward(sd, mel_t, img_t, taps)
-    r = taps["audio_encoder.0"].numpy()
     rel = {}
     try:
-        for on in (1, 0):
+        for on in (3, 0):
             Engine.set_knob("AUDIO0", on)
             engine.debug_capture(True)
             engine.wav2lip_forward_host(mel_t.numpy().reshape(B, 80, 16), img_t.numpy())
-            o = engine.debug_get("audio_encoder.0", r.shape)
+            for name in ("audio_encoder.0", "audio_encoder.3", "audio_encoder.12"):
+                r = taps[name].numpy()
+                o = engine.debug_get(name, r.shape)
+                rel[on, name] = float(np.linalg.norm(o - r) / np.linalg.norm(r))
+                print(f"[audio0={on}] {name} rel_l2={rel[on, name]:.3e} maxabs={float(np.abs(o - r).max()):.3e}")
             engine.debug_capture(False)
-            rel[on] = float(np.linalg.norm(o - r) / np.linalg.norm(r))
-            print(f"[audio0={on}] audio_encoder.0 rel_l2={rel[on]:.3e} maxabs={float(np.abs(o - r).max()):.3e}")
     finally:
         engine.debug_capture(False)
-        Engine.set_knob("AUDIO0", 1)
-    assert rel[1] <= 2e-3 and rel[1] <= rel[0] * 1.5 + 1e-5
+        Engine.set_knob("AUDIO0", 3)
+    for name in ("audio_encoder.0", "audio_encoder.3", "audio_encoder.12"):
+        assert rel[3, name] <= 2e-3 and rel[3, name] <= rel[0, name] * 1.5 + 1e-5, name
     aid = engine.register_avatar(faces, frames, coords)
     rng = np.random.default_rng(7)
     try:
@@ -175,18 +177,19 @@ def test_audio0_kernel_vs_generic_first_layer(engine, golden_dir):
             mel = torch.from_numpy((np.stack([feats[i % len(feats)] for i in range(n)]) +
                                     0.05 * rng.standard_normal((n, 80, 16))).astype(np.float32)).cuda()
             out = {}
-            for on in (1, 0):
+            for on in (3, 1, 0):
                 Engine.set_knob("AUDIO0", on)
                 pred = torch.zeros(n, 256, 256, 3, dtype=torch.uint8, device="cuda")
                 engine.wav2lip_infer([(aid, index, n, mel.data_ptr(), pred.data_ptr())])
                 out[on] = pred.cpu().numpy()
-            d = np.abs(out[1].astype(np.int32) - out[0].astype(np.int32))
-            print(f"[audio0, {n} frames] max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
-            # (a last-bit change in the FIRST layer reaches every pixel through the audio embedding: as many truncation flips as the
-            # rowconv / rowgemm-vs-conv3 comparison below sees)
-            assert d.max() <= 1 and float((d != 0).mean()) < 0.10
+            for on in (3, 1):
+                d = np.abs(out[on].astype(np.int32) - out[0].astype(np.int32))
+                print(f"[audio0={on} vs 0, {n} frames] max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
+                # (a last-bit change in the first layers reaches every pixel through the audio embedding: as many truncation flips as the
+                # rowconv / rowgemm-vs-conv3 comparison below sees)
+                assert d.max() <= 1 and float((d != 0).mean()) < 0.10
     finally:
-        Engine.set_knob("AUDIO0", 1)
+        Engine.set_knob("AUDIO0", 3)
         engine.release_avatar(aid)
 
 
