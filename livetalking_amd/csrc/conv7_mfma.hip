@@ -393,4 +393,127 @@ int audio3_launch(const Audio3Plan* p, const f16* x, int x_ld, int x_coff, int N
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ convs2d
+// The shallow stride-2 layers of the face encoder, face_encoder_blocks.1.0 (16 -> 32, 256^2 -> 128^2) and 2.0 (32 -> 64, 128^2 -> 64^2)
+// (wav2lip_v2.py:15,19: Conv2d(k3, s2, p1) + BN + ReLU), the last Wav2Lip layers on the first-generation kernel: K = 9 x 16 / 9 x 32 is
+// one or two 16-channel chunks, so an LDS-staged tile pays a patch copy and two barriers for 9 - 18 MFMAs per wave - 251 + 198 us of a
+// 256-frame pass at 0.15 PFLOP/s, and every LDS route off that kernel measured slower (rounds 3, 4, 6).  Same idea as audio3_kernel: no
+// LDS.  A wave owns one output row of one frame and one 32-channel tile of the output channels; its 9 x CB weight operands stay in
+// registers for the whole row; per 32-pixel tile of the row the pixel operand of (tap, channel block) is one 16-byte load per lane
+// (lane & 31 = pixel, lane >> 5 = which 8 of the block's 16 channels; the 2.25x tap redundancy of a stride-2 3x3 window is served by the
+// vector L1, which is what bounds the kernel), all 9 x CB loads in flight before the first MFMA; the other waves of the SIMD hide the
+// round trip.  Same fp16 operands and fp32 accumulation as the generic route, another summation order.
+template <int CB>
+__global__ __launch_bounds__(256) void convs2d_kernel(const f16* __restrict__ x, const int x_cbt, const int x_cb0, const int H, const int W,
+                                                      const int ntasks, const int NT, const f16x8* __restrict__ wq, const float* __restrict__ ss,
+                                                      const int Cout, f16* __restrict__ y, const int y_cbt, const int y_cb0) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);      // (frame, output row, cout tile)
+    if (task >= ntasks) return;                                 // (no barriers below)
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int nt = task % NT, row = task / NT, f = row / Ho, oy = row - f * Ho;
+    f16x8 av[9 * CB];
+#pragma unroll
+    for (int k = 0; k < 9 * CB; ++k) av[k] = wq[(nt * 9 * CB + k) * 64 + lane];
+    f32x4 sc[4], sf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const f32x4*>(ss + 32 * nt + 8 * q + 4 * kh);
+        sf[q] = *reinterpret_cast<const f32x4*>(ss + Cout + 32 * nt + 8 * q + 4 * kh);
+    }
+    const f16x8 zero = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    const size_t HW = (size_t)H * W;
+    const f16* const xf = x + ((size_t)f * x_cbt + x_cb0) * HW * 16 + 8 * kh;
+    f16* const yf = y + (((size_t)f * y_cbt + y_cb0 + 2 * nt) * Ho + oy) * Wo * 16 + 4 * kh;
+    for (int ox0 = 0; ox0 < Wo; ox0 += 32) {
+        const int ox = ox0 + l31;
+        f16x8 bv[9 * CB];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;      // iy <= H - 1, ix <= W - 1 always
+            const bool in = iy >= 0 && ix >= 0;
+            const f16* const px = xf + ((size_t)(in ? iy : 0) * W + (in ? ix : 0)) * 16;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f16x8 xv = *reinterpret_cast<const f16x8*>(px + cb * HW * 16);
+                bv[t * CB + cb] = in ? xv : zero;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9 * CB; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[k], bv[k], acc, 0, 0, 0);
+        // accumulator v of a lane: output channel 32 nt + 8 (v / 4) + 4 kh + (v % 4) of pixel ox
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)__builtin_amdgcn_fmed3f(fmaf(acc[4 * q + r], sc[q][r], sf[q][r]), 0.f, 65504.f);
+            *reinterpret_cast<f16x4*>(yf + ((size_t)(q >> 1) * Ho * Wo + ox) * 16 + 8 * (q & 1)) = o;
+        }
+    }
+}
+
+struct ConvS2dPlan {
+    f16x8* d_wq = nullptr;         // [Cout / 32][9 taps][Cin / 16][64 lanes] x 8 halfs: the weight operand of every MFMA
+    float* d_ss = nullptr;         // [Cout] scale, [Cout] shift
+    int Cin = 0, Cout = 0;
+};
+
+int convs2d_plan_create(ConvS2dPlan** out, const float* weight /*[Cout][Cin][3][3]*/, int Cin, int Cout, const float* scale, const float* shift,
+                        std::string* err) {
+    if (!(Cin == 16 || Cin == 32) || Cout % 32 || Cout <= 0) { if (err) *err = "convs2d: 16 or 32 input channels, output channels in tiles of 32"; return -1; }
+    const int CB = Cin / 16, NT = Cout / 32;
+    std::vector<f16> wq((size_t)NT * 9 * CB * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int t = 0; t < 9; ++t)
+            for (int cb = 0; cb < CB; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * nt + (lane & 31), ci = 16 * cb + 8 * (lane >> 5) + j;
+                        wq[((((size_t)nt * 9 + t) * CB + cb) * 64 + lane) * 8 + j] = (f16)weight[((size_t)co * Cin + ci) * 9 + t];
+                    }
+    std::vector<float> ss((size_t)2 * Cout);
+    for (int co = 0; co < Cout; ++co) { ss[co] = scale[co]; ss[Cout + co] = shift[co]; }
+    ConvS2dPlan* p = new ConvS2dPlan();
+    p->Cin = Cin; p->Cout = Cout;
+    if (hipMalloc((void**)&p->d_wq, wq.size() * sizeof(f16)) != hipSuccess || hipMalloc((void**)&p->d_ss, ss.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->d_wq, wq.data(), wq.size() * sizeof(f16), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (p->d_wq) (void)hipFree(p->d_wq);
+        if (p->d_ss) (void)hipFree(p->d_ss);
+        delete p;
+        if (err) *err = "convs2d: allocation / upload failed";
+        return -2;
+    }
+    *out = p;
+    return 0;
+}
+
+void convs2d_plan_destroy(ConvS2dPlan* p) {
+    if (!p) return;
+    if (p->d_wq) (void)hipFree(p->d_wq);
+    if (p->d_ss) (void)hipFree(p->d_ss);
+    delete p;
+}
+
+// x: [N][x_ld / 16][H][W][16] (channels [x_coff, x_coff + Cin)), y: [N][y_ld / 16][H / 2][W / 2][16] (channels [y_coff, y_coff + Cout)); H, W even, W / 2 a
+// multiple of 32
+int convs2d_launch(const ConvS2dPlan* p, const f16* x, int x_ld, int x_coff, int N, int H, int W, f16* y, int y_ld, int y_coff, hipStream_t stream,
+                   std::string* err) {
+    if (!p || !x || !y || N <= 0 || H <= 0 || (H & 1) || W <= 0 || (W & 63) || ((x_ld | x_coff | y_ld | y_coff) & 15)) { if (err) *err = "convs2d: bad arguments"; return -1; }
+    const int NT = p->Cout / 32;
+    const long long ntasks = (long long)N * (H / 2) * NT;
+    if (ntasks > (1ll << 30)) { if (err) *err = "convs2d: launch too large"; return -1; }
+    const dim3 grid((unsigned)((ntasks + 3) / 4));
+    if (p->Cin == 16)
+        hipLaunchKernelGGL(convs2d_kernel<1>, grid, dim3(256), 0, stream, x, x_ld >> 4, x_coff >> 4, H, W, (int)ntasks, NT, p->d_wq, p->d_ss, p->Cout, y, y_ld >> 4, y_coff >> 4);
+    else
+        hipLaunchKernelGGL(convs2d_kernel<2>, grid, dim3(256), 0, stream, x, x_ld >> 4, x_coff >> 4, H, W, (int)ntasks, NT, p->d_wq, p->d_ss, p->Cout, y, y_ld >> 4, y_coff >> 4);
+    if (hipGetLastError() != hipSuccess) { if (err) *err = "convs2d: launch failed"; return -2; }
+    return 0;
+}
+
 }  // namespace ltk

@@ -218,5 +218,11 @@ struct Audio3Plan;
 int audio3_plan_create(Audio3Plan** out, const float* weight /*[64][32][3][3]*/, const float* scale, const float* shift, std::string* err);
 void audio3_plan_destroy(Audio3Plan* p);
 int audio3_launch(const Audio3Plan* p, const f16* x, int x_ld, int x_coff, int N, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err);
+// ... and the face encoder's shallow stride-2 layers (Conv2d(16 / 32 -> Cout, 3, 2, 1) + BN + ReLU) the same way: a wave = one output row x 32 output
+// channels, weights in registers, pixel operands straight from global memory (knob CONV_S2D)
+struct ConvS2dPlan;
+int convs2d_plan_create(ConvS2dPlan** out, const float* weight /*[Cout][Cin][3][3]*/, int Cin, int Cout, const float* scale, const float* shift, std::string* err);
+void convs2d_plan_destroy(ConvS2dPlan* p);
+int convs2d_launch(const ConvS2dPlan* p, const f16* x, int x_ld, int x_coff, int N, int H, int W, f16* y, int y_ld, int y_coff, hipStream_t stream, std::string* err);
 
 }  // namespace ltk

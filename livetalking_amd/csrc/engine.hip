@@ -144,6 +144,7 @@ struct Layer {
     bool res_folded = false;   // the identity branch lives in the centre tap of the packed weights
     bool audio = false;   // audio-encoder layer (independent of the face encoder until decoder block 0)
     int special = 0;      // 3: audio_encoder.3, which has a kernel of its own (audio3_kernel, knob AUDIO0 bit 1)
+    ConvS2dPlan* s2d = nullptr;   // face_encoder_blocks.1.0 / 2.0: the shallow stride-2 layers on convs2d_kernel (conv7_mfma.hip, knob CONV_S2D)
     bool face_enc = false;   // face-encoder layer: depends on the bank frame only (knob FACE_CACHE)
     double macs = 0;  // per frame
     // measured tile / split choice per frame-count bucket (<= 16, 32, 64, 128, 256+ frames per launch); 0 = conv3's rule
@@ -580,6 +581,11 @@ int build_layer_impl(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* s
         if (rc) return fail(LTK_E_HIP, p + ": " + err);
         L->special = 3;
     }
+    if (!d.transposed && d.k == 3 && d.sh == 2 && d.sw == 2 && d.pad == 1 && !d.residual && (d.cin == 16 || d.cin == 32) && d.cout % 32 == 0 &&
+        knob(K_CONV_S2D) && !L->s2d) {
+        rc = convs2d_plan_create(&L->s2d, w, d.cin, d.cout, sc.data(), sf.data(), &err);
+        if (rc) return fail(rc == -2 ? LTK_E_HIP : LTK_E_INVALID, p + ": " + err);
+    }
     L->name = p;
     L->cin_real = d.cin;
     L->residual = d.residual;
@@ -594,6 +600,7 @@ int build_layer(ltk_engine* e, const LayerDef& d, const ltk_named_tensor* sd, in
     if (rc) {
         conv_plan_destroy(&L->plan); rowgemm_plan_destroy(&L->rg);
         for (RowGemmPlan& q : L->rgT) rowgemm_plan_destroy(&q);
+        convs2d_plan_destroy(L->s2d); L->s2d = nullptr;
     }
     return rc;
 }
@@ -622,6 +629,7 @@ void wav2lip_unload(ltk_engine* e) {
     for (Layer& L : e->layers) {
         conv_plan_destroy(&L.plan); rowgemm_plan_destroy(&L.rg);
         for (RowGemmPlan& q : L.rgT) rowgemm_plan_destroy(&q);
+        convs2d_plan_destroy(L.s2d); L.s2d = nullptr;
     }
     e->layers.clear();
     for (int i = 0; i < B_COUNT; ++i) {
@@ -837,6 +845,8 @@ int run_convs(ltk_engine* e, int nf, hipStream_t s, const OutPtrs* head_outs = n
         if (e->c7 && knob(K_CONV7) && L.in_buf == B_X0)       // face_encoder_blocks.0.0
             rc = conv7_launch(e->c7, faces ? reinterpret_cast<const FacePtrs*>(reinterpret_cast<const uint8_t* const*>(faces) + f0) : nullptr,
                               B(B_X0) + (size_t)f0 * 65536 * 8, n, io.y, L.out_ld, L.out_coff, s, &err);
+        else if (L.s2d && knob(K_CONV_S2D) && !(L.H & 1) && !(L.W & 63))                          // face_encoder_blocks.1.0 / 2.0
+            rc = convs2d_launch(L.s2d, io.x, L.in_ld, L.in_coff, n, L.H, L.W, io.y, L.out_ld, L.out_coff, on_aux ? e->aux : s, &err);
         else if (e->a3 && (knob(K_AUDIO0) & 2) && L.special == 3 && L.H == 80 && L.W == 16)      // audio_encoder.3
             rc = audio3_launch(e->a3, io.x, L.in_ld, L.in_coff, n, io.y, L.out_ld, L.out_coff, on_aux ? e->aux : s, &err);
         else if (e->a0 && (knob(K_AUDIO0) & 1) && L.in_buf == B_MEL)  // audio_encoder.0: reads the float32 mel windows of the pass's table itself

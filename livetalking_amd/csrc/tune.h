@@ -92,6 +92,9 @@ enum Knob {
     K_AUDIO0,             // LTK_AUDIO0         bit 0: audio_encoder.0 (1 -> 32 channels on the 80 x 16 mel window) as a VALU kernel that reads the float32 mel
                           //                    windows itself (conv7_mfma.hip audio0_kernel: no pack_mel launch, no 8-channel padded MFMA launch); bit 1: the
                           //                    stride-(3, 1) layer audio_encoder.3 on MFMAs fed straight from global memory (audio3_kernel); default 3; 0: pack_mel + conv_mfma_kernel
+    K_CONV_S2D,           // LTK_CONV_S2D       1 (default): the face encoder's shallow stride-2 layers (face_encoder_blocks.1.0 / 2.0: 16 -> 32 @256^2, 32 -> 64 @128^2) on
+                          //                    convs2d_kernel (conv7_mfma.hip: a wave = one output row x 32 output channels, weights in registers, pixel operands
+                          //                    straight from global memory, no LDS); 0: conv_mfma_kernel (first generation)
     K_COUNT
 };
 

@@ -194,6 +194,54 @@ def test_audio_first_layers_vs_generic_path(engine, golden_dir):
 
 
 @pytest.mark.gpu
+def test_convs2d_kernel_vs_first_generation_kernel(engine, golden_dir):
+    """Knob CONV_S2D (default 1, conv7_mfma.hip convs2d_kernel): the face encoder's shallow stride-2 layers face_encoder_blocks.1.0 / 2.0
+    (wav2lip_v2.py:15,19) with the pixel operands of their MFMAs straight from global memory, against the first-generation kernel: each
+    layer's tap holds the oracle's to the per-layer tolerance either way; frames of 1-, 5- and 16-frame calls differ by <= 1 LSB."""
+    from livetalking_amd.engine import Engine
+    g, frames, faces, coords, feats = _golden_inputs(golden_dir)
+    B, index = int(g["batch"]), int(g["index"])
+    sd = {k: torch.from_numpy(v) for k, v in synth.wav2lip_state_dict(int(g["weight_seed"])).items()}
+    mel_t, img_t = plugin_oracle.pack_inputs(faces, index, B, feats)
+    taps = {}
+    wav2lip_oracle.forward(sd, mel_t, img_t, taps)
+    names = ("face_encoder_blocks.1.0", "face_encoder_blocks.2.0", "face_encoder_blocks.2.3")
+    rel = {}
+    try:
+        for on in (1, 0):
+            Engine.set_knob("CONV_S2D", on)
+            engine.debug_capture(True)
+            engine.wav2lip_forward_host(mel_t.numpy().reshape(B, 80, 16), img_t.numpy())
+            for name in names:
+                r = taps[name].numpy()
+                o = engine.debug_get(name, r.shape)
+                rel[on, name] = float(np.linalg.norm(o - r) / np.linalg.norm(r))
+                print(f"[convs2d={on}] {name} rel_l2={rel[on, name]:.3e} maxabs={float(np.abs(o - r).max()):.3e}")
+            engine.debug_capture(False)
+    finally:
+        engine.debug_capture(False)
+        Engine.set_knob("CONV_S2D", 1)
+    for name in names:
+        assert rel[1, name] <= 2e-3 and rel[1, name] <= rel[0, name] * 1.5 + 1e-5, name
+    aid = engine.register_avatar(faces, frames, coords)
+    try:
+        for n in (1, 5, 16):
+            mel = torch.from_numpy(np.stack([feats[i % len(feats)] for i in range(n)]).astype(np.float32)).cuda()
+            out = {}
+            for on in (1, 0):
+                Engine.set_knob("CONV_S2D", on)
+                pred = torch.zeros(n, 256, 256, 3, dtype=torch.uint8, device="cuda")
+                engine.wav2lip_infer([(aid, index + 3, n, mel.data_ptr(), pred.data_ptr())])
+                out[on] = pred.cpu().numpy()
+            d = np.abs(out[1].astype(np.int32) - out[0].astype(np.int32))
+            print(f"[convs2d 1 vs 0, {n} frames] max diff {d.max()} LSB, differing bytes {float((d != 0).mean()):.2e}")
+            assert d.max() <= 1 and float((d != 0).mean()) < 0.10
+    finally:
+        Engine.set_knob("CONV_S2D", 1)
+        engine.release_avatar(aid)
+
+
+@pytest.mark.gpu
 def test_fused_head_vs_separate_head(engine, golden_dir):
     """output_block conv 80->32 + 1x1 head + sigmoid in ONE launch (knob HEAD_FUSED, the default) against the two-launch
     path (32-channel map rounded to fp16 in between): the fused epilogue keeps fp32, so frames may differ by the
