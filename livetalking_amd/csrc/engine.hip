@@ -1512,7 +1512,10 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
                 if (k == slot) continue;
                 const ltk_engine::PfSlot& sl = e->pfs[k];
                 if (sl.valid && now - sl.filled_at < kPfStale) continue;
-                if (!victim || sl.stamp < e->pfs[victim].stamp) victim = k;
+                // ... and among the free ones the MOST recently used: a lone session then alternates between two slots (five graphs: captured
+                // within its first six calls) instead of walking all sixteen (33 graphs, each launch variant run eagerly once and captured
+                // once: the first ~35 calls of a session - all of a 20-step benchmark run - paid for captures, 4.5 % on its timed line)
+                if (!victim || sl.stamp > e->pfs[victim].stamp) victim = k;
             }
             if (victim) {
             ltk_engine::PfSlot& sl = e->pfs[victim];
