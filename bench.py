@@ -1063,7 +1063,7 @@ def main():
                         "HBM bytes per conv-stack pass")
         if not args.no_also:
             mt = run_sub("musetalk-both", ["--batch", str(args.batch)])
-            also = [run_sub("also-w2l16", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "3", "--paced", "4"])]
+            also = [run_sub("also-w2l16", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "12", "--paced", "4"])]
             also += mt if isinstance(mt, list) else [mt]
             tags = ["configs[3] per-GPU share: 16 wav2lip256 sessions on one GPU (16 session threads, continuous batching)",
                     "configs[2]: MuseTalk, 1 session",
@@ -1080,7 +1080,7 @@ def main():
                 for a, sb in zip(also, subs):
                     if sb is not None and isinstance(a, dict) and isinstance(a.get("roofline"), dict):
                         add_traffic(a["roofline"], *sb)
-            fc = run_sub("also-w2l16-facecache", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "3", "--paced", "4"],
+            fc = run_sub("also-w2l16-facecache", ["--sessions", "16", "--batch", str(args.batch), "--steps", "10", "--warmup", "12", "--paced", "4"],
                          env={"LTK_FACE_CACHE": "1"})
             if isinstance(fc, dict):
                 fc["baseline_config"] = ("configs[3] per-GPU share in the opt-in deployment mode LTK_FACE_CACHE=1 (not a benchmark line: the face "
