@@ -455,7 +455,7 @@ def run_musetalk(args, ranks: Ranks, shared=None):
     drv = SessionThreads(sessions, [d_feat[s] for s in range(S)], stride=3)
     # untimed priming in front of the W warm-up steps: the MuseTalk pass is captured as a hipGraph the second time a frame count is
     # seen, and a capture inside the timed region would be timed
-    PRIME = 3
+    PRIME = 3 if S == 1 else 8      # several session threads: their coalesced calls come in sizes 16 .. 16 S, each captured on its second sighting
     for i in range(PRIME):
         drv.step(i)
     for i in range(args.warmup):
