@@ -1507,7 +1507,7 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             // slots the surplus sessions simply run whole passes instead of evicting each other.
             constexpr double kPfStale = 1.5;
             const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            int victim = 0;
+            int victim = 0, busy = 0;
             for (int k = 1; k <= ltk_engine::kPfSlots; ++k) {
                 if (k == slot) continue;
                 const ltk_engine::PfSlot& sl = e->pfs[k];
@@ -1515,8 +1515,13 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
                 // ... and among the free ones the MOST recently used: a lone session then alternates between two slots (five graphs: captured
                 // within its first six calls) instead of walking all sixteen (33 graphs, each launch variant run eagerly once and captured
                 // once: the first ~35 calls of a session - all of a 20-step benchmark run - paid for captures, 4.5 % on its timed line)
+                // (... whose last reader is done: with calls of several sessions in flight the most recently consumed slot may still be read by
+                // another session's pass, and a prefetch into it would wait for that pass instead of running beside it)
+                if (sl.read && hipEventQuery(sl.ev_read) != hipSuccess) { if (!busy || sl.stamp > e->pfs[busy].stamp) busy = k; continue; }
                 if (!victim || sl.stamp > e->pfs[victim].stamp) victim = k;
             }
+            (void)hipGetLastError();          // hipEventQuery's hipErrorNotReady is not an error
+            if (!victim) victim = busy;
             if (victim) {
             ltk_engine::PfSlot& sl = e->pfs[victim];
             sl.valid = false;
