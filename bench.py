@@ -374,7 +374,7 @@ def run_wav2lip(args, ranks: Ranks):
                        "parallelism": f"session-sharded x{ranks.world} (no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 5), "traffic": None,
-                         "kernel": "conv3_kernel + conv_mfma_kernel + rowgemm / rowconv_kernel (the 54 conv/convT layers + fused head = one pass)",
+                         "kernel": "conv3_kernel + conv7 / audio0 / audio3 / convs2d_kernel + rowgemm / rowconv_kernel (the 54 conv/convT layers + fused head = one pass)",
                          "pass_ms": round(conv_ms, 4),
                          # the stable cross-round figure: the pass with every call running the whole network (rounds 1-4 measured exactly this)
                          "conv_stack_ms": round(conv_ms_whole if conv_ms_whole else conv_ms, 4),
@@ -900,7 +900,7 @@ def measure_traffic(sub, extra, passes, conv_only):
                 continue
             if "conv3_head_kernel" in k:
                 heads[counter] = heads.get(counter, 0) + int(cnt)       # one fused-head launch per Wav2Lip pass: the pass count of the run
-            if conv_only and "conv" not in k and "rowgemm" not in k:       # conv7 / conv3 / conv_mfma / rowconv + rowgemm: the layer kernels
+            if conv_only and "conv" not in k and "rowgemm" not in k and "audio0_kernel" not in k and "audio3_kernel" not in k:       # conv7 / conv3 / convs2d / conv_mfma / rowconv + rowgemm / audio0 + audio3: the layer kernels
                 continue
             if not conv_only and ("__amd_rocclr" in k or "debug" in k):
                 continue

@@ -98,7 +98,7 @@ def main():
             for r in seg:
                 n = short(r[0])
                 f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{streams.index(r[8])} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
-                if a.all_kernels or "conv" in n or "rowgemm" in n:
+                if a.all_kernels or "conv" in n or "rowgemm" in n or "audio0_kernel" in n or "audio3_kernel" in n:
                     conv_us += (r[2] - r[1]) / 1e3
             f.write(f"# first start .. last end: {(max(r[2] for r in seg)-t0)/1e3:.1f} us; sum of {'all' if a.all_kernels else 'conv'} kernels "
                     f"{conv_us:.1f} us; {len(seg)} launches on {len(streams)} stream(s)\n")
@@ -107,7 +107,7 @@ def main():
     write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
     sq = counters(os.path.join(sub("pmc_sq"), "r_results.db"))
     l2 = counters(os.path.join(sub("pmc_l2"), "r_results.db"))
-    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else k.startswith(("conv", "rowconv", "rowgemm")))]
+    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else (k.startswith(("conv", "rowconv", "rowgemm")) or "audio0_kernel" in k or "audio3_kernel" in k))]
     blits = {k: stats[k][0] for k in stats if "__amd_rocclr" in k}
     rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
     wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024
