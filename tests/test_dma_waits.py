@@ -58,3 +58,38 @@ def test_dma_ring_kernels_wait_for_their_copies_before_the_barrier(tmp_path):
             assert waits[-1], f"{name}: the chunk-loop barrier has no vmcnt wait in front of it: {waits}"
         checked += 1
     assert checked >= 40, f"only {checked} DMA kernels found: the scan no longer sees the instantiations"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_direct_operand_kernels_issue_their_loads_before_the_first_mfma(tmp_path):
+    """audio3_kernel / convs2d_kernel (conv7_mfma.hip, round 6) feed their MFMAs straight from global memory; what makes them faster
+    than the LDS-staged launches they replaced is that ALL operand loads of a tile are in flight before its first MFMA (a
+    sched_barrier between the phases).  Left to its own schedule hipcc pairs every few loads with their MFMAs - as many serial
+    round trips, and exactly as slow as the old launches (profiles/r06_audio0_ab.txt) - without any test failing.  Likewise
+    audio0_kernel's nine mel loads must be issued back to back, not as nine load / wait pairs."""
+    funcs = _functions("conv7_mfma.hip", tmp_path)
+
+    def loads_before_first(lines, what, load="global_load_dwordx4"):
+        n = 0
+        for l in lines:
+            if what in l:
+                return n
+            if load in l:
+                n += 1
+        raise AssertionError(f"no {what} found")
+
+    seen = 0
+    for name, lines in funcs.items():
+        if "audio3_kernel" in name:
+            assert loads_before_first(lines, "v_mfma") >= 54, name           # 18 pixel operands + 36 weight operands
+            seen += 1
+        elif "convs2d_kernel" in name:
+            cb = 2 if "ILi2E" in name else 1
+            assert loads_before_first(lines, "v_mfma") >= 18 * cb, name      # 9 CB weight operands + 9 CB pixel operands of the first tile
+            seen += 1
+        elif "audio0_kernel" in name:
+            first_wait = next(i for i, l in enumerate(lines) if "s_waitcnt" in l and "vmcnt" in l)
+            issued = sum(1 for l in lines[:first_wait] if "global_load_dword " in l or "global_load_dword\t" in l or l.strip().startswith("global_load_dword v"))
+            assert issued >= 9, f"{name}: {issued} mel loads in front of the first vmcnt wait"
+            seen += 1
+    assert seen == 4, f"{seen} of the 4 kernels found"
