@@ -1517,6 +1517,7 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
                 // once: the first ~35 calls of a session - all of a 20-step benchmark run - paid for captures, 4.5 % on its timed line)
                 // (... whose last reader is done: with calls of several sessions in flight the most recently consumed slot may still be read by
                 // another session's pass, and a prefetch into it would wait for that pass instead of running beside it)
+                if (knob(K_PF_LRU)) { if (!victim || sl.stamp < e->pfs[victim].stamp) victim = k; continue; }      // (A/B: the rule this replaced)
                 if (sl.read && hipEventQuery(sl.ev_read) != hipSuccess) { if (!busy || sl.stamp > e->pfs[busy].stamp) busy = k; continue; }
                 if (!victim || sl.stamp > e->pfs[victim].stamp) victim = k;
             }

@@ -95,6 +95,8 @@ enum Knob {
     K_CONV_S2D,           // LTK_CONV_S2D       1 (default): the face encoder's shallow stride-2 layers (face_encoder_blocks.1.0 / 2.0: 16 -> 32 @256^2, 32 -> 64 @128^2) on
                           //                    convs2d_kernel (conv7_mfma.hip: a wave = one output row x 32 output channels, weights in registers, pixel operands
                           //                    straight from global memory, no LDS); 0: conv_mfma_kernel (first generation)
+    K_PF_LRU,             // LTK_PF_LRU         0 (default): a prefetch goes into the MOST recently used free slot (a lone session alternates between two slots: 7 launch
+                          //                    graphs); 1: least recently used (round 6's first rule: a lone session walks all 16 slots, 33 graphs; kept for A/Bs)
     K_COUNT
 };
 

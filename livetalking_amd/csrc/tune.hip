@@ -52,6 +52,7 @@ const KnobDef kDefs[K_COUNT] = {
     {"LTK_GN_COOP", 1},
     {"LTK_AUDIO0", 3},
     {"LTK_CONV_S2D", 1},
+    {"LTK_PF_LRU", 0},
 };
 
 std::atomic<int> g_val[K_COUNT];     // knob_set (tests, tuners) may run beside launch threads reading the table
