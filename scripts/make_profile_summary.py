@@ -107,7 +107,7 @@ def main():
     write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
     sq = counters(os.path.join(sub("pmc_sq"), "r_results.db"))
     l2 = counters(os.path.join(sub("pmc_l2"), "r_results.db"))
-    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else (k.startswith(("conv", "rowconv", "rowgemm")) or "audio0_kernel" in k or "audio3_kernel" in k))]
+    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else (k.startswith(("conv", "rowconv", "rowgemm")) or "convs2d_kernel" in k or "audio0_kernel" in k or "audio3_kernel" in k))]       # (un-templated / mangled names do not start with "conv")
     blits = {k: stats[k][0] for k in stats if "__amd_rocclr" in k}
     rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
     wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024
