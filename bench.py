@@ -865,6 +865,12 @@ def cpu_baseline(batch: int):
             "b1": {"value": round(f1, 3), "unit": "frames/s", "sample": "same, B=1 (BASELINE.json configs[0])"}}
 
 
+def is_layer_kernel(name):
+    """A kernel that runs one of the 54 conv / convT layers of a Wav2Lip pass (or its fused head): conv7 / conv3 / convs2d / conv_mfma /
+    rowconv + rowgemm / audio0 + audio3 - templated kernels print demangled ("conv3_kernel<...>"), the others mangled ("_ZN3ltk14convs2d_kernel...")."""
+    return "conv" in name or "rowgemm" in name or "audio0_kernel" in name or "audio3_kernel" in name
+
+
 def measure_traffic(sub, extra, passes, conv_only):
     """HBM bytes per pass from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
     SEPARATE --pmc passes (TCC slots), FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), KiB units.  Each pass
@@ -900,7 +906,7 @@ def measure_traffic(sub, extra, passes, conv_only):
                 continue
             if "conv3_head_kernel" in k:
                 heads[counter] = heads.get(counter, 0) + int(cnt)       # one fused-head launch per Wav2Lip pass: the pass count of the run
-            if conv_only and "conv" not in k and "rowgemm" not in k and "audio0_kernel" not in k and "audio3_kernel" not in k:       # conv7 / conv3 / convs2d / conv_mfma / rowconv + rowgemm / audio0 + audio3: the layer kernels
+            if conv_only and not is_layer_kernel(k):
                 continue
             if not conv_only and ("__amd_rocclr" in k or "debug" in k):
                 continue

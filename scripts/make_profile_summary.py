@@ -20,6 +20,12 @@ import re
 import sqlite3
 
 
+def is_layer_kernel(name):
+    """Same predicate as bench.py's (tests/test_abi_and_host.py holds the two together): the kernels that run the conv / convT layers of a
+    Wav2Lip pass.  Templated kernels are listed demangled ("conv3_kernel<...>"), the others mangled ("_ZN3ltk14convs2d_kernel...")."""
+    return "conv" in name or "rowgemm" in name or "audio0_kernel" in name or "audio3_kernel" in name
+
+
 def short(name):
     name = re.sub(r"\(.*$", "", name)
     return name.replace("void ", "").replace("ltk::", "")
@@ -98,7 +104,7 @@ def main():
             for r in seg:
                 n = short(r[0])
                 f.write(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} s{streams.index(r[8])} {r[3]//max(r[4],1):6d} {r[5]:7d} {n}\n")
-                if a.all_kernels or "conv" in n or "rowgemm" in n or "audio0_kernel" in n or "audio3_kernel" in n:
+                if a.all_kernels or is_layer_kernel(n):
                     conv_us += (r[2] - r[1]) / 1e3
             f.write(f"# first start .. last end: {(max(r[2] for r in seg)-t0)/1e3:.1f} us; sum of {'all' if a.all_kernels else 'conv'} kernels "
                     f"{conv_us:.1f} us; {len(seg)} launches on {len(streams)} stream(s)\n")
@@ -107,7 +113,7 @@ def main():
     write = counters(os.path.join(sub("pmc_write"), "r_results.db"))
     sq = counters(os.path.join(sub("pmc_sq"), "r_results.db"))
     l2 = counters(os.path.join(sub("pmc_l2"), "r_results.db"))
-    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else (k.startswith(("conv", "rowconv", "rowgemm")) or "convs2d_kernel" in k or "audio0_kernel" in k or "audio3_kernel" in k))]       # (un-templated / mangled names do not start with "conv")
+    conv = [k for k in stats if (("__amd_rocclr" not in k) if a.all_kernels else is_layer_kernel(k))]
     blits = {k: stats[k][0] for k in stats if "__amd_rocclr" in k}
     rd = sum(fetch.get(k, {}).get("FETCH_SIZE", (0, 0))[0] for k in conv) * 1024 * 2
     wr = sum(write.get(k, {}).get("WRITE_SIZE", (0, 0))[0] for k in conv) * 1024

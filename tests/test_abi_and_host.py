@@ -510,3 +510,29 @@ def test_tile_table_entries_name_existing_layers_and_legal_tiles():
     for name, bucket, pxw, nbt, ks in entries:
         assert name in layers, name
         assert int(bucket) in range(5) and int(pxw) in (0, 1, 2, 4) and int(nbt) in (0, 1, 2) and 0 <= int(ks) <= 32
+
+
+def test_profile_kernel_filters_agree_on_the_recorded_kernel_names():
+    """bench.py's live PMC traffic sum and scripts/make_profile_summary.py's per-kernel tables select "the layer kernels of a Wav2Lip
+    pass" by name; un-templated kernels are listed under their mangled names (round 6: convs2d_kernel's rows were dropped by a
+    startswith("conv") test).  Both predicates over every kernel name of the committed traces: equal, every layer kernel in, helpers out."""
+    import csv
+    import importlib.util
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_profile_summary", os.path.join(root, "scripts", "make_profile_summary.py"))
+    mps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mps)
+    names = set()
+    for f in ("r06_w2l_kernel_stats.csv", "r06_w2l256_kernel_stats.csv"):
+        with open(os.path.join(root, "profiles", f)) as fh:
+            rows = [r for r in csv.reader(l for l in fh if not l.startswith("#"))]
+        names |= {r[0] for r in rows[1:]}
+    assert len(names) > 15
+    for n in names:
+        assert bench.is_layer_kernel(n) == mps.is_layer_kernel(n), n
+    layer = {n for n in names if bench.is_layer_kernel(n)}
+    for must in ("conv7_kernel", "conv3_kernel", "conv3_head_kernel", "convs2d_kernel", "audio0_kernel", "audio3_kernel", "rowconv_kernel", "rowgemm_kernel"):
+        assert any(must in n for n in layer), must
+    for n in names - layer:                  # what stays out: torch's fills, the runtime's blits, table uploads, the test-hook head
+        assert "ltk" not in n or any(h in n for h in ("upload", "pack", "head_kernel", "paste", "mel")), n
