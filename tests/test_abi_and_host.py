@@ -536,3 +536,27 @@ def test_profile_kernel_filters_agree_on_the_recorded_kernel_names():
         assert any(must in n for n in layer), must
     for n in names - layer:                  # what stays out: torch's fills, the runtime's blits, table uploads, the test-hook head
         assert "ltk" not in n or any(h in n for h in ("upload", "pack", "head_kernel", "paste", "mel")), n
+
+
+def test_kernel_resources_script_follows_the_makefile():
+    """scripts/kernel_resources.py / isa_spill_report.py recompile the sources device-only: their flags must be the Makefile's
+    (a per-file flag such as -amdgpu-mfma-vgpr-form changes the register allocation they report)."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    with open(os.path.join(root, "livetalking_amd", "csrc", "Makefile")) as f:
+        mk = f.read()
+    base = re.search(r"^CXXFLAGS\s*=\s*(.+)$", mk, re.M).group(1).replace("$(ARCH)", re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)).split()
+    assert kr.BASE == base
+    extra = {}
+    for objs, flags in re.findall(r"^([\w. ]+\.o):\s*CXXFLAGS\s*\+=\s*(.+)$", mk, re.M):
+        for o in objs.split():
+            extra.setdefault(o.replace(".o", ".hip"), []).extend(flags.split())
+    assert kr.EXTRA == extra
+    assert set(kr.makefile_sources()) >= set(extra) and len(kr.makefile_sources()) == 10
+    # the name shortener on the two kinds of names the compiler's remarks carry
+    assert kr.pretty("_ZN3ltk14convs2d_kernelILi2EEEvPKDF16_ii", "_ZN3ltk14convs2d_kernelILi2EEEvPKDF16_ii") == "ltk::convs2d_kernel<2>"
+    assert kr.pretty("x", "void ltk::conv7_kernel<true>(ltk::C7Args, ltk::FacePtrs const*)") == "ltk::conv7_kernel<true>"
