@@ -56,7 +56,8 @@ def report(name, body):
     mf = sorted(((y - x, x, y) for x, y in loops if any("v_mfma" in l for l in body[x:y + 1])))
     total = sum(bool(SPILL.search(l)) for l in body)
     if not mf:
-        return f"{pretty(name, name):<46} no MFMA loop; spill instructions in the kernel: {total}"
+        nm = sum("v_mfma" in l for l in body)
+        return f"{pretty(name, name):<46} no MFMA loop ({nm} MFMAs in straight-line code); spill instructions in the kernel: {total}"
     _, x, y = mf[0]
     ins, nm, sp = count(x, y)
     outer = next(((a, b) for _, a, b in mf[1:] if a <= x and b >= y and count(a, b)[1] >= nm and (b - a) > 2 * (y - x)), None)
@@ -69,6 +70,7 @@ def main():
     srcs = sys.argv[1:] or ["conv3_mfma.hip", "conv_mfma.hip"]
     print("#")
     print("# scripts/isa_spill_report.py " + " ".join(srcs) + ": spill instructions (v_readlane / v_writelane / scratch_load / scratch_store) by loop level")
+    print("# (lane moves a kernel issues on purpose - cross-lane reductions - count too: kernel_resources.py's spill columns say which kernels spill at all)")
     for s in srcs:
         lines = asm_of(s)
         names = [n for n, _ in kernels(lines)]
