@@ -325,6 +325,7 @@ struct ltk_engine {
     struct SoloSeq { int avatar = -1, next = -1, nf = 0; unsigned long stamp = 0; };
     SoloSeq solo_seq[2 * kPfSlots];
     unsigned long pf_hits = 0, pf_misses = 0, pf_issued = 0;
+    std::atomic<bool> pf_fail_logged{false};       // a prefetch that could not be launched is reported once (the call itself succeeds)
     // LTK_INFER_TIMING=1 (measurement): host time of ltk_wav2lip_infer by phase, printed when the engine is destroyed
     double tm_prep = 0, tm_launch = 0, tm_pf = 0, tm_wait = 0;
     unsigned long tm_calls = 0;
@@ -1531,12 +1532,17 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
             for (int i = 0; i < total; ++i) nx.p[i] = a.d_face + (size_t)mirror_index(a.n, first + total + i) * 256 * 256 * 3;
             sl.hold = hold[0];                  // (a previous prefetch into this slot is behind us on aux2: its bank may go now)
             launch_upload_tables(&nx, nullptr, nullptr, total, e->d_tab_next, e->aux2);
-            rc = launch_prefetch(e, total, victim);
-            if (!rc) {
+            // a prefetch that cannot be launched does not fail the call: this call's pass is already enqueued and complete without it (returning
+            // an error here would hand the caller an error while the pass still writes its frames); the session's next call misses and runs whole
+            if (launch_prefetch(e, total, victim) == 0) {
                 ++e->pf_issued;
                 sl.valid = true; sl.avatar = reqs[0].avatar; sl.first = first + total; sl.nf = total; sl.epoch = knob_epoch();
                 sl.stamp = ++e->pf_clock;
                 sl.filled_at = now;
+            } else {
+                (void)hipGetLastError();
+                if (!e->pf_fail_logged.exchange(true))
+                    fprintf(stderr, "ltk: prefetch of %d frames could not be launched (%s); such calls run whole passes\n", total, g_err.c_str());
             }
             }
         }
