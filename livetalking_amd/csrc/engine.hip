@@ -1561,6 +1561,8 @@ int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* st
     if (!rc) {
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
+    } else {
+        (void)hipStreamSynchronize(e->compute);         // an error behind launches: nothing of this call may still be writing the caller's buffers when it returns
     }
     if (timing) {
         const auto tp4 = std::chrono::steady_clock::now();
@@ -2242,6 +2244,8 @@ int ltk_musetalk_infer(ltk_engine* e, const ltk_mt_req* reqs, int nreq, void* st
         if (stream) { if (hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) rc = fail(LTK_E_HIP, "hipStreamWaitEvent failed"); }
         if (hipEventSynchronize(done) != hipSuccess) rc = fail(LTK_E_HIP, "hipEventSynchronize failed");
         if (!rc && mt_gn_error(e->mt)) rc = fail(LTK_E_HIP, std::string("musetalk: ") + mt_graph_error(e->mt));
+    } else {
+        (void)hipStreamSynchronize(e->compute);         // (as in ltk_wav2lip_infer: no error return with this call's launches still in flight)
     }
     return rc;
 }
