@@ -91,7 +91,10 @@ int ltk_mel_step(ltk_engine* e, const float* pcm, int n_samples, const int32_t* 
  * sessions at once: bank gather + lower-half mask + 6-channel pack, the 55
  * conv/convT layers of Wav2Lip.forward (wav2lip_v2.py:123-163), sigmoid*255 and
  * the uint8 truncation paste_back_frame applies (wav2lip_avatar.py:138,145).
- * Each request's frames land in its own d_pred.  Returns when they are ready. */
+ * Each request's frames land in its own d_pred.  Returns when they are ready;
+ * an error return likewise leaves none of the call's launches in flight (the
+ * caller may free d_pred / d_mel at once), and a face-encoder prefetch for the
+ * session's NEXT call (knob PREFETCH) that cannot be launched is not an error. */
 int ltk_wav2lip_infer(ltk_engine* e, const ltk_w2l_req* reqs, int nreq, void* stream);
 
 /* avatars/wav2lip_avatar.py:141-147 LipReal.paste_back_frame: bilinear-resize
