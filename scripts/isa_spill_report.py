@@ -4,7 +4,8 @@
 scripts/kernel_resources.py lists which kernels spill SGPRs into VGPR lanes (v_writelane / v_readlane) or VGPRs into scratch; what that
 costs depends on WHERE the spill code runs.  For every kernel of the given sources this prints its innermost loop that contains MFMAs
 (smallest backward-branch range with a v_mfma in it) - instructions, MFMAs - and the spill instructions inside that loop, inside the
-next enclosing MFMA loop (one work item of the persistent conv3 kernels) and in the whole kernel.
+next enclosing MFMA loop (one work item of the persistent conv3 kernels) and in the whole kernel; and what the innermost loop waits on:
+barriers, waits for ALL outstanding vector-memory loads (vmcnt(0)), LDS reads and LDS-DMA loads.
 
     python scripts/isa_spill_report.py conv3_mfma.hip conv_mfma.hip >> profiles/rNN_kernel_resources.txt
 """
@@ -53,6 +54,11 @@ def report(name, body):
     def count(x, y):
         seg = body[x:y + 1]
         return (sum(bool(INSTR.match(l)) for l in seg), sum("v_mfma" in l for l in seg), sum(bool(SPILL.search(l)) for l in seg))
+
+    def sync(x, y):          # what makes a wave wait inside the loop: barriers, waits for ALL outstanding vector-memory loads, LDS reads / DMA issues
+        seg = body[x:y + 1]
+        return (sum("s_barrier" in l for l in seg), sum(bool(re.search(r"s_waitcnt\s+.*vmcnt\(0\)", l)) for l in seg),
+                sum(bool(re.search(r"\sds_read|\sds_load", l)) for l in seg), sum(bool(re.search(r"global_load_lds|buffer_load.* lds", l)) for l in seg))
     mf = sorted(((y - x, x, y) for x, y in loops if any("v_mfma" in l for l in body[x:y + 1])))
     total = sum(bool(SPILL.search(l)) for l in body)
     if not mf:
@@ -62,7 +68,9 @@ def report(name, body):
     ins, nm, sp = count(x, y)
     outer = next(((a, b) for _, a, b in mf[1:] if a <= x and b >= y and count(a, b)[1] >= nm and (b - a) > 2 * (y - x)), None)
     o = count(*outer) if outer else None
-    return (f"{pretty(name, name):<46} innermost MFMA loop: {ins:>4} instructions, {nm:>3} MFMAs, {sp:>2} spill instructions | "
+    nb, nw, nds, ndma = sync(x, y)
+    return (f"{pretty(name, name):<46} innermost MFMA loop: {ins:>4} instructions, {nm:>3} MFMAs, {sp:>2} spill instructions, "
+            f"{nb} s_barrier, {nw} vmcnt(0) waits, {nds:>3} LDS reads, {ndma:>2} LDS-DMA loads | "
             + (f"enclosing loop: {o[0]:>5} instructions, {o[2]:>3} spill instructions | " if o else "") + f"whole kernel: {total}")
 
 
